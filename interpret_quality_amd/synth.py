@@ -1,0 +1,99 @@
+"""Deterministic synthetic inputs: point clouds, FPS-free helpers and reference-format weights.
+
+No datasets or checkpoints exist offline (SURVEY.md §8c limits), so every test, the golden
+generator and bench.py draw their inputs from here.  Recipes follow SURVEY.md §8(d):
+
+* cloud ``i``: ``np.random.default_rng(1000 + i)``, 1024 points uniform in the unit ball, then
+  centred and scaled to max-norm 1 the way the reference's ShapeNet loader does
+  (final_data_shapley.py:155-157), float32; label ``i % 10``.
+* weights: one PCG64 stream per parameter, keyed by ``crc32(parameter name)`` so that a tensor's
+  values never depend on which other tensors exist.  Keys and shapes are those of the reference's
+  ``state_dict()`` (models/pointnet.py:11-115), i.e. what tools/final_util.py:236-262 loads.
+"""
+import zlib
+
+import numpy as np
+
+NUM_CLASSES = 10
+
+
+def make_cloud(i, num_points=1024):
+    """Synthetic cloud ``i`` -> ((num_points, 3) float32, int label)."""
+    rng = np.random.default_rng(1000 + i)
+    direction = rng.standard_normal((num_points, 3))
+    direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    radius = rng.random((num_points, 1)) ** (1.0 / 3.0)
+    pts = (direction * radius).astype(np.float32)
+    pts = pts - np.expand_dims(np.mean(pts, axis=0), 0)
+    dist = np.max(np.sqrt(np.sum(pts ** 2, axis=1)), 0)
+    pts = pts / dist
+    return pts.astype(np.float32), i % NUM_CLASSES
+
+
+def make_orders(num_samples, num_regions, seed=1):
+    """Permutations exactly as the reference draws them (final_shapley_value.py:59-72):
+    global NumPy RNG seeded by ``set_random`` (tools/final_util.py:113-120), one
+    ``np.random.permutation`` per sample."""
+    np.random.seed(seed)
+    rows = [np.random.permutation(np.arange(0, num_regions, 1)) for _ in range(num_samples)]
+    return np.stack(rows, axis=0).astype(np.int64)
+
+
+# --------------------------------------------------------------------------------------------
+# weights
+# --------------------------------------------------------------------------------------------
+
+def _rng_for(name, seed):
+    return np.random.Generator(np.random.PCG64([zlib.crc32(name.encode()), seed]))
+
+
+def _linear(sd, name, cout, cin, seed, conv, gain, bias_std=0.05):
+    w = _rng_for(name + ".weight", seed).standard_normal((cout, cin)) * (gain / np.sqrt(cin))
+    b = _rng_for(name + ".bias", seed).standard_normal((cout,)) * bias_std
+    sd[name + ".weight"] = w.astype(np.float32).reshape((cout, cin, 1) if conv else (cout, cin))
+    sd[name + ".bias"] = b.astype(np.float32)
+
+
+def _bn(sd, name, c, seed):
+    sd[name + ".weight"] = _rng_for(name + ".weight", seed).uniform(0.8, 1.2, (c,)).astype(np.float32)
+    sd[name + ".bias"] = (_rng_for(name + ".bias", seed).standard_normal((c,)) * 0.1).astype(np.float32)
+    sd[name + ".running_mean"] = (_rng_for(name + ".running_mean", seed).standard_normal((c,)) * 0.1).astype(np.float32)
+    sd[name + ".running_var"] = _rng_for(name + ".running_var", seed).uniform(0.5, 1.5, (c,)).astype(np.float32)
+    sd[name + ".num_batches_tracked"] = np.array(100, dtype=np.int64)
+
+
+def _stn(sd, prefix, k, seed):
+    g = np.sqrt(2.0)
+    _linear(sd, prefix + ".conv1", 64, k, seed, True, g)
+    _linear(sd, prefix + ".conv2", 128, 64, seed, True, g)
+    _linear(sd, prefix + ".conv3", 1024, 128, seed, True, g)
+    _linear(sd, prefix + ".fc1", 512, 1024, seed, False, g)
+    _linear(sd, prefix + ".fc2", 256, 512, seed, False, g)
+    # the regressed transform is identity + a moderate perturbation, as in a trained net
+    _linear(sd, prefix + ".fc3", k * k, 256, seed, False, 0.3 / np.sqrt(k), bias_std=0.02)
+    for j, c in enumerate((64, 128, 1024, 512, 256), start=1):
+        _bn(sd, "%s.bn%d" % (prefix, j), c, seed)
+
+
+def pointnet_state_dict(seed=0):
+    """Reference-keyed PointNetCls state dict (111 tensors) as numpy arrays."""
+    sd = {}
+    g = np.sqrt(2.0)
+    _stn(sd, "feat.stn", 3, seed)
+    _linear(sd, "feat.conv1", 64, 3, seed, True, g)
+    _linear(sd, "feat.conv2", 128, 64, seed, True, g)
+    _linear(sd, "feat.conv3", 1024, 128, seed, True, g)
+    for j, c in enumerate((64, 128, 1024), start=1):
+        _bn(sd, "feat.bn%d" % j, c, seed)
+    _stn(sd, "feat.fstn", 64, seed)
+    _linear(sd, "fc1", 512, 1024, seed, False, g)
+    _linear(sd, "fc2", 256, 512, seed, False, g)
+    _linear(sd, "fc3", NUM_CLASSES, 256, seed, False, 2.0)
+    _bn(sd, "bn1", 512, seed)
+    _bn(sd, "bn2", 256, seed)
+    return sd
+
+
+def to_torch(sd):
+    import torch
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}

@@ -1,0 +1,323 @@
+"""CPU ORACLE (test infrastructure, NOT product code).
+
+A plain-PyTorch/NumPy restatement of the reference's Shapley / multi-order-interaction hot path
+(SURVEY.md §8a).  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module; nothing under ``interpret_quality_amd/`` does.
+
+Parity status: PINNED.  ``tests/golden/gen_golden.py`` imports the reference itself from
+``/root/reference`` (never copied), runs it on the seeded inputs of
+``interpret_quality_amd/synth.py`` and commits the outputs under ``tests/golden/``;
+``tests/test_oracle_golden.py`` checks every function below against those vectors (bit-exact for
+indices and masks, <=1e-6 relative for floating point; in practice the CPU results are identical
+because the same ATen kernels run in the same order).
+
+Each function cites the reference lines (relative to /root/reference) it restates.  The code is
+deliberately written differently from the reference (vectorised masks, functional network with an
+explicit state dict) - it restates behaviour, it does not copy text.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5  # nn.BatchNorm1d default, models/pointnet.py:22-26
+
+
+# --------------------------------------------------------------------------------------------
+# geometry
+# --------------------------------------------------------------------------------------------
+
+def square_distance(src, dst):
+    """tools/final_util.py:134-147 - expanded form, cancellation included:
+    ``-2 src.dst^T`` then ``+= |src|^2`` then ``+= |dst|^2`` (that order)."""
+    b, n, _ = src.shape
+    m = dst.shape[1]
+    d = torch.matmul(src, dst.transpose(1, 2)) * -2
+    d = d + (src * src).sum(-1).reshape(b, n, 1)
+    d = d + (dst * dst).sum(-1).reshape(b, 1, m)
+    return d
+
+
+def farthest_point_sample(xyz, npoint):
+    """final_save_fps.py:10-31 (= models/pointnet2.py:45-68): start at index 0, running
+    min-distance, argmax with first-index ties.  xyz (B,N,3) -> (B,npoint) int64."""
+    b, n, _ = xyz.shape
+    out = torch.zeros(b, npoint, dtype=torch.long)
+    mind = torch.full((b, n), 1e10, dtype=xyz.dtype)
+    cur = torch.zeros(b, dtype=torch.long)
+    ar = torch.arange(b)
+    for i in range(npoint):
+        out[:, i] = cur
+        c = xyz[ar, cur, :].reshape(b, 1, 3)
+        d = ((xyz - c) ** 2).sum(-1)
+        mind = torch.where(d < mind, d, mind)
+        cur = torch.max(mind, -1)[1]
+    return out
+
+
+def cal_region_id(data, fps_index):
+    """final_shapley_value.py:20-35 - nearest FPS centre per point.  data (1,N,3) tensor,
+    fps_index (R,) -> (N,) int64 ndarray."""
+    idx = torch.as_tensor(fps_index, dtype=torch.long)
+    centres = data[:, idx, :]
+    return torch.argmin(square_distance(data, centres), dim=2).reshape(-1).numpy()
+
+
+def rotate_xyz(x, angle_tuple):
+    """final_rotate_center_enum_all.py:15-38 - R = Rx.Ry.Rz, returns x.R^T."""
+    tx, ty, tz = angle_tuple[0], angle_tuple[1], angle_tuple[2]
+    cx, cy, cz = torch.cos(tx), torch.cos(ty), torch.cos(tz)
+    sx, sy, sz = torch.sin(tx), torch.sin(ty), torch.sin(tz)
+    rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    r = torch.matmul(torch.matmul(rx, ry), rz)
+    return torch.matmul(x, r.expand(x.shape[0], 3, 3).permute(0, 2, 1))
+
+
+def translate_pc(data, trans):
+    """final_trans_center_enum_all.py:13-21."""
+    return data + trans
+
+
+def scale_pc(data, scale):
+    """final_scale_center_enum_all.py:14-22."""
+    return data * scale
+
+
+def generate_rotate_angle(angle_threshold=math.pi / 4, num=6):
+    """final_rotate_center_enum_all.py:41-58 - 6^3 grid, 'ij' order, float32."""
+    t = np.linspace(-angle_threshold, angle_threshold, num=num)
+    gx, gy, gz = np.meshgrid(t, t, t, indexing="ij")
+    g = np.stack([gx.reshape(-1), gy.reshape(-1), gz.reshape(-1)], axis=1)
+    return torch.tensor(g, dtype=torch.float32)
+
+
+def generate_trans_vector(threshold=0.5, num=6):
+    """final_trans_center_enum_all.py:24-43 - grid clipped to norm <= threshold (in float32)."""
+    t = np.linspace(-threshold, threshold, num=num)
+    gx, gy, gz = np.meshgrid(t, t, t, indexing="ij")
+    rows = []
+    for v in zip(gx.reshape(-1), gy.reshape(-1), gz.reshape(-1)):
+        tv = torch.tensor(list(v), dtype=torch.float32)
+        if torch.norm(tv) > threshold:
+            tv = tv / torch.norm(tv) * threshold
+        rows.append(tv)
+    return torch.stack(rows, dim=0)
+
+
+def generate_scale(lower=0.5, upper=2.0, num=30):
+    """final_scale_center_enum_all.py:25-31."""
+    return torch.from_numpy(np.linspace(start=lower, stop=upper, num=num)).float()
+
+
+# --------------------------------------------------------------------------------------------
+# PointNet forward (models/pointnet.py)
+# --------------------------------------------------------------------------------------------
+
+def _bn(x, sd, name):
+    return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"],
+                        sd[name + ".weight"], sd[name + ".bias"], False, 0.0, BN_EPS)
+
+
+def _conv(x, sd, name):
+    return F.conv1d(x, sd[name + ".weight"], sd[name + ".bias"])
+
+
+def _fc(x, sd, name):
+    return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
+
+
+def _stn(x, sd, p, k):
+    """models/pointnet.py:29-47 - STNkd.forward."""
+    h = F.relu(_bn(_conv(x, sd, p + ".conv1"), sd, p + ".bn1"))
+    h = F.relu(_bn(_conv(h, sd, p + ".conv2"), sd, p + ".bn2"))
+    h = F.relu(_bn(_conv(h, sd, p + ".conv3"), sd, p + ".bn3"))
+    h = torch.max(h, 2, keepdim=True)[0].reshape(-1, 1024)
+    h = F.relu(_bn(_fc(h, sd, p + ".fc1"), sd, p + ".bn4"))
+    h = F.relu(_bn(_fc(h, sd, p + ".fc2"), sd, p + ".bn5"))
+    h = _fc(h, sd, p + ".fc3")
+    h = h + torch.eye(k, dtype=h.dtype).reshape(1, k * k)
+    return h.reshape(-1, k, k)
+
+
+def pointnet_forward(sd, x):
+    """models/pointnet.py:64-89,109-115 - eval-mode PointNetCls.  x (B,3,N) float32 ->
+    (logits (B,10), trans_feat (B,64,64), crt_points (B,1024) int64)."""
+    trans = _stn(x, sd, "feat.stn", 3)
+    h = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)
+    h = F.relu(_bn(_conv(h, sd, "feat.conv1"), sd, "feat.bn1"))
+    trans_feat = _stn(h, sd, "feat.fstn", 64)
+    h = torch.bmm(h.transpose(2, 1), trans_feat).transpose(2, 1)
+    h = F.relu(_bn(_conv(h, sd, "feat.conv2"), sd, "feat.bn2"))
+    h = _bn(_conv(h, sd, "feat.conv3"), sd, "feat.bn3")
+    g, crt = torch.max(h, 2)
+    g = g.reshape(-1, 1024)
+    g = F.relu(_bn(_fc(g, sd, "fc1"), sd, "bn1"))
+    g = F.relu(_bn(_fc(g, sd, "fc2"), sd, "bn2"))  # dropout is identity in eval mode
+    return _fc(g, sd, "fc3"), trans_feat, crt
+
+
+class PointNetOracle:
+    """Callable with the reference module's call signature (returns the 3-tuple)."""
+
+    def __init__(self, state_dict):
+        self.sd = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v)))
+                   for k, v in state_dict.items()}
+
+    def __call__(self, x):
+        with torch.no_grad():
+            return pointnet_forward(self.sd, x)
+
+
+# --------------------------------------------------------------------------------------------
+# reward, masking, Shapley sampling (tools/final_common.py, final_shapley_value.py)
+# --------------------------------------------------------------------------------------------
+
+def get_reward(logits, lbl, softmax_type="modified"):
+    """tools/final_common.py:11-24.  'modified': z_y - logsumexp(z_{!=y}); 'normal':
+    log_softmax[y]."""
+    y = int(lbl[0])
+    if softmax_type == "normal":
+        return F.log_softmax(logits, dim=1)[:, y]
+    others = np.arange(logits.shape[1]) != y
+    return logits[:, y] - torch.logsumexp(logits[:, others], dim=1)
+
+
+def cal_reward(model, data, lbl, softmax_type="modified", is_pointnet=True):
+    """tools/final_common.py:26-43.  data (B',N,3) -> (v (B',), logits (B',C))."""
+    x = data.permute(0, 2, 1).contiguous()
+    out = model(x)
+    logits = out[0] if is_pointnet else out
+    return get_reward(logits, lbl, softmax_type), logits
+
+
+def shapley_masked_batch(data, center, orders, region_id):
+    """tools/final_common.py:46-61 and :88-89 (= final_shapley_value.py:74-88,141-142 for one
+    order).  Row ``o*(R+1)+i`` keeps the regions ``orders[o][:i]`` and collapses every other point
+    onto ``center``.  Vectorised; the reference does it with R*bs index assignments."""
+    orders = np.asarray(orders)
+    bs, r = orders.shape
+    n = data.shape[1]
+    pos = np.empty((bs, r), dtype=np.int64)
+    np.put_along_axis(pos, orders, np.broadcast_to(np.arange(r), (bs, r)), axis=1)
+    pos_pt = pos[:, np.asarray(region_id)]                      # (bs, N) position of each point's region
+    keep = pos_pt[:, None, :] < np.arange(r + 1)[None, :, None]  # (bs, R+1, N)
+    keep = torch.from_numpy(keep.reshape(bs * (r + 1), n, 1))
+    full = data.expand(bs * (r + 1), n, 3)
+    return torch.where(keep, full, center.reshape(1, 1, 3).expand_as(full)).clone()
+
+
+def cal_norm_factor(model, data, lbl, center, softmax_type="modified"):
+    """final_shapley_value.py:39-56 - v(N) - v(empty) as a python float."""
+    empty = center.reshape(1, 1, 3).expand(data.shape[0], data.shape[1], 3).clone()
+    v_n, _ = cal_reward(model, data, lbl, softmax_type)
+    v_0, _ = cal_reward(model, empty, lbl, softmax_type)
+    return (v_n - v_0).item()
+
+
+def generate_all_orders(num_samples_save, num_regions):
+    """final_shapley_value.py:59-72 - consumes the GLOBAL NumPy RNG (seed it with np.random.seed
+    first, as tools/final_util.py:113-120 does)."""
+    rows = [np.random.permutation(np.arange(0, num_regions, 1)).reshape((1, -1))
+            for _ in range(num_samples_save)]
+    return np.concatenate(rows, axis=0)
+
+
+def shap_sampling_all_regions_batch(model, data, lbl, region_id, orders, num_samples, bs,
+                                    num_regions, softmax_type="modified"):
+    """tools/final_common.py:64-103 - loop B body.  Returns (phi (R,) float64, logits
+    (num_samples*(R+1), C) float32).  ``num_samples // bs`` batches (remainder dropped, :78), fp32
+    ``dv`` added into a float64 accumulator in permutation order (:93-96), divided by num_samples
+    (:97)."""
+    center = torch.mean(data, dim=1).squeeze()
+    phi = np.zeros((num_regions,))
+    all_logits = []
+    with torch.no_grad():
+        for it in range(num_samples // bs):
+            chunk = orders[it * bs:(it + 1) * bs]
+            masked = shapley_masked_batch(data, center, chunk, region_id)
+            v, logits = cal_reward(model, masked, lbl, softmax_type)
+            all_logits.append(logits)
+            v = v.reshape(bs, num_regions + 1)
+            for o in range(bs):
+                dv = v[o, 1:] - v[o, :-1]
+                phi[chunk[o]] += dv.numpy()
+    phi /= num_samples
+    all_logits = torch.cat(all_logits, dim=0)
+    assert all_logits.shape[0] == num_samples * (num_regions + 1)  # tools/final_common.py:99
+    return phi, all_logits
+
+
+def shap_sampling_stage1(model, data, lbl, region_id, orders, num_regions, softmax_type="modified"):
+    """final_shapley_value.py:138-156 - loop A for one cloud: one order per forward; returns
+    (running sum (R,) float64, region_sv_all (S,R) float64)."""
+    center = torch.mean(data, dim=1).squeeze()
+    total = np.zeros((num_regions,))
+    rows = []
+    with torch.no_grad():
+        for order in orders:
+            masked = shapley_masked_batch(data, center, order[None, :], region_id)
+            v, _ = cal_reward(model, masked, lbl, softmax_type)
+            dv = (v[1:] - v[:-1]).numpy()
+            total[order] += dv
+            row = np.zeros((num_regions,))
+            row[order] += dv
+            rows.append(row)
+    return total, np.stack(rows, axis=0)
+
+
+# --------------------------------------------------------------------------------------------
+# multi-order interaction (final_point_binary_interaction_logits.py, final_cal_interactions.py)
+# --------------------------------------------------------------------------------------------
+
+def interaction_masked_batch(data_cf, center, region_id, region_i, region_j, contexts):
+    """final_point_binary_interaction_logits.py:45-56.  data_cf (1,3,N); contexts (bs,m) int.
+    Rows 4k..4k+3 keep S+{i,j}, S+{i}, S+{j}, S; masked entries are exactly ``x*0 + c``."""
+    region_id = np.asarray(region_id)
+    bs = contexts.shape[0]
+    n = data_cf.shape[2]
+    keep = np.zeros((4 * bs, n), dtype=bool)
+    is_i = region_id == region_i
+    is_j = region_id == region_j
+    for k in range(bs):
+        s = np.isin(region_id, contexts[k])
+        keep[4 * k + 0] = s | is_i | is_j
+        keep[4 * k + 1] = s | is_i
+        keep[4 * k + 2] = s | is_j
+        keep[4 * k + 3] = s
+    mask = torch.from_numpy(keep).to(data_cf.dtype).reshape(4 * bs, 1, n).expand(4 * bs, 3, n)
+    fill = center.reshape(1, 3, 1).expand(4 * bs, 3, n) * (1 - mask)
+    return data_cf.expand(4 * bs, -1, -1) * mask + fill
+
+
+def compute_order_interaction_logits(model, data, region_id, pairs, contexts, bs, is_pointnet=True):
+    """final_point_binary_interaction_logits.py:15-70 - loop C.  data (1,N,3); pairs (P,2);
+    contexts (P,C,m) -> logits (P,4C,num_class)."""
+    num_context = contexts.shape[1]
+    center = torch.mean(data, dim=1).squeeze()
+    data_cf = data.permute(0, 2, 1)
+    per_pair = []
+    with torch.no_grad():
+        for p, (ri, rj) in enumerate(pairs):
+            chunks = []
+            for it in range(math.ceil(num_context / bs)):
+                ctx = contexts[p][it * bs:min(num_context, (it + 1) * bs)]
+                masked = interaction_masked_batch(data_cf, center, region_id, ri, rj, ctx)
+                out = model(masked)
+                chunks.append(out[0] if is_pointnet else out)
+            per_pair.append(torch.cat(chunks, dim=0).unsqueeze(0))
+    return torch.cat(per_pair, dim=0)
+
+
+def compute_order_interaction(all_logits, lbl, softmax_type="modified"):
+    """final_cal_interactions.py:14-37 - ((v0 + v3) - v1) - v2 in float32, widened to float64 by
+    ``.item()``.  (P,4C,K) -> (P,C) float64 ndarray."""
+    p = all_logits.shape[0]
+    c = all_logits.shape[1] // 4
+    out = np.zeros((p, c))
+    for i in range(p):
+        v = get_reward(all_logits[i], lbl, softmax_type).reshape(c, 4)
+        out[i] = (v[:, 0] + v[:, 3] - v[:, 1] - v[:, 2]).double().numpy()
+    return out
