@@ -1,0 +1,175 @@
+/*
+ * iq.h - C ABI of libiq_hip.so, the MI355X (gfx950) implementation of the Shapley-value /
+ * multi-order-interaction hot path of ada-shen/Interpret_quality.
+ *
+ * The reference has no FFI of its own: the path sits behind Python functions.
+ * Each entry point below therefore names the reference function (file:line, relative to the
+ * reference root) whose device work it replaces; INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr()),
+ *    row-major contiguous, unless the parameter is documented as "host";
+ *  - no allocation inside the library: scratch memory is a caller-provided workspace;
+ *  - every launch function takes a hipStream_t (passed as void*; NULL = default stream) and is
+ *    asynchronous with respect to the host;
+ *  - return value: IQ_OK (0) or a negative IQ_E* code; a message for the calling thread's last
+ *    error is available from iq_last_error();
+ *  - indices are int32 at the ABI (the Python wrappers convert from int64), coalitions are
+ *    uint64 bit masks over regions (bit r set = region r kept), so num_regions <= 64.
+ */
+#ifndef IQ_H_
+#define IQ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* iq_stream_t; /* hipStream_t */
+
+enum {
+    IQ_OK = 0,
+    IQ_EINVAL = -1,      /* bad argument (shape, null pointer, unsupported size) */
+    IQ_ELAUNCH = -2,     /* HIP launch or runtime error */
+    IQ_EWORKSPACE = -3,  /* workspace too small */
+    IQ_EUNSUPPORTED = -4
+};
+
+#define IQ_MAX_REGIONS 64
+#define IQ_MAX_POINTS 4096
+#define IQ_NUM_FEAT 1024
+
+int iq_version(void);
+const char* iq_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Coalition masking
+ * ------------------------------------------------------------------------------------------- */
+
+/* Shapley prefix masking: replaces tools/final_common.py:46-61 (mask_data_batch) together with
+ * the expand().clone() at :88, and final_shapley_value.py:74-88 (mask_data) for bs = 1.
+ * Row o*(R+1)+i of `out` keeps the regions orders[o][0..i-1]; every other point := center.
+ * out is (bs*(R+1), N, 3) if channel_first == 0, else (bs*(R+1), 3, N)
+ * (the layout after the permute().contiguous() of tools/final_common.py:35). */
+int iq_mask_shapley(const float* cloud /*N,3*/, const int32_t* region_id /*N*/,
+                    const int32_t* orders /*bs,R*/, const float* center /*3*/, float* out,
+                    int N, int R, int bs, int channel_first, iq_stream_t stream);
+
+/* Interaction masking: replaces final_point_binary_interaction_logits.py:45-56.
+ * For context k: rows 4k..4k+3 of out (4*nb, 3, N) keep S+{i,j}, S+{i}, S+{j}, S where
+ * S = ctx_mask[k] (bit mask over regions) and (i, j) = pairs[k]; masked entries := center. */
+int iq_mask_interaction(const float* cloud /*N,3*/, const int32_t* region_id /*N*/,
+                        const int32_t* pairs /*nb,2*/, const uint64_t* ctx_mask /*nb*/,
+                        const float* center /*3*/, float* out /*4nb,3,N*/,
+                        int N, int R, int nb, iq_stream_t stream);
+
+/* Generic coalition masking from explicit keep masks: out row b keeps the regions in keep[b].
+ * (Used by the models that consume materialised clouds; PointNet never materialises them.) */
+int iq_mask_coalitions(const float* cloud /*N,3*/, const int32_t* region_id /*N*/,
+                       const uint64_t* keep /*B*/, const float* center /*3*/, float* out,
+                       int N, int B, int channel_first, iq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Reward and reductions
+ * ------------------------------------------------------------------------------------------- */
+
+/* tools/final_common.py:11-24 (get_reward).  modified != 0: v = z_y - logsumexp(z_{!=y});
+ * modified == 0 ("normal"): v = log_softmax(z)[y]. */
+int iq_reward(const float* logits /*B,C*/, int label, int modified, float* v /*B*/,
+              int B, int C, iq_stream_t stream);
+
+/* tools/final_common.py:92-96 and final_shapley_value.py:145-150: dv = v[1:] - v[:-1] per
+ * permutation (float32), scattered by the permutation into float64 rows and summed over the
+ * permutations IN ORDER (bit-stable, matches the host loop of the reference).
+ *   sv_rows  (S,R) float64  = the rows of region_sv_all.npy        (may be NULL)
+ *   phi_sum  (R,)  float64  = sum over the S permutations (not divided)
+ *   snaps    (n_snap,R) float64 = running sums after snap_counts[k] permutations (may be NULL),
+ *            i.e. what save_shapley (final_shapley_value.py:91-106) divides by count. */
+int iq_shapley_accum(const float* v /*S*(R+1)*/, const int32_t* orders /*S,R*/,
+                     double* sv_rows, double* phi_sum, const int32_t* snap_counts, int n_snap,
+                     double* snaps, int R, int S, iq_stream_t stream);
+
+/* final_cal_interactions.py:28-36: I[k] = ((v[4k] + v[4k+3]) - v[4k+1]) - v[4k+2] in float32. */
+int iq_interaction_reduce(const float* v /*4n*/, float* out /*n*/, int n, iq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Geometry
+ * ------------------------------------------------------------------------------------------- */
+
+/* final_shapley_value.py:20-35 (cal_region_id) with tools/final_util.py:134-147: nearest FPS
+ * centre per point by the expanded-form squared distance, first index on ties. */
+int iq_region_assign(const float* cloud /*N,3*/, const int32_t* fps_idx /*R*/,
+                     int32_t* region_id /*N*/, int N, int R, iq_stream_t stream);
+
+/* final_save_fps.py:10-31 (= models/pointnet2.py:45-68): farthest point sampling, start index 0,
+ * ties -> lowest index.  xyz (B,N,3) -> idx (B,S). */
+int iq_fps(const float* xyz, int32_t* idx, int B, int N, int S, iq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * PointNet (models/pointnet.py:11-115) - fused fp32-MFMA forward over coalitions
+ * ------------------------------------------------------------------------------------------- */
+
+/* One dense layer y = act(W x + b), BatchNorm(eval) already folded in.  `w` is in the library's
+ * MFMA B-fragment order (iq_pack_weight), `b` has cout_padded entries. */
+typedef struct iq_dense_layer {
+    const float* w;
+    const float* b;
+    int32_t cin;
+    int32_t cout;
+} iq_dense_layer;
+
+typedef struct iq_pointnet_weights {
+    const float* stn_in;  /* [64][4] = (w0,w1,w2,bias) of feat.stn.conv1+bn1 */
+    iq_dense_layer stn_c2, stn_c3, stn_fc1, stn_fc2, stn_fc3;       /* fc3 bias includes +I */
+    const float* feat_in; /* [64][4] of feat.conv1+bn1 */
+    iq_dense_layer fstn_c1, fstn_c2, fstn_c3, fstn_fc1, fstn_fc2, fstn_fc3; /* fc3: iq_pack_fstn_fc3 */
+    iq_dense_layer feat_c2, feat_c3, cls_fc1, cls_fc2, cls_fc3;
+} iq_pointnet_weights;
+
+/* Host-side packing helpers (host pointers).  iq_packed_floats = number of floats of the packed
+ * image of a (cout, cin) weight; cin must be a multiple of 8. */
+size_t iq_packed_floats(int cout, int cin);
+int iq_padded_cout(int cout);
+int iq_pack_weight(const float* w_host /*cout,cin*/, float* out_host, int cout, int cin);
+/* feat.fstn.fc3 (4096 x 256): permutes the output rows so that the layer's output vector IS the
+ * packed B-fragment image of trans_feat for the trunk's per-coalition 64x64 product, and adds the
+ * identity (models/pointnet.py:42-45) into the bias.  out_w has iq_packed_floats(4096,256)
+ * floats, out_b 4096.  perm_host[r] (4096 int32, may be NULL) receives the source row of output
+ * row r, so a caller can undo the permutation. */
+int iq_pack_fstn_fc3(const float* w_host, const float* b_host, float* out_w, float* out_b,
+                     int32_t* perm_host);
+
+/* Workspace (bytes) needed by iq_pointnet_coalitions for B coalitions over nclouds clouds. */
+size_t iq_pointnet_workspace_bytes(int B, int nclouds, int N, int R);
+
+/* Logits of B coalitions without materialising the masked clouds.  Replaces, for PointNet, the
+ * chain mask_data_batch -> cal_reward -> model(...) of tools/final_common.py:88-91 and
+ * final_point_binary_interaction_logits.py:45-60.
+ *   clouds    (nclouds, N, 3) if channel_first == 0, else (nclouds, 3, N)
+ *   centers   (nclouds, 3)   the point every masked point collapses onto
+ *   region_id (nclouds, N)   int32 in [0, R)
+ *   keep      (B,) uint64    bit r set = region r keeps its points
+ *   cloud_of  (B,) int32     cloud index of each coalition (NULL = all 0)
+ *   logits    (B, 10)
+ *   trans_feat_packed (B, 4096) optional output (NULL to skip): packed image of trans_feat
+ * Exact with respect to the dense evaluation of the same kernels: identical points produce
+ * identical features and max-pooling ignores duplicates. */
+int iq_pointnet_coalitions(const iq_pointnet_weights* w /*host struct of device pointers*/,
+                           const float* clouds, const float* centers, const int32_t* region_id,
+                           const uint64_t* keep, const int32_t* cloud_of, float* logits,
+                           float* trans_feat_packed, void* workspace, size_t workspace_bytes,
+                           int B, int nclouds, int N, int R, int channel_first,
+                           iq_stream_t stream);
+
+/* Name and average-free launch counters of the dominant kernel, for bench.py's roofline leg:
+ * iq_pointnet_flops_per_coalition() = algorithmic FLOP of the dense reference network
+ * (0.879 GFLOP). */
+double iq_pointnet_flops_per_coalition(int N);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IQ_H_ */

@@ -1,0 +1,92 @@
+"""ctypes binding of libiq_hip.so (include/iq.h).  cffi is not installed in the target image
+(SURVEY.md §0), so the thin C-ABI layer the north star asks for is bound with ctypes.
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+c_f32p = ctypes.c_void_p
+c_ptr = ctypes.c_void_p
+
+
+class IqError(RuntimeError):
+    pass
+
+
+class DenseLayer(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("b", ctypes.c_void_p), ("cin", ctypes.c_int32), ("cout", ctypes.c_int32)]
+
+
+class PointNetWeights(ctypes.Structure):
+    _fields_ = [
+        ("stn_in", ctypes.c_void_p),
+        ("stn_c2", DenseLayer), ("stn_c3", DenseLayer), ("stn_fc1", DenseLayer), ("stn_fc2", DenseLayer),
+        ("stn_fc3", DenseLayer),
+        ("feat_in", ctypes.c_void_p),
+        ("fstn_c1", DenseLayer), ("fstn_c2", DenseLayer), ("fstn_c3", DenseLayer), ("fstn_fc1", DenseLayer),
+        ("fstn_fc2", DenseLayer), ("fstn_fc3", DenseLayer),
+        ("feat_c2", DenseLayer), ("feat_c3", DenseLayer), ("cls_fc1", DenseLayer), ("cls_fc2", DenseLayer),
+        ("cls_fc3", DenseLayer),
+    ]
+
+
+_I = ctypes.c_int
+_P = ctypes.c_void_p
+_SZ = ctypes.c_size_t
+
+# name -> (restype, argtypes); every symbol include/iq.h declares
+SIGNATURES = {
+    "iq_version": (_I, []),
+    "iq_last_error": (ctypes.c_char_p, []),
+    "iq_mask_shapley": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "iq_mask_interaction": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "iq_mask_coalitions": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "iq_reward": (_I, [_P, _I, _I, _P, _I, _I, _P]),
+    "iq_shapley_accum": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P]),
+    "iq_interaction_reduce": (_I, [_P, _P, _I, _P]),
+    "iq_region_assign": (_I, [_P, _P, _P, _I, _I, _P]),
+    "iq_fps": (_I, [_P, _P, _I, _I, _I, _P]),
+    "iq_packed_floats": (_SZ, [_I, _I]),
+    "iq_padded_cout": (_I, [_I]),
+    "iq_pack_weight": (_I, [_P, _P, _I, _I]),
+    "iq_pack_fstn_fc3": (_I, [_P, _P, _P, _P, _P]),
+    "iq_pointnet_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "iq_pointnet_coalitions": (_I, [ctypes.POINTER(PointNetWeights), _P, _P, _P, _P, _P, _P, _P, _P, _SZ,
+                                    _I, _I, _I, _I, _I, _P]),
+    "iq_pointnet_flops_per_coalition": (ctypes.c_double, [_I]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIBPATH
+
+
+def load():
+    """Load libiq_hip.so (never builds implicitly on the GPU box: the .so ships with the repo)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise IqError("libiq_hip.so not found at %s - run `python -m interpret_quality_amd.build` "
+                      "(there is no CPU or PyTorch fallback for the HIP path)" % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().iq_last_error()
+        raise IqError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))

@@ -1,0 +1,123 @@
+// Geometry kernels: nearest-centre region assignment (K6) and farthest point sampling (K7).
+//
+// Both are index-valued, so the floating-point expressions are written with explicitly rounded
+// operations (__fmul_rn/__fadd_rn: no FMA contraction) in the order the reference's PyTorch
+// expressions evaluate them; ties resolve to the lowest index like the CPU argmin/argmax.
+#include "iq_common.h"
+
+namespace {
+
+// ---- K6: tools/final_util.py:134-147 + final_shapley_value.py:29-31 -------------------------
+__global__ __launch_bounds__(256) void region_assign_kernel(const float* __restrict__ cloud,
+                                                            const int32_t* __restrict__ fps_idx,
+                                                            int32_t* __restrict__ region_id, int N, int R) {
+    __shared__ float cs[IQ_MAX_REGIONS * 4];
+    if (threadIdx.x < R) {
+        const int c = fps_idx[threadIdx.x];
+        const float x = cloud[c * 3], y = cloud[c * 3 + 1], z = cloud[c * 3 + 2];
+        cs[threadIdx.x * 4 + 0] = x;
+        cs[threadIdx.x * 4 + 1] = y;
+        cs[threadIdx.x * 4 + 2] = z;
+        cs[threadIdx.x * 4 + 3] = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+    }
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const float x = cloud[p * 3], y = cloud[p * 3 + 1], z = cloud[p * 3 + 2];
+    const float sx = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+    float best = INFINITY;
+    int arg = 0;
+    for (int r = 0; r < R; ++r) {
+        // matmul row (K = 3) as an fma chain, then * -2, + |src|^2, + |dst|^2
+        float dot = __fmul_rn(x, cs[r * 4]);
+        dot = __fmaf_rn(y, cs[r * 4 + 1], dot);
+        dot = __fmaf_rn(z, cs[r * 4 + 2], dot);
+        float d = __fmul_rn(-2.f, dot);
+        d = __fadd_rn(d, sx);
+        d = __fadd_rn(d, cs[r * 4 + 3]);
+        if (d < best) { best = d; arg = r; }
+    }
+    region_id[p] = arg;
+}
+
+// ---- K7: final_save_fps.py:10-31 --------------------------------------------------------------
+// One workgroup per cloud; coordinates and running min-distance live in LDS; per iteration one
+// wave-shuffle arg-max + one cross-wave step (2 barriers).
+constexpr int kFpsThreads = 256;
+
+__device__ inline void argmax_combine(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+__global__ __launch_bounds__(kFpsThreads) void fps_kernel(const float* __restrict__ xyz,
+                                                          int32_t* __restrict__ idx, int N, int S) {
+    extern __shared__ float lds[];
+    float* px = lds;           // N
+    float* py = px + N;        // N
+    float* pz = py + N;        // N
+    float* mind = pz + N;      // N
+    __shared__ float wv[kFpsThreads / 64];
+    __shared__ int wi[kFpsThreads / 64];
+    __shared__ int far_s;
+
+    const float* src = xyz + (size_t)blockIdx.x * N * 3;
+    for (int p = threadIdx.x; p < N; p += kFpsThreads) {
+        px[p] = src[p * 3];
+        py[p] = src[p * 3 + 1];
+        pz[p] = src[p * 3 + 2];
+        mind[p] = 1e10f;
+    }
+    if (threadIdx.x == 0) far_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int it = 0; it < S; ++it) {
+        const int far = far_s;
+        if (threadIdx.x == 0) idx[(size_t)blockIdx.x * S + it] = far;
+        const float cx = px[far], cy = py[far], cz = pz[far];
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int p = threadIdx.x; p < N; p += kFpsThreads) {
+            const float dx = __fsub_rn(px[p], cx), dy = __fsub_rn(py[p], cy), dz = __fsub_rn(pz[p], cz);
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            float m = mind[p];
+            if (d < m) { m = d; mind[p] = d; }
+            if (m > bv) { bv = m; bi = p; }  // increasing p: strict > keeps the lowest index
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            argmax_combine(bv, bi, ov, oi);
+        }
+        __syncthreads();  // everyone has read far_s
+        if (lane == 0) { wv[wave] = bv; wi[wave] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float v = wv[0];
+            int i = wi[0];
+            for (int w = 1; w < kFpsThreads / 64; ++w) argmax_combine(v, i, wv[w], wi[w]);
+            far_s = i;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int iq_region_assign(const float* cloud, const int32_t* fps_idx, int32_t* region_id,
+                                int N, int R, iq_stream_t stream) {
+    IQ_REQUIRE(cloud && fps_idx && region_id, "iq_region_assign: null pointer");
+    IQ_REQUIRE(N > 0 && R >= 1 && R <= IQ_MAX_REGIONS, "iq_region_assign: N=%d R=%d", N, R);
+    hipLaunchKernelGGL(region_assign_kernel, dim3((N + 255) / 256), dim3(256), 0, iq::as_stream(stream),
+                       cloud, fps_idx, region_id, N, R);
+    return iq::check_launch("region_assign_kernel");
+}
+
+extern "C" int iq_fps(const float* xyz, int32_t* idx, int B, int N, int S, iq_stream_t stream) {
+    IQ_REQUIRE(B >= 0 && N > 0 && N <= 8192 && S >= 1, "iq_fps: B=%d N=%d S=%d", B, N, S);
+    if (B == 0) return IQ_OK;
+    IQ_REQUIRE(xyz && idx, "iq_fps: null pointer");
+    const size_t lds = (size_t)N * 4 * sizeof(float);
+    hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(kFpsThreads), lds, iq::as_stream(stream), xyz, idx, N, S);
+    return iq::check_launch("fps_kernel");
+}

@@ -1,0 +1,598 @@
+// Fused fp32-MFMA PointNet forward over coalitions (models/pointnet.py:11-115).
+//
+// A masked cloud is {kept points} + {the centre, if anything was masked}.  Every per-point layer
+// is a pointwise function and every pooling is a max, so
+//   * the input-STN's 3->64->128->1024 chain is evaluated ONCE per cloud and pre-pooled per region
+//     (chain<kPrepool>); a coalition's pooled feature is a max over its kept regions (+ centre);
+//   * the feature-STN and trunk chains run only over a coalition's DISTINCT points.
+// Both are exact with respect to evaluating the same kernels on the materialised cloud.
+//
+// chain kernel: one workgroup (4 waves) per coalition, 64-row chunks:
+//   stage0 (VALU)  x -> x.trans -> conv1(3->64)+bn+relu                      -> LDS act0
+//   L1  (MFMA)     64->64   (fstn.conv1 | per-coalition trans_feat product)  -> LDS act1
+//   L2  (MFMA)     64->128  conv2+bn+relu                                    -> LDS act2
+//   L3  (MFMA)     128->1024 conv3+bn(+relu), column max over rows           -> registers
+// v_mfma_f32_32x32x2_f32 throughout (exact fp32 fma chains).  A operands come from LDS
+// (XOR-swizzled, conflict-free ds_read_b128), B operands (weights) stream from L2 in a
+// pre-packed fragment order (1 KiB contiguous per wave-load).  LDS = 52 KB -> 3 workgroups/CU.
+#include "iq_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kFeat = IQ_NUM_FEAT;
+constexpr int kMC = 64;        // rows per chunk
+constexpr int kMaxN = 1024;    // points per cloud supported by the chain kernel
+constexpr int kThreads = 256;
+
+enum ChainMode { kPrepool = 0, kFstn = 1, kTrunk = 2 };
+
+// LDS activation image: row-major [row][k], 16-byte groups XOR-swizzled by (row & 15).
+__device__ __forceinline__ int swz(int row, int k, int ld) {
+    return row * ld + ((((k >> 2) ^ (row & 15))) << 2) + (k & 3);
+}
+
+// A fragment of v_mfma_f32_32x32x2_f32 for K-block kb (8 k values): lane (row = l&31, h = l>>5)
+// holds k = 8kb + 4h + j in element j; MFMA step j consumes element j of A and B.
+__device__ __forceinline__ f32x4 lds_a(const float* act, int ld, int m0, int kb, int lane) {
+    const int row = m0 + (lane & 31);
+    return *reinterpret_cast<const f32x4*>(act + row * ld + (((2 * kb + (lane >> 5)) ^ (row & 15)) << 2));
+}
+
+// B fragment from the packed weight image: ((nt*KB + kb)*64 + lane)*4.
+__device__ __forceinline__ f32x4 glb_b(const float* wp, int lane) {
+    return *reinterpret_cast<const f32x4*>(wp + lane * 4);
+}
+
+__device__ __forceinline__ f32x16 mfma4(f32x4 a, f32x4 b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+}
+
+__device__ __forceinline__ float max16(f32x16 c) {
+    float m0 = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
+    float m1 = fmaxf(fmaxf(c[4], c[5]), fmaxf(c[6], c[7]));
+    float m2 = fmaxf(fmaxf(c[8], c[9]), fmaxf(c[10], c[11]));
+    float m3 = fmaxf(fmaxf(c[12], c[13]), fmaxf(c[14], c[15]));
+    return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+}
+
+// C/D layout of the 32x32 MFMA: col = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5).
+__device__ __forceinline__ int c_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+
+struct ChainArgs {
+    const float* clouds;       // strides below, in floats
+    int ps, cs, cl;            // point, channel, cloud stride
+    const float* centers;      // (nclouds,3)
+    const int32_t* region_id;  // (nclouds,N)
+    const uint16_t* rank;      // (nclouds,N) rank of a point inside its region
+    const int32_t* rsize;      // (nclouds,R)
+    const uint64_t* keep;      // (items) or null = keep everything       [kFstn/kTrunk]
+    const int32_t* cloud_of;   // (items) or null                          [kFstn/kTrunk]
+    const float* trans;        // (items,9) input transform                [kFstn/kTrunk]
+    const float* w_in;         // [64][4] folded 3->64 layer
+    const float* w1;           // kFstn: packed 64x64; kTrunk: per item packed image (items,4096)
+    const float* b1;
+    const float* w2;
+    const float* b2;
+    const float* w3;
+    const float* b3;
+    float* out;                // (items,1024)
+    int N, R, items, nclouds, with_centre;
+};
+
+template <int MTS>
+__device__ __forceinline__ void l3_pass(const float* __restrict__ w3, const float* act2, int wave, int lane,
+                                        float (&runmax)[8]) {
+    // B fragments run two K-blocks ahead of the MFMAs, across n-tile boundaries as well.
+    const float* wq = w3 + (size_t)wave * 16 * 256;
+    f32x4 b0 = glb_b(wq, lane);
+    f32x4 b1 = glb_b(wq + 256, lane);
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {
+        const float* wnext = w3 + (size_t)(min(q + 1, 7) * 4 + wave) * 16 * 256;
+        f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll 4
+        for (int kb = 0; kb < 16; ++kb) {
+            const f32x4 bn = (kb + 2 < 16) ? glb_b(wq + (kb + 2) * 256, lane) : glb_b(wnext + (kb + 2 - 16) * 256, lane);
+            const f32x4 a0 = lds_a(act2, 128, 0, kb, lane);
+            acc0 = mfma4(a0, b0, acc0);
+            if (MTS == 2) {
+                const f32x4 a1 = lds_a(act2, 128, 32, kb, lane);
+                acc1 = mfma4(a1, b0, acc1);
+            }
+            b0 = b1;
+            b1 = bn;
+        }
+        float m = max16(acc0);
+        if (MTS == 2) m = fmaxf(m, max16(acc1));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? fmaxf(runmax[i], m) : runmax[i];
+        wq = wnext;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
+    __shared__ __attribute__((aligned(16))) float bufA[kMC * 128];  // act0 (ld 64) then act2 (ld 128)
+    __shared__ __attribute__((aligned(16))) float bufB[kMC * 64];   // act1
+    __shared__ __attribute__((aligned(16))) float xs[kMC * 3];      // transformed inputs; aliased by prefix[]
+    __shared__ int16_t rows[kMaxN + kMC];
+    __shared__ int nkept_s;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int item = blockIdx.x;
+    const int N = a.N, R = a.R;
+
+    int cloud;
+    uint64_t keep;
+    bool add_centre = false;
+    if (MODE == kPrepool) {
+        const int per = R + a.with_centre;
+        cloud = item / per;
+        const int r = item - cloud * per;
+        keep = r < R ? (1ull << r) : 0ull;
+        add_centre = (r == R);
+    } else {
+        cloud = a.cloud_of ? a.cloud_of[item] : (a.nclouds == 1 ? 0 : item);
+        const uint64_t full = R >= 64 ? ~0ull : ((1ull << R) - 1);
+        keep = (a.keep ? a.keep[item] : ~0ull) & full;
+    }
+
+    // ---- row list: kept points compacted by region, then the centre, then padding ----------
+    int* prefix = reinterpret_cast<int*>(xs);
+    if (wave == 0) {
+        const int sz = (lane < R && ((keep >> lane) & 1)) ? a.rsize[cloud * R + lane] : 0;
+        int inc = sz;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        prefix[lane] = inc - sz;
+        if (lane == 63) nkept_s = inc;
+    }
+    __syncthreads();
+    for (int p = tid; p < N; p += kThreads) {
+        const int r = a.region_id[(size_t)cloud * N + p];
+        if ((keep >> r) & 1) rows[prefix[r] + a.rank[(size_t)cloud * N + p]] = (int16_t)p;
+    }
+    const int nkept = nkept_s;
+    __syncthreads();
+    if (MODE != kPrepool) add_centre = nkept < N;
+    const int nrows = nkept + (add_centre ? 1 : 0);
+    float* outp = a.out + (size_t)item * kFeat;
+    if (nrows == 0) {  // empty region in the pre-pool: identity of max
+        for (int c = tid; c < kFeat; c += kThreads) outp[c] = -INFINITY;
+        return;
+    }
+    const int npad = (nrows + kMC - 1) / kMC * kMC;
+    {
+        const int16_t padval = add_centre ? (int16_t)N : rows[nkept - 1];
+        for (int i = nkept + tid; i < npad; i += kThreads) rows[i] = padval;
+    }
+    // (visibility of rows[] padding is covered by the barrier after stage 0a)
+
+    const int c0 = tid & 63, rg = tid >> 6;
+    const f32x4 win = *reinterpret_cast<const f32x4*>(a.w_in + c0 * 4);
+    float t9[9];
+    if (MODE != kPrepool) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) t9[i] = a.trans[(size_t)item * 9 + i];
+    }
+    const float* w1 = (MODE == kTrunk) ? a.w1 + (size_t)item * 4096 : a.w1;
+
+    float runmax[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) runmax[q] = -INFINITY;
+
+    __syncthreads();
+    for (int ch = 0; ch * kMC < npad; ++ch) {
+        const int rows_here = min(kMC, nrows - ch * kMC);
+        const int mts = rows_here > 32 ? 2 : 1;
+
+        // ---- stage 0a: fetch + input transform (models/pointnet.py:67-69) ------------------
+        if (tid < kMC) {
+            const int p = rows[ch * kMC + tid];
+            float x, y, z;
+            if (p == N) {
+                x = a.centers[cloud * 3]; y = a.centers[cloud * 3 + 1]; z = a.centers[cloud * 3 + 2];
+            } else {
+                const float* src = a.clouds + (size_t)cloud * a.cl + (size_t)p * a.ps;
+                x = src[0]; y = src[a.cs]; z = src[2 * a.cs];
+            }
+            if (MODE != kPrepool) {
+                const float x2 = fmaf(z, t9[6], fmaf(y, t9[3], x * t9[0]));
+                const float y2 = fmaf(z, t9[7], fmaf(y, t9[4], x * t9[1]));
+                const float z2 = fmaf(z, t9[8], fmaf(y, t9[5], x * t9[2]));
+                x = x2; y = y2; z = z2;
+            }
+            xs[tid * 3] = x; xs[tid * 3 + 1] = y; xs[tid * 3 + 2] = z;
+        }
+        __syncthreads();
+        // ---- stage 0b: 3 -> 64 (+bn, relu), thread = (channel c0, 16 rows) -----------------
+        {
+            float* dst = (MODE == kPrepool) ? bufB : bufA;
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int r = rg * 16 + i;
+                const float f = fmaf(win[2], xs[r * 3 + 2], fmaf(win[1], xs[r * 3 + 1], win[0] * xs[r * 3])) + win[3];
+                dst[swz(r, c0, 64)] = fmaxf(f, 0.f);
+            }
+        }
+        __syncthreads();
+        // ---- L1: 64 -> 64 ------------------------------------------------------------------
+        if (MODE != kPrepool) {
+            const int mt = wave & 1, nt = wave >> 1;
+            if (mt < mts) {
+                f32x16 acc = {0};
+                const float* wq = w1 + (size_t)nt * 8 * 256;
+#pragma unroll 2
+                for (int kb = 0; kb < 8; ++kb)
+                    acc = mfma4(lds_a(bufA, 64, mt * 32, kb, lane), glb_b(wq + kb * 256, lane), acc);
+                const int col = nt * 32 + (lane & 31);
+                const float bias = (MODE == kFstn) ? a.b1[col] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = acc[i] + bias;
+                    if (MODE == kFstn) v = fmaxf(v, 0.f);
+                    bufB[swz(mt * 32 + c_row(i, lane), col, 64)] = v;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- L2: 64 -> 128 (+bn, relu) -----------------------------------------------------
+        {
+            const int mt = wave & 1, nt0 = wave >> 1, nt1 = nt0 + 2;
+            if (mt < mts) {
+                f32x16 acc0 = {0}, acc1 = {0};
+                const float* wq0 = a.w2 + (size_t)nt0 * 8 * 256;
+                const float* wq1 = a.w2 + (size_t)nt1 * 8 * 256;
+#pragma unroll 2
+                for (int kb = 0; kb < 8; ++kb) {
+                    const f32x4 av = lds_a(bufB, 64, mt * 32, kb, lane);
+                    acc0 = mfma4(av, glb_b(wq0 + kb * 256, lane), acc0);
+                    acc1 = mfma4(av, glb_b(wq1 + kb * 256, lane), acc1);
+                }
+                const int col0 = nt0 * 32 + (lane & 31), col1 = nt1 * 32 + (lane & 31);
+                const float bias0 = a.b2[col0], bias1 = a.b2[col1];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = mt * 32 + c_row(i, lane);
+                    bufA[swz(row, col0, 128)] = fmaxf(acc0[i] + bias0, 0.f);
+                    bufA[swz(row, col1, 128)] = fmaxf(acc1[i] + bias1, 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- L3: 128 -> 1024, running column max -------------------------------------------
+        if (mts == 2) l3_pass<2>(a.w3, bufA, wave, lane, runmax);
+        else          l3_pass<1>(a.w3, bufA, wave, lane, runmax);
+        // the barrier after the next chunk's stage 0a orders these reads before bufA is rewritten
+    }
+
+    // max commutes with the (monotone) per-column bias add and relu
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float v = runmax[q];
+        v = fmaxf(v, __shfl_xor(v, 32));
+        const int n = (q * 4 + wave) * 32 + (lane & 31);
+        v += a.b3[n];
+        if (MODE != kTrunk) v = fmaxf(v, 0.f);
+        if (lane < 32) outp[n] = v;
+    }
+}
+
+// ---- per-cloud region tables ---------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void pn_prepare_kernel(const int32_t* __restrict__ region_id,
+                                                              uint16_t* __restrict__ rank,
+                                                              int32_t* __restrict__ rsize, int N, int R) {
+    __shared__ int16_t rid[kMaxN];
+    __shared__ int cnt[IQ_MAX_REGIONS];
+    const int cloud = blockIdx.x;
+    if (threadIdx.x < IQ_MAX_REGIONS) cnt[threadIdx.x] = 0;
+    for (int p = threadIdx.x; p < N; p += kThreads) rid[p] = (int16_t)region_id[(size_t)cloud * N + p];
+    __syncthreads();
+    for (int p = threadIdx.x; p < N; p += kThreads) {
+        const int r = rid[p];
+        int k = 0;
+        for (int q = 0; q < p; ++q) k += (rid[q] == r);
+        rank[(size_t)cloud * N + p] = (uint16_t)k;
+        atomicAdd(&cnt[r], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < R) rsize[cloud * R + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// ---- pooled input-STN feature of a coalition: max over kept regions (+ centre) -------------
+__global__ __launch_bounds__(kThreads) void pn_stn_gather_kernel(const float* __restrict__ G,
+                                                                 const int32_t* __restrict__ rsize,
+                                                                 const uint64_t* __restrict__ keep,
+                                                                 const int32_t* __restrict__ cloud_of,
+                                                                 float* __restrict__ out, int N, int R,
+                                                                 int nclouds, int with_centre) {
+    const int item = blockIdx.x;
+    const int cloud = cloud_of ? cloud_of[item] : (nclouds == 1 ? 0 : item);
+    const uint64_t full = R >= 64 ? ~0ull : ((1ull << R) - 1);
+    const uint64_t k = (keep ? keep[item] : ~0ull) & full;
+    const int per = R + with_centre;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(G) + (size_t)cloud * per * (kFeat / 4) + threadIdx.x;
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int nkept = 0;
+    for (int r = 0; r < R; ++r) {
+        if ((k >> r) & 1) {
+            nkept += rsize[cloud * R + r];
+            const f32x4 v = g4[(size_t)r * (kFeat / 4)];
+            m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+        }
+    }
+    if (with_centre && nkept < N) {
+        const f32x4 v = g4[(size_t)R * (kFeat / 4)];
+        m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+    }
+    reinterpret_cast<f32x4*>(out)[(size_t)item * (kFeat / 4) + threadIdx.x] = m;
+}
+
+// ---- batched dense layer  out = act(A W^T + b)  --------------------------------------------
+// No LDS: the fp32 MFMA is slow enough (64 cycles) that both operands stream straight from
+// L1/L2 into registers, one K-block ahead.  Wave tile (MT*32) x (NT*32); 4 waves as WM x WN.
+template <int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __restrict__ A, int lda,
+                                                             const float* __restrict__ wp,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ out, int ldo, int M, int K,
+                                                             int Nout, int relu) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = (blockIdx.x * WM + wm) * MT * 32;
+    const int nt0 = (blockIdx.y * WN + wn) * NT;
+    const int KB = K >> 3;
+    const int ntiles = (Nout + 31) >> 5;
+    if (m0 >= M || nt0 >= ntiles) return;
+
+    const float* ap[MT];
+    const float* bp[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row = min(m0 + i * 32 + (lane & 31), M - 1);
+        ap[i] = A + (size_t)row * lda + 4 * (lane >> 5);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int nt = min(nt0 + j, ntiles - 1);
+        bp[j] = wp + ((size_t)nt * KB * 64 + lane) * 4;
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x16){0};
+
+    f32x4 av[MT], bv[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) av[i] = *reinterpret_cast<const f32x4*>(ap[i]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(bp[j]);
+    for (int kb = 0; kb < KB; ++kb) {
+        f32x4 an[MT], bn[NT];
+        const int kn = min(kb + 1, KB - 1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) an[i] = *reinterpret_cast<const f32x4*>(ap[i] + 8 * kn);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bn[j] = *reinterpret_cast<const f32x4*>(bp[j] + (size_t)kn * 256);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = mfma4(av[i], bv[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) av[i] = an[i];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = bn[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = (nt0 + j) * 32 + (lane & 31);
+        if (nt0 + j >= ntiles || col >= Nout) continue;
+        const float b = bias[col];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + i * 32 + c_row(r, lane);
+                if (row < M) {
+                    float v = acc[i][j][r] + b;
+                    if (relu) v = fmaxf(v, 0.f);
+                    out[(size_t)row * ldo + col] = v;
+                }
+            }
+        }
+    }
+}
+
+int launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,
+                  hipStream_t st) {
+    if (M == 0) return IQ_OK;
+    IQ_REQUIRE(L.w && L.b && L.cin % 8 == 0 && L.cout >= 1, "dense layer: bad descriptor (cin=%d cout=%d)", L.cin, L.cout);
+    const int ntiles = (L.cout + 31) / 32;
+    if (ntiles >= 4) {
+        dim3 grid((M + 127) / 128, (ntiles + 3) / 4);
+        hipLaunchKernelGGL((pn_linear_kernel<2, 2, 2, 2>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M,
+                           L.cin, L.cout, relu);
+    } else {
+        dim3 grid((M + 255) / 256, ntiles);
+        hipLaunchKernelGGL((pn_linear_kernel<2, 1, 4, 1>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M,
+                           L.cin, L.cout, relu);
+    }
+    return iq::check_launch("pn_linear_kernel");
+}
+
+struct Workspace {
+    uint16_t* rank;
+    int32_t* rsize;
+    float* G;
+    float* gbuf;
+    float* h1;
+    float* h2;
+    float* trans;
+    float* tfp;
+    size_t bytes;
+};
+
+Workspace carve(void* base, int B, int nclouds, int N, int R) {
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = iq::align_up(off + bytes, 256);
+        return reinterpret_cast<char*>(base) + o;
+    };
+    w.rank = reinterpret_cast<uint16_t*>(take((size_t)nclouds * N * sizeof(uint16_t)));
+    w.rsize = reinterpret_cast<int32_t*>(take((size_t)nclouds * IQ_MAX_REGIONS * sizeof(int32_t)));
+    w.G = reinterpret_cast<float*>(take((size_t)nclouds * (R + 1) * kFeat * sizeof(float)));
+    w.gbuf = reinterpret_cast<float*>(take((size_t)B * kFeat * sizeof(float)));
+    w.h1 = reinterpret_cast<float*>(take((size_t)B * 512 * sizeof(float)));
+    w.h2 = reinterpret_cast<float*>(take((size_t)B * 256 * sizeof(float)));
+    w.trans = reinterpret_cast<float*>(take((size_t)B * 9 * sizeof(float)));
+    w.tfp = reinterpret_cast<float*>(take((size_t)B * 4096 * sizeof(float)));
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t iq_pointnet_workspace_bytes(int B, int nclouds, int N, int R) {
+    if (B < 0 || nclouds < 0 || N < 0 || R < 0) return 0;
+    return carve(nullptr, B, nclouds, N, R).bytes;
+}
+
+extern "C" double iq_pointnet_flops_per_coalition(int N) {
+    // MACs per point: stn 3*64+64*128+128*1024, bmm 9, conv1 192, fstn 64*64+64*128+128*1024,
+    // bmm 4096, conv2 8192, conv3 131072 = 426377; FC heads: stn 1024*512+512*256+256*9,
+    // fstn ...+256*4096, cls ...+256*10
+    const double per_point = 426377.0;
+    const double fc = 3.0 * (1024.0 * 512 + 512.0 * 256) + 256.0 * (9 + 4096 + 10);
+    return 2.0 * (per_point * N + fc);
+}
+
+extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float* clouds, const float* centers,
+                                      const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of,
+                                      float* logits, float* trans_feat_packed, void* workspace,
+                                      size_t workspace_bytes, int B, int nclouds, int N, int R,
+                                      int channel_first, iq_stream_t stream) {
+    IQ_REQUIRE(w && clouds && region_id && logits, "iq_pointnet_coalitions: null pointer");
+    IQ_REQUIRE(B >= 0 && nclouds >= 1, "iq_pointnet_coalitions: B=%d nclouds=%d", B, nclouds);
+    IQ_REQUIRE(N >= 1 && N <= kMaxN, "iq_pointnet_coalitions: N=%d not in [1,%d]", N, kMaxN);
+    IQ_REQUIRE(R >= 1 && R <= IQ_MAX_REGIONS, "iq_pointnet_coalitions: R=%d not in [1,%d]", R, IQ_MAX_REGIONS);
+    IQ_REQUIRE(cloud_of || nclouds == 1 || nclouds == B, "iq_pointnet_coalitions: cloud_of required when 1 < nclouds != B");
+    const int with_centre = centers ? 1 : 0;  // no centre = dense mode (nothing is ever masked)
+    IQ_REQUIRE(centers || !keep, "iq_pointnet_coalitions: keep masks need centers");
+    if (B == 0) return IQ_OK;
+    const size_t need = iq_pointnet_workspace_bytes(B, nclouds, N, R);
+    if (!workspace || workspace_bytes < need)
+        return iq::fail(IQ_EWORKSPACE, "iq_pointnet_coalitions: workspace %zu < %zu bytes", workspace_bytes, need);
+    Workspace ws = carve(workspace, B, nclouds, N, R);
+    hipStream_t st = iq::as_stream(stream);
+    int rc;
+
+    hipLaunchKernelGGL(pn_prepare_kernel, dim3(nclouds), dim3(kThreads), 0, st, region_id, ws.rank, ws.rsize, N, R);
+    if ((rc = iq::check_launch("pn_prepare_kernel"))) return rc;
+
+    ChainArgs a{};
+    a.clouds = clouds;
+    if (channel_first) { a.ps = 1; a.cs = N; } else { a.ps = 3; a.cs = 1; }
+    a.cl = 3 * N;
+    a.centers = centers;
+    a.region_id = region_id;
+    a.rank = ws.rank;
+    a.rsize = ws.rsize;
+    a.N = N; a.R = R; a.nclouds = nclouds; a.with_centre = with_centre;
+
+    // 1. input-STN chain, pre-pooled per (cloud, region) [+ centre]
+    a.keep = nullptr; a.cloud_of = nullptr; a.trans = nullptr;
+    a.w_in = w->stn_in;
+    a.w1 = nullptr; a.b1 = nullptr;
+    a.w2 = w->stn_c2.w; a.b2 = w->stn_c2.b;
+    a.w3 = w->stn_c3.w; a.b3 = w->stn_c3.b;
+    a.out = ws.G;
+    a.items = nclouds * (R + with_centre);
+    hipLaunchKernelGGL(pn_chain_kernel<kPrepool>, dim3(a.items), dim3(kThreads), 0, st, a);
+    if ((rc = iq::check_launch("pn_chain_kernel<prepool>"))) return rc;
+
+    hipLaunchKernelGGL(pn_stn_gather_kernel, dim3(B), dim3(kThreads), 0, st, ws.G, ws.rsize, keep, cloud_of, ws.gbuf,
+                       N, R, nclouds, with_centre);
+    if ((rc = iq::check_launch("pn_stn_gather_kernel"))) return rc;
+    if ((rc = launch_linear(ws.gbuf, kFeat, w->stn_fc1, ws.h1, 512, B, 1, st))) return rc;
+    if ((rc = launch_linear(ws.h1, 512, w->stn_fc2, ws.h2, 256, B, 1, st))) return rc;
+    if ((rc = launch_linear(ws.h2, 256, w->stn_fc3, ws.trans, 9, B, 0, st))) return rc;
+
+    // 2. feature-STN chain over each coalition's distinct points
+    a.keep = keep; a.cloud_of = cloud_of; a.trans = ws.trans;
+    a.w_in = w->feat_in;
+    a.w1 = w->fstn_c1.w; a.b1 = w->fstn_c1.b;
+    a.w2 = w->fstn_c2.w; a.b2 = w->fstn_c2.b;
+    a.w3 = w->fstn_c3.w; a.b3 = w->fstn_c3.b;
+    a.out = ws.gbuf;
+    a.items = B;
+    hipLaunchKernelGGL(pn_chain_kernel<kFstn>, dim3(B), dim3(kThreads), 0, st, a);
+    if ((rc = iq::check_launch("pn_chain_kernel<fstn>"))) return rc;
+    float* tfp = trans_feat_packed ? trans_feat_packed : ws.tfp;
+    if ((rc = launch_linear(ws.gbuf, kFeat, w->fstn_fc1, ws.h1, 512, B, 1, st))) return rc;
+    if ((rc = launch_linear(ws.h1, 512, w->fstn_fc2, ws.h2, 256, B, 1, st))) return rc;
+    if ((rc = launch_linear(ws.h2, 256, w->fstn_fc3, tfp, 4096, B, 0, st))) return rc;
+
+    // 3. trunk chain
+    a.w1 = tfp; a.b1 = nullptr;
+    a.w2 = w->feat_c2.w; a.b2 = w->feat_c2.b;
+    a.w3 = w->feat_c3.w; a.b3 = w->feat_c3.b;
+    hipLaunchKernelGGL(pn_chain_kernel<kTrunk>, dim3(B), dim3(kThreads), 0, st, a);
+    if ((rc = iq::check_launch("pn_chain_kernel<trunk>"))) return rc;
+    if ((rc = launch_linear(ws.gbuf, kFeat, w->cls_fc1, ws.h1, 512, B, 1, st))) return rc;
+    if ((rc = launch_linear(ws.h1, 512, w->cls_fc2, ws.h2, 256, B, 1, st))) return rc;
+    if ((rc = launch_linear(ws.h2, 256, w->cls_fc3, logits, w->cls_fc3.cout, B, 0, st))) return rc;
+    return IQ_OK;
+}
+
+// ---- host-side weight packing ---------------------------------------------------------------
+extern "C" int iq_padded_cout(int cout) { return (cout + 31) / 32 * 32; }
+
+extern "C" size_t iq_packed_floats(int cout, int cin) { return (size_t)iq_padded_cout(cout) * cin; }
+
+extern "C" int iq_pack_weight(const float* w, float* out, int cout, int cin) {
+    IQ_REQUIRE(w && out && cout >= 1 && cin >= 8 && cin % 8 == 0, "iq_pack_weight: cout=%d cin=%d", cout, cin);
+    const int KB = cin / 8, ntiles = iq_padded_cout(cout) / 32;
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int n = nt * 32 + (lane & 31), k = 8 * kb + 4 * (lane >> 5) + j;
+                    out[(((size_t)nt * KB + kb) * 64 + lane) * 4 + j] = n < cout ? w[(size_t)n * cin + k] : 0.f;
+                }
+    return IQ_OK;
+}
+
+extern "C" int iq_pack_fstn_fc3(const float* w, const float* b, float* out_w, float* out_b, int32_t* perm) {
+    IQ_REQUIRE(w && b && out_w && out_b, "iq_pack_fstn_fc3: null pointer");
+    // Output element e of the layer must be element e of the packed B image of trans_feat for the
+    // product f1 @ trans_feat (models/pointnet.py:74-76): B[k][n] = trans_feat[k][n], i.e. source
+    // row k*64 + n of fc3, at e = ((nt*8 + kb)*64 + lane)*4 + j.
+    float* tmp = new float[4096 * 256];
+    for (int nt = 0; nt < 2; ++nt)
+        for (int kb = 0; kb < 8; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int n = nt * 32 + (lane & 31), k = 8 * kb + 4 * (lane >> 5) + j;
+                    const int e = ((nt * 8 + kb) * 64 + lane) * 4 + j;
+                    const int src = k * 64 + n;
+                    for (int c = 0; c < 256; ++c) tmp[(size_t)e * 256 + c] = w[(size_t)src * 256 + c];
+                    out_b[e] = b[src] + (k == n ? 1.f : 0.f);
+                    if (perm) perm[e] = src;
+                }
+    const int rc = iq_pack_weight(tmp, out_w, 4096, 256);
+    delete[] tmp;
+    return rc;
+}

@@ -1,0 +1,142 @@
+"""torch-tensor front end of the C ABI (include/iq.h).  PyTorch only owns the device memory and
+the stream; all arithmetic happens in libiq_hip.so.  Every function raises if a tensor is not on
+a GPU - there is no CPU fallback."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.IqError("%s must be a CUDA/HIP tensor (the HIP path has no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise _lib.IqError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise _lib.IqError("%s must be contiguous" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def as_i32(x, device):
+    """int64 ndarray/tensor -> int32 device tensor (indices are int32 at the ABI)."""
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    return x.to(device=device, dtype=torch.int32).contiguous()
+
+
+def region_bitmask(regions):
+    """Iterable of region ids -> python int bit mask."""
+    m = 0
+    for r in regions:
+        m |= 1 << int(r)
+    return m
+
+
+def masks_to_tensor(masks, device):
+    """uint64 bit masks as an int64-typed device tensor (same bits)."""
+    arr = np.asarray(masks, dtype=np.uint64).view(np.int64)
+    return torch.from_numpy(np.ascontiguousarray(arr)).to(device)
+
+
+def mask_shapley(cloud, region_id, orders, center, channel_first=False):
+    """cloud (N,3) f32, region_id (N,) i32, orders (bs,R) i32, center (3,) f32 ->
+    (bs*(R+1), N, 3) or (bs*(R+1), 3, N)."""
+    lib = _lib.load()
+    n = cloud.shape[0]
+    bs, r = orders.shape
+    shape = (bs * (r + 1), 3, n) if channel_first else (bs * (r + 1), n, 3)
+    out = torch.empty(shape, dtype=torch.float32, device=cloud.device)
+    _lib.check(lib.iq_mask_shapley(_dev(cloud, torch.float32, "cloud"), _dev(region_id, torch.int32, "region_id"),
+                                   _dev(orders, torch.int32, "orders"), _dev(center, torch.float32, "center"),
+                                   _p(out), n, r, bs, int(channel_first), _stream()), "iq_mask_shapley")
+    return out
+
+
+def mask_interaction(cloud, region_id, pairs, ctx_mask, center, num_regions):
+    """pairs (nb,2) i32, ctx_mask (nb,) i64 (bit masks) -> (4*nb, 3, N)."""
+    lib = _lib.load()
+    n = cloud.shape[0]
+    nb = pairs.shape[0]
+    out = torch.empty((4 * nb, 3, n), dtype=torch.float32, device=cloud.device)
+    _lib.check(lib.iq_mask_interaction(_dev(cloud, torch.float32, "cloud"), _dev(region_id, torch.int32, "region_id"),
+                                       _dev(pairs, torch.int32, "pairs"), _dev(ctx_mask, torch.int64, "ctx_mask"),
+                                       _dev(center, torch.float32, "center"), _p(out), n, num_regions, nb,
+                                       _stream()), "iq_mask_interaction")
+    return out
+
+
+def mask_coalitions(cloud, region_id, keep, center, channel_first=False):
+    lib = _lib.load()
+    n = cloud.shape[0]
+    b = keep.shape[0]
+    shape = (b, 3, n) if channel_first else (b, n, 3)
+    out = torch.empty(shape, dtype=torch.float32, device=cloud.device)
+    _lib.check(lib.iq_mask_coalitions(_dev(cloud, torch.float32, "cloud"), _dev(region_id, torch.int32, "region_id"),
+                                      _dev(keep, torch.int64, "keep"), _dev(center, torch.float32, "center"),
+                                      _p(out), n, b, int(channel_first), _stream()), "iq_mask_coalitions")
+    return out
+
+
+def reward(logits, label, modified=True):
+    lib = _lib.load()
+    b, c = logits.shape
+    v = torch.empty((b,), dtype=torch.float32, device=logits.device)
+    _lib.check(lib.iq_reward(_dev(logits, torch.float32, "logits"), int(label), int(modified), _p(v), b, c,
+                             _stream()), "iq_reward")
+    return v
+
+
+def shapley_accum(v, orders, snap_counts=None):
+    """v (S*(R+1),) f32, orders (S,R) i32 -> (phi_sum (R,) f64, sv_rows (S,R) f64, snaps or None)."""
+    lib = _lib.load()
+    s, r = orders.shape
+    dev = v.device
+    sv_rows = torch.zeros((max(s, 1), r), dtype=torch.float64, device=dev)
+    phi = torch.empty((r,), dtype=torch.float64, device=dev)
+    snaps = None
+    counts = None
+    n_snap = 0
+    if snap_counts is not None and len(snap_counts) > 0:
+        counts = torch.tensor(list(snap_counts), dtype=torch.int32, device=dev)
+        n_snap = counts.numel()
+        snaps = torch.zeros((n_snap, r), dtype=torch.float64, device=dev)
+    _lib.check(lib.iq_shapley_accum(_dev(v, torch.float32, "v"), _dev(orders, torch.int32, "orders"), _p(sv_rows),
+                                    _p(phi), _p(counts), n_snap, _p(snaps), r, s, _stream()), "iq_shapley_accum")
+    return phi, sv_rows[:s], snaps
+
+
+def interaction_reduce(v):
+    lib = _lib.load()
+    n = v.numel() // 4
+    out = torch.empty((n,), dtype=torch.float32, device=v.device)
+    _lib.check(lib.iq_interaction_reduce(_dev(v, torch.float32, "v"), _p(out), n, _stream()), "iq_interaction_reduce")
+    return out
+
+
+def region_assign(cloud, fps_idx):
+    lib = _lib.load()
+    n = cloud.shape[0]
+    r = fps_idx.shape[0]
+    out = torch.empty((n,), dtype=torch.int32, device=cloud.device)
+    _lib.check(lib.iq_region_assign(_dev(cloud, torch.float32, "cloud"), _dev(fps_idx, torch.int32, "fps_idx"),
+                                    _p(out), n, r, _stream()), "iq_region_assign")
+    return out
+
+
+def fps(xyz, npoint):
+    """xyz (B,N,3) f32 -> (B,npoint) i32."""
+    lib = _lib.load()
+    b, n, _ = xyz.shape
+    out = torch.empty((b, npoint), dtype=torch.int32, device=xyz.device)
+    _lib.check(lib.iq_fps(_dev(xyz, torch.float32, "xyz"), _p(out), b, n, npoint, _stream()), "iq_fps")
+    return out

@@ -1,0 +1,80 @@
+"""CPU: the C-ABI library loads, exports every symbol include/iq.h declares, and its host-side
+helpers (weight packing, sizes) behave.  No compute call is made - there is no GPU here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from interpret_quality_amd import _lib, build
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build(verbose=False)  # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def test_header_symbols_exported_and_bound(lib):
+    header = open(os.path.join(REPO, "include", "iq.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)  # drop comments
+    declared = set(re.findall(r"\b(iq_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.iq_version() >= 100
+
+
+def test_pack_weight_layout(lib):
+    rng = np.random.default_rng(0)
+    cout, cin = 40, 16
+    w = rng.standard_normal((cout, cin)).astype(np.float32)
+    assert lib.iq_padded_cout(cout) == 64
+    out = np.empty(lib.iq_packed_floats(cout, cin), dtype=np.float32)
+    assert lib.iq_pack_weight(w.ctypes.data, out.ctypes.data, cout, cin) == 0
+    kb_n = cin // 8
+    for nt in range(2):
+        for kb in range(kb_n):
+            for lane in range(64):
+                for j in range(4):
+                    n, k = nt * 32 + (lane & 31), 8 * kb + 4 * (lane >> 5) + j
+                    want = w[n, k] if n < cout else 0.0
+                    assert out[((nt * kb_n + kb) * 64 + lane) * 4 + j] == want
+    assert lib.iq_pack_weight(w.ctypes.data, out.ctypes.data, cout, 12) != 0  # cin % 8
+    assert b"cin" in lib.iq_last_error()
+
+
+def test_pack_fstn_fc3_is_a_row_permutation_plus_identity(lib):
+    rng = np.random.default_rng(1)
+    w = rng.standard_normal((4096, 256)).astype(np.float32)
+    b = rng.standard_normal(4096).astype(np.float32)
+    ow = np.empty(lib.iq_packed_floats(4096, 256), dtype=np.float32)
+    ob = np.empty(4096, dtype=np.float32)
+    perm = np.empty(4096, dtype=np.int32)
+    assert lib.iq_pack_fstn_fc3(w.ctypes.data, b.ctypes.data, ow.ctypes.data, ob.ctypes.data, perm.ctypes.data) == 0
+    assert sorted(perm.tolist()) == list(range(4096))
+    k, n = perm // 64, perm % 64
+    np.testing.assert_array_equal(ob, b[perm] + (k == n).astype(np.float32))
+    # packed rows = permuted rows run through iq_pack_weight
+    ref = np.empty_like(ow)
+    wp = np.ascontiguousarray(w[perm])
+    assert lib.iq_pack_weight(wp.ctypes.data, ref.ctypes.data, 4096, 256) == 0
+    np.testing.assert_array_equal(ow, ref)
+
+
+def test_workspace_and_flops(lib):
+    assert lib.iq_pointnet_workspace_bytes(0, 1, 1024, 32) > 0
+    small = lib.iq_pointnet_workspace_bytes(100, 1, 1024, 32)
+    big = lib.iq_pointnet_workspace_bytes(3300, 1, 1024, 32)
+    assert big > small > 100 * 4096 * 4
+    assert abs(lib.iq_pointnet_flops_per_coalition(1024) / 0.879e9 - 1) < 0.01
+
+
+def test_hip_path_refuses_cpu_tensors():
+    import torch
+    from interpret_quality_amd import hip_ops
+    with pytest.raises(_lib.IqError):
+        hip_ops.reward(torch.zeros(4, 10), 0)

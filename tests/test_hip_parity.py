@@ -1,0 +1,287 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the CPU oracle and
+the golden vectors generated from the reference.  Bit-exact for masks / indices / reductions over
+given v; 1e-4 relative (the north star's tolerance) for anything that runs the network."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from interpret_quality_amd import hip_ops, synth
+from interpret_quality_amd.pointnet import PointNetCls
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4  # north star: "within 1e-4 relative fp32"
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import ref_cpu
+    return ref_cpu
+
+
+@pytest.fixture(scope="module")
+def model(pointnet_sd):
+    m = PointNetCls(None)
+    m.load_state_dict(pointnet_sd)
+    return m.to(dev()).eval()
+
+
+def cloud_setup(oracle, ci, num_regions):
+    pts, label = synth.make_cloud(ci)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    fps = oracle.farthest_point_sample(data, num_regions)[0]
+    region_id = oracle.cal_region_id(data, fps)
+    return data, label, fps.numpy(), region_id
+
+
+# ------------------------------------------------------------------------------------------------
+# masking
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("num_regions,bs", [(8, 4), (32, 50), (32, 1)])
+@pytest.mark.parametrize("channel_first", [False, True])
+def test_mask_shapley_bitwise(oracle, num_regions, bs, channel_first):
+    data, _, _, region_id = cloud_setup(oracle, 0, num_regions)
+    orders = synth.make_orders(bs, num_regions, seed=3)
+    center = torch.mean(data, dim=1).squeeze()
+    want = oracle.shapley_masked_batch(data, center, orders, region_id)
+    if channel_first:
+        want = want.permute(0, 2, 1).contiguous()
+    d = dev()
+    got = hip_ops.mask_shapley(data[0].to(d), hip_ops.as_i32(region_id, d), hip_ops.as_i32(orders, d),
+                               center.to(d), channel_first=channel_first)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_mask_shapley_golden_checksum(oracle):
+    import hashlib
+    g = load_golden("pointnet_shapley_R32.npz")
+    pts, _ = synth.make_cloud(0)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    center = torch.mean(data, dim=1).squeeze()
+    d = dev()
+    got = hip_ops.mask_shapley(data[0].to(d), hip_ops.as_i32(g["c0_region_id"], d),
+                               hip_ops.as_i32(g["c0_orders"][:int(g["bs"])], d), center.to(d))
+    assert hashlib.sha256(got.cpu().numpy().tobytes()).hexdigest() == str(g["c0_masked_sha256"])
+
+
+def test_mask_interaction_bitwise(oracle):
+    g = load_golden("pointnet_interaction_R32.npz")
+    pts, _ = synth.make_cloud(int(g["cloud_id"]))
+    data = torch.from_numpy(pts).unsqueeze(0)
+    center = torch.mean(data, dim=1).squeeze()
+    d = dev()
+    for tag in ("ratio0", "ratio4", "ratio50", "ratio100"):
+        ctx = g[tag + "_contexts"]
+        for p, (ri, rj) in enumerate(g["pairs"]):
+            want = oracle.interaction_masked_batch(data.permute(0, 2, 1), center, g["region_id"], ri, rj, ctx[p])
+            nb = ctx.shape[1]
+            pairs = np.tile(np.array([[ri, rj]]), (nb, 1))
+            masks = [hip_ops.region_bitmask(c) for c in ctx[p]]
+            got = hip_ops.mask_interaction(data[0].to(d), hip_ops.as_i32(g["region_id"], d), hip_ops.as_i32(pairs, d),
+                                           hip_ops.masks_to_tensor(masks, d), center.to(d), 32)
+            assert torch.equal(got.cpu(), want.contiguous())
+
+
+def test_mask_empty_batch():
+    d = dev()
+    cloud = torch.zeros((1024, 3), device=d)
+    rid = torch.zeros((1024,), dtype=torch.int32, device=d)
+    out = hip_ops.mask_shapley(cloud, rid, torch.zeros((0, 32), dtype=torch.int32, device=d), torch.zeros(3, device=d))
+    assert out.shape == (0, 1024, 3)
+
+
+# ------------------------------------------------------------------------------------------------
+# reward / reductions
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("modified", [True, False])
+def test_reward(oracle, modified):
+    g = load_golden("pointnet_shapley_R32.npz")
+    logits = torch.from_numpy(g["c1_logits"])
+    for label in (0, 1, 9):
+        want = oracle.get_reward(logits, torch.tensor([label]), "modified" if modified else "normal")
+        got = hip_ops.reward(logits.to(dev()), label, modified)
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-6, atol=2e-6)
+    if not modified:
+        np.testing.assert_allclose(hip_ops.reward(logits[:16].to(dev()), 1, False).cpu().numpy(), g["c1_v_normal16"],
+                                   rtol=2e-6, atol=2e-6)
+
+
+def test_shapley_accum_bitwise():
+    rng = np.random.default_rng(0)
+    s, r = 1000, 32
+    orders = synth.make_orders(s, r, seed=2)
+    v = rng.standard_normal(s * (r + 1)).astype(np.float32)
+    # the reference's host loop (tools/final_common.py:92-96)
+    phi = np.zeros((r,))
+    rows = np.zeros((s, r))
+    snaps_want = {}
+    for o in range(s):
+        vo = v[o * (r + 1):(o + 1) * (r + 1)]
+        dv = vo[1:] - vo[:-1]
+        phi[orders[o]] += dv
+        rows[o, orders[o]] += dv
+        if o + 1 in (100, 500, 1000):
+            snaps_want[o + 1] = phi.copy()
+    d = dev()
+    got_phi, got_rows, snaps = hip_ops.shapley_accum(torch.from_numpy(v).to(d), hip_ops.as_i32(orders, d),
+                                                     snap_counts=[100, 500, 1000])
+    assert np.array_equal(got_phi.cpu().numpy(), phi)
+    assert np.array_equal(got_rows.cpu().numpy(), rows)
+    for k, c in enumerate((100, 500, 1000)):
+        assert np.array_equal(snaps[k].cpu().numpy(), snaps_want[c])
+    # efficiency: every permutation telescopes to v(N) - v(empty)
+    np.testing.assert_allclose(got_rows.cpu().numpy().sum(1),
+                               (v.reshape(s, r + 1)[:, -1].astype(np.float64) - v.reshape(s, r + 1)[:, 0]), atol=1e-5)
+
+
+def test_interaction_reduce_bitwise(oracle):
+    g = load_golden("pointnet_interaction_R32.npz")
+    for tag in ("ratio4", "ratio50"):
+        logits = torch.from_numpy(g[tag + "_logits"])
+        lbl = torch.tensor([0])
+        p, c4, k = logits.shape
+        v = oracle.get_reward(logits.reshape(p * c4, k), lbl)
+        got = hip_ops.interaction_reduce(v.to(dev())).cpu().numpy().astype(np.float64).reshape(p, c4 // 4)
+        want = oracle.compute_order_interaction(logits, lbl)
+        assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------
+# geometry
+# ------------------------------------------------------------------------------------------------
+def test_fps_golden():
+    g = load_golden("geometry.npz")
+    pts, _ = synth.make_cloud(3)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    collapsed = data.clone()
+    collapsed[0, 300:, :] = collapsed[0, :300].mean(dim=0)
+    both = torch.cat([data, collapsed], dim=0).to(dev())
+    for s in (32, 128, 512):
+        got = hip_ops.fps(both, s).cpu().numpy()
+        assert np.array_equal(got, g["fps_%d" % s]), "FPS S=%d differs" % s
+
+
+@pytest.mark.parametrize("num_regions", [8, 32])
+def test_region_assign(oracle, num_regions):
+    g = load_golden("pointnet_shapley_R%d.npz" % num_regions)
+    for ci in (0, 1):
+        pts, _ = synth.make_cloud(ci)
+        d = dev()
+        got = hip_ops.region_assign(torch.from_numpy(pts).to(d), hip_ops.as_i32(g["c%d_fps_index" % ci], d)).cpu().numpy()
+        want = g["c%d_region_id" % ci]
+        diff = np.nonzero(got != want)[0]
+        # index-valued: allow only genuine near-ties of the cancellation-prone expanded distance
+        if len(diff):
+            data = torch.from_numpy(pts).unsqueeze(0)
+            dist = oracle.square_distance(data, data[:, torch.from_numpy(g["c%d_fps_index" % ci]), :])[0].numpy()
+            for p in diff:
+                assert abs(dist[p, got[p]] - dist[p, want[p]]) < 1e-6, "point %d assigned to a non-tied centre" % p
+        assert len(diff) <= 2
+
+
+# ------------------------------------------------------------------------------------------------
+# PointNet
+# ------------------------------------------------------------------------------------------------
+def test_pointnet_dense_forward(model, oracle, pointnet_sd):
+    g = load_golden("pointnet_dense.npz")
+    x = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in range(4)]).permute(0, 2, 1).contiguous()
+    logits, trans_feat, _ = model(x.to(dev()))
+    assert rel_err(logits.cpu().numpy(), g["logits"]) < RTOL
+    o_logits, o_tf, _ = oracle.PointNetOracle(pointnet_sd)(x)
+    assert rel_err(trans_feat.cpu().numpy(), o_tf.numpy()) < RTOL
+    assert rel_err(logits.cpu().numpy(), o_logits.numpy()) < RTOL
+
+
+@pytest.mark.parametrize("num_regions", [8, 32])
+def test_pointnet_coalitions_vs_golden_and_oracle(model, oracle, num_regions):
+    """Shapley rows: fused coalition path == reference logits (golden) within 1e-4."""
+    g = load_golden("pointnet_shapley_R%d.npz" % num_regions)
+    d = dev()
+    ns = int(g["num_samples"])
+    for ci in g["cloud_ids"]:
+        p = "c%d_" % ci
+        pts, label = synth.make_cloud(int(ci))
+        orders = g[p + "orders"]
+        data = torch.from_numpy(pts).unsqueeze(0)
+        center = torch.mean(data, dim=1)  # same centre bits as the reference run
+        keep = []
+        for o in range(ns):
+            for i in range(num_regions + 1):
+                keep.append(hip_ops.region_bitmask(orders[o][:i]))
+        logits = model.coalition_logits(data.to(d), center.to(d), hip_ops.as_i32(g[p + "region_id"], d).reshape(1, -1),
+                                        hip_ops.masks_to_tensor(keep, d), None, num_regions=num_regions)
+        assert rel_err(logits.cpu().numpy(), g[p + "logits"]) < RTOL
+        v = hip_ops.reward(logits, label, True)
+        phi, _, _ = hip_ops.shapley_accum(v, hip_ops.as_i32(orders, d))
+        phi = phi.cpu().numpy() / ns
+        assert np.abs(phi - g[p + "phi"]).max() < RTOL * np.abs(g[p + "phi"]).max()
+        assert abs(phi.sum() - float(g[p + "norm_factor"])) < 1e-4 * abs(float(g[p + "norm_factor"])) + 1e-5
+
+
+def test_pointnet_fused_equals_dense_on_materialised_clouds(model, oracle):
+    """Exactness of the dedup: coalition path == the same kernels on the masked clouds, bitwise."""
+    d = dev()
+    data, _, _, region_id = cloud_setup(oracle, 2, 32)
+    orders = synth.make_orders(3, 32, seed=5)
+    center = torch.mean(data, dim=1)
+    keep = [hip_ops.region_bitmask(orders[o][:i]) for o in range(3) for i in range(33)]
+    rid = hip_ops.as_i32(region_id, d)
+    fused = model.coalition_logits(data.to(d), center.to(d), rid.reshape(1, -1), hip_ops.masks_to_tensor(keep, d),
+                                   None, num_regions=32)
+    masked = hip_ops.mask_shapley(data[0].to(d), rid, hip_ops.as_i32(orders, d), center[0].to(d), channel_first=True)
+    dense, _, _ = model(masked)
+    assert torch.equal(fused, dense)
+
+
+def test_pointnet_interaction_vs_golden(model):
+    g = load_golden("pointnet_interaction_R32.npz")
+    d = dev()
+    pts, _ = synth.make_cloud(int(g["cloud_id"]))
+    data = torch.from_numpy(pts).unsqueeze(0)
+    center = torch.mean(data, dim=1)
+    rid = hip_ops.as_i32(g["region_id"], d).reshape(1, -1)
+    for tag in ("ratio0", "ratio4", "ratio50", "ratio100"):
+        ctx = g[tag + "_contexts"]
+        keep = []
+        for p, (ri, rj) in enumerate(g["pairs"]):
+            for c in ctx[p]:
+                s = hip_ops.region_bitmask(c)
+                bi, bj = 1 << int(ri), 1 << int(rj)
+                keep += [s | bi | bj, s | bi, s | bj, s]
+        logits = model.coalition_logits(data.to(d), center.to(d), rid, hip_ops.masks_to_tensor(keep, d), None,
+                                        num_regions=32)
+        want = g[tag + "_logits"].reshape(-1, 10)
+        assert rel_err(logits.cpu().numpy(), want) < RTOL
+
+
+def test_pointnet_multi_cloud_batch(model, oracle):
+    """Coalitions of several clouds (poses) in one launch via cloud_of."""
+    d = dev()
+    datas, cents, rids = [], [], []
+    for ci in (0, 1, 2):
+        data, _, _, region_id = cloud_setup(oracle, ci, 8)
+        datas.append(data[0]); cents.append(torch.mean(data, dim=1)[0]); rids.append(torch.from_numpy(region_id))
+    clouds = torch.stack(datas).to(d)
+    centers = torch.stack(cents).to(d)
+    region_id = torch.stack(rids).to(device=d, dtype=torch.int32)
+    keep = [0, 1, 3, 0xff, 0x55, 0xaa, 0x80, 0x7f, 0xff]
+    cloud_of = [0, 0, 1, 1, 2, 2, 0, 1, 2]
+    got = model.coalition_logits(clouds, centers, region_id, hip_ops.masks_to_tensor(keep, d),
+                                 torch.tensor(cloud_of, dtype=torch.int32, device=d), num_regions=8)
+    for k, (m, c) in enumerate(zip(keep, cloud_of)):
+        one = model.coalition_logits(clouds[c:c + 1].contiguous(), centers[c:c + 1].contiguous(),
+                                     region_id[c:c + 1].contiguous(), hip_ops.masks_to_tensor([m], d), None,
+                                     num_regions=8)
+        assert torch.equal(got[k], one[0])
