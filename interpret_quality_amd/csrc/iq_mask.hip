@@ -83,10 +83,10 @@ __global__ __launch_bounds__(kThreads) void mask_rows_kernel(MaskArgs a) {
 }
 
 int launch(MaskArgs a, iq_stream_t stream) {
+    if (a.rows == 0) return IQ_OK;
     IQ_REQUIRE(a.cloud && a.region_id && a.center && a.out, "mask: null pointer");
     IQ_REQUIRE(a.N > 0 && a.N % 4 == 0 && a.N <= IQ_MAX_POINTS, "mask: N=%d must be a multiple of 4 in (0,%d]", a.N, IQ_MAX_POINTS);
     IQ_REQUIRE(a.R >= 0 && a.R <= IQ_MAX_REGIONS, "mask: R=%d out of range", a.R);
-    if (a.rows == 0) return IQ_OK;
     const int grid = (a.rows + kRowsPerWg - 1) / kRowsPerWg;
     hipLaunchKernelGGL(mask_rows_kernel, dim3(grid), dim3(kThreads), 0, iq::as_stream(stream), a);
     return iq::check_launch("mask_rows_kernel");
