@@ -164,10 +164,17 @@ int iq_pointnet_coalitions(const iq_pointnet_weights* w /*host struct of device 
                            int B, int nclouds, int N, int R, int channel_first,
                            iq_stream_t stream);
 
-/* Name and average-free launch counters of the dominant kernel, for bench.py's roofline leg:
- * iq_pointnet_flops_per_coalition() = algorithmic FLOP of the dense reference network
- * (0.879 GFLOP). */
+/* Algorithmic FLOP of the dense reference network per coalition (0.879 GFLOP at
+ * N = 1024), the basis of bench.py's roofline figures. */
 double iq_pointnet_flops_per_coalition(int N);
+
+/* Optional HIP-event profiler (bench.py's roofline leg).  While enabled, iq_pointnet_coalitions
+ * brackets its chain-kernel launches with hipEvents recorded on the launch stream.
+ * iq_profile_read(slot) synchronises on the recorded events of that slot, returns their summed
+ * duration and count, and forgets them.  Slots: 0 = input-STN pre-pool chain, 1 = feature-STN
+ * chain, 2 = trunk chain, 3 = whole iq_pointnet_coalitions call. */
+int iq_profile_enable(int on);
+int iq_profile_read(int slot, double* total_ms, int* launches);
 
 #ifdef __cplusplus
 }

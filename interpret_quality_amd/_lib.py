@@ -59,6 +59,8 @@ SIGNATURES = {
     "iq_pointnet_coalitions": (_I, [ctypes.POINTER(PointNetWeights), _P, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                     _I, _I, _I, _I, _I, _P]),
     "iq_pointnet_flops_per_coalition": (ctypes.c_double, [_I]),
+    "iq_profile_enable": (_I, [_I]),
+    "iq_profile_read": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
 }
 
 _lib = None
@@ -73,6 +75,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own libamdhip64.so.7; load it FIRST so that libiq_hip.so binds to the same
+    # HIP runtime instance (two runtimes in one process do not share devices, streams or memory).
+    import torch  # noqa: F401
     path = lib_path()
     if not os.path.exists(path):
         raise IqError("libiq_hip.so not found at %s - run `python -m interpret_quality_amd.build` "

@@ -16,6 +16,7 @@
 // (XOR-swizzled, conflict-free ds_read_b128), B operands (weights) stream from L2 in a
 // pre-packed fragment order (1 KiB contiguous per wave-load).  LDS = 52 KB -> 3 workgroups/CU.
 #include "iq_common.h"
+#include "iq_profile.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -498,6 +499,7 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
     Workspace ws = carve(workspace, B, nclouds, N, R);
     hipStream_t st = iq::as_stream(stream);
     int rc;
+    iq::ProfileSpan call_span(iq::kSlotCall, st);
 
     hipLaunchKernelGGL(pn_prepare_kernel, dim3(nclouds), dim3(kThreads), 0, st, region_id, ws.rank, ws.rsize, N, R);
     if ((rc = iq::check_launch("pn_prepare_kernel"))) return rc;
@@ -520,7 +522,10 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
     a.w3 = w->stn_c3.w; a.b3 = w->stn_c3.b;
     a.out = ws.G;
     a.items = nclouds * (R + with_centre);
-    hipLaunchKernelGGL(pn_chain_kernel<kPrepool>, dim3(a.items), dim3(kThreads), 0, st, a);
+    {
+        iq::ProfileSpan span(iq::kSlotPrepool, st);
+        hipLaunchKernelGGL(pn_chain_kernel<kPrepool>, dim3(a.items), dim3(kThreads), 0, st, a);
+    }
     if ((rc = iq::check_launch("pn_chain_kernel<prepool>"))) return rc;
 
     hipLaunchKernelGGL(pn_stn_gather_kernel, dim3(B), dim3(kThreads), 0, st, ws.G, ws.rsize, keep, cloud_of, ws.gbuf,
@@ -538,7 +543,10 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
     a.w3 = w->fstn_c3.w; a.b3 = w->fstn_c3.b;
     a.out = ws.gbuf;
     a.items = B;
-    hipLaunchKernelGGL(pn_chain_kernel<kFstn>, dim3(B), dim3(kThreads), 0, st, a);
+    {
+        iq::ProfileSpan span(iq::kSlotFstn, st);
+        hipLaunchKernelGGL(pn_chain_kernel<kFstn>, dim3(B), dim3(kThreads), 0, st, a);
+    }
     if ((rc = iq::check_launch("pn_chain_kernel<fstn>"))) return rc;
     float* tfp = trans_feat_packed ? trans_feat_packed : ws.tfp;
     if ((rc = launch_linear(ws.gbuf, kFeat, w->fstn_fc1, ws.h1, 512, B, 1, st))) return rc;
@@ -549,7 +557,10 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
     a.w1 = tfp; a.b1 = nullptr;
     a.w2 = w->feat_c2.w; a.b2 = w->feat_c2.b;
     a.w3 = w->feat_c3.w; a.b3 = w->feat_c3.b;
-    hipLaunchKernelGGL(pn_chain_kernel<kTrunk>, dim3(B), dim3(kThreads), 0, st, a);
+    {
+        iq::ProfileSpan span(iq::kSlotTrunk, st);
+        hipLaunchKernelGGL(pn_chain_kernel<kTrunk>, dim3(B), dim3(kThreads), 0, st, a);
+    }
     if ((rc = iq::check_launch("pn_chain_kernel<trunk>"))) return rc;
     if ((rc = launch_linear(ws.gbuf, kFeat, w->cls_fc1, ws.h1, 512, B, 1, st))) return rc;
     if ((rc = launch_linear(ws.h1, 512, w->cls_fc2, ws.h2, 256, B, 1, st))) return rc;

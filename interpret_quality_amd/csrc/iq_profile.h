@@ -1,0 +1,26 @@
+// RAII HIP-event bracket around a kernel launch, recorded on the launch stream (bench.py's
+// roofline leg reads the totals through iq_profile_read).  Costs nothing when disabled.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace iq {
+
+enum ProfileSlot { kSlotPrepool = 0, kSlotFstn = 1, kSlotTrunk = 2, kSlotCall = 3, kSlotMask = 4 };
+
+bool profile_enabled();
+
+class ProfileSpan {
+  public:
+    ProfileSpan(int which, hipStream_t st);
+    ~ProfileSpan();
+    ProfileSpan(const ProfileSpan&) = delete;
+    ProfileSpan& operator=(const ProfileSpan&) = delete;
+
+  private:
+    int which_;
+    hipStream_t st_;
+    bool on_;
+    hipEvent_t start_{}, stop_{};
+};
+
+}  // namespace iq

@@ -1,0 +1,99 @@
+"""Host-side mirror of the reference's shared Shapley kernel module (tools/final_common.py).
+
+Same function names, argument meaning and return types as the reference, so the stage scripts
+read the same; the arithmetic runs in libiq_hip.so.  For PointNet the masked clouds are never
+materialised (``model.coalition_logits``); for any other model the masking kernel writes the
+batch and the model consumes it, as in the reference.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import hip_ops
+from ._lib import IqError
+
+
+def _is_pointnet(args):
+    return args.model == "pointnet" or args.model == "pointnet_roty_da"  # tools/final_common.py:36
+
+
+def get_reward(logits, lbl, args):
+    """tools/final_common.py:11-24.  logits (B',C) -> v (B',)."""
+    modified = getattr(args, "softmax_type", "modified") != "normal"  # 'yi'/'minuslog' behave as 'modified'
+    return hip_ops.reward(logits.contiguous(), int(lbl[0]), modified)
+
+
+def cal_reward(model, data, lbl, args):
+    """tools/final_common.py:26-43.  data (B',N,3) -> (v (B',), logits (B',C))."""
+    x = data.permute(0, 2, 1).contiguous()
+    out = model(x)
+    logits = out[0] if _is_pointnet(args) else out
+    return get_reward(logits, lbl, args), logits
+
+
+def mask_data_batch(masked_data, center, orders, region_id, args):
+    """tools/final_common.py:46-61.  In-place on ``masked_data`` ((R+1)*bs, N, 3), which holds
+    bs*(R+1) copies of one cloud on entry (tools/final_common.py:88); one launch instead of
+    R*bs index assignments."""
+    dev = masked_data.device
+    cloud = masked_data[-1].clone()  # the last row of a block is never masked
+    out = hip_ops.mask_shapley(cloud, hip_ops.as_i32(region_id, dev), hip_ops.as_i32(np.asarray(orders), dev),
+                               center.contiguous(), channel_first=False)
+    masked_data.copy_(out)
+    return masked_data
+
+
+def prefix_keep_masks(orders, num_regions):
+    """(S,R) permutations -> (S*(R+1),) uint64 keep masks: row i of order o keeps orders[o][:i]."""
+    orders = np.asarray(orders, dtype=np.uint64)
+    bits = np.left_shift(np.uint64(1), orders)                       # (S,R)
+    pref = np.concatenate([np.zeros((orders.shape[0], 1), dtype=np.uint64),
+                           np.bitwise_or.accumulate(bits, axis=1)], axis=1)
+    return pref.reshape(-1)
+
+
+def shapley_logits(model, data, lbl, region_id, orders, args, center=None):
+    """Logits of all prefix coalitions of ``orders`` ((S,R) ndarray) for one cloud (1,N,3).
+    PointNet: fused coalition path; other models: mask kernel + model forward in batches of
+    ``args.shapley_batch_size`` permutations."""
+    dev = data.device
+    r = args.num_regions
+    if center is None:
+        center = torch.mean(data, dim=1)  # (1,3), tools/final_common.py:80
+    rid = hip_ops.as_i32(region_id, dev)
+    if hasattr(model, "coalition_logits"):
+        keep = hip_ops.masks_to_tensor(prefix_keep_masks(orders, r), dev)
+        return model.coalition_logits(data.contiguous(), center.reshape(1, 3).contiguous(), rid.reshape(1, -1),
+                                      keep, None, num_regions=r)
+    bs = args.shapley_batch_size
+    chunks = []
+    for i in range(0, len(orders), bs):
+        o = hip_ops.as_i32(np.asarray(orders[i:i + bs]), dev)
+        x = hip_ops.mask_shapley(data[0].contiguous(), rid, o, center.reshape(3).contiguous(), channel_first=True)
+        chunks.append(model(x))
+    return torch.cat(chunks, dim=0)
+
+
+def shap_sampling_all_regions_batch(model, data_disturb, lbl, region_id, load_order_list, args):
+    """tools/final_common.py:64-103.  Returns (region_shap_value (R,) float64 ndarray,
+    all_logits_this_pose (num_samples*(R+1), C) tensor).  As in the reference only
+    ``(num_samples // bs) * bs`` permutations are evaluated while the sum is divided by
+    ``num_samples`` (:78,:97); a batch size that does not divide num_samples is rejected up front
+    instead of tripping the assert at :99."""
+    bs = args.shapley_batch_size
+    if args.num_samples % bs != 0:
+        raise IqError("shapley_batch_size=%d does not divide num_samples=%d (tools/final_common.py:78,99)"
+                      % (bs, args.num_samples))
+    t_start = time.time()
+    orders = np.asarray(load_order_list[:args.num_samples])
+    with torch.no_grad():
+        logits = shapley_logits(model, data_disturb, lbl, region_id, orders, args)
+        v = get_reward(logits, lbl, args)
+        phi_sum, _, _ = hip_ops.shapley_accum(v, hip_ops.as_i32(orders, data_disturb.device))
+        region_shap_value = phi_sum.cpu().numpy()  # the only device->host sync of the pose
+    region_shap_value /= args.num_samples
+    assert logits.size()[0] == args.num_samples * (args.num_regions + 1)
+    if getattr(args, "verbose", True):
+        print("done time: ", time.time() - t_start)
+    return region_shap_value, logits
