@@ -174,6 +174,15 @@ double iq_pointnet_flops_per_coalition(int N);
  * duration and count, and forgets them.  Slots: 0 = input-STN pre-pool chain, 1 = feature-STN
  * chain, 2 = trunk chain, 3 = whole iq_pointnet_coalitions call. */
 int iq_profile_enable(int on);
+/* Experiment knob: selects between co-compiled kernel variants so that they can be timed
+ * interleaved in ONE process.  key 0 = L3 weight-streaming variant of the chain kernel. */
+int iq_set_tuning(int key, int value);
+/* Debug: workgroups per CU the runtime admits for the chain kernel variants (100*v0 + v2). */
+int iq_debug_chain_occupancy(void);
+/* Debug: per-phase shader-clock sums of the feature-STN chain (diagnostic STAMP instantiation, never
+ * used unless enabled).  enable != 0 arms and zeroes 8 counters; out_host (8 x u64 or NULL) receives
+ * the counters accumulated so far. */
+int iq_debug_stamps(int enable, unsigned long long* out_host);
 int iq_profile_read(int slot, double* total_ms, int* launches);
 
 #ifdef __cplusplus

@@ -60,6 +60,9 @@ SIGNATURES = {
                                     _I, _I, _I, _I, _I, _P]),
     "iq_pointnet_flops_per_coalition": (ctypes.c_double, [_I]),
     "iq_profile_enable": (_I, [_I]),
+    "iq_set_tuning": (_I, [_I, _I]),
+    "iq_debug_chain_occupancy": (_I, []),
+    "iq_debug_stamps": (_I, [_I, ctypes.POINTER(ctypes.c_ulonglong)]),
     "iq_profile_read": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
 }
 

@@ -19,6 +19,10 @@ bool g_enabled = false;
 
 bool profile_enabled() { return g_enabled; }
 
+namespace { int g_tune[kTuneCount] = {0}; }
+int tuning(int key) { return (key >= 0 && key < kTuneCount) ? g_tune[key] : 0; }
+void set_tuning(int key, int value) { if (key >= 0 && key < kTuneCount) g_tune[key] = value; }
+
 ProfileSpan::ProfileSpan(int which, hipStream_t st) : which_(which), st_(st), on_(g_enabled) {
     if (!on_) return;
     (void)hipEventCreate(&start_);
@@ -33,6 +37,12 @@ ProfileSpan::~ProfileSpan() {
     g_spans.push_back(Span{start_, stop_, which_});
 }
 }  // namespace iq
+
+extern "C" int iq_set_tuning(int key, int value) {
+    IQ_REQUIRE(key >= 0 && key < iq::kTuneCount, "iq_set_tuning: key %d", key);
+    iq::set_tuning(key, value);
+    return IQ_OK;
+}
 
 extern "C" int iq_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(iq::g_mu);

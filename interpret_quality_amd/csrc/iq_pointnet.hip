@@ -30,16 +30,18 @@ constexpr int kThreads = 256;
 
 enum ChainMode { kPrepool = 0, kFstn = 1, kTrunk = 2 };
 
-// LDS activation image: row-major [row][k], 16-byte groups XOR-swizzled by (row & 15).
-__device__ __forceinline__ int swz(int row, int k, int ld) {
-    return row * ld + ((((k >> 2) ^ (row & 15))) << 2) + (k & 3);
-}
+// LDS activation images are row-major [row][k] with the row stride padded by 4 floats (68 / 132):
+// a 16-lane ds_read_b128 group reads 16 different rows at one k, i.e. bank offsets 4*row mod 64 ->
+// conflict-free, and every address in the MFMA loops is ONE per-lane base plus an immediate.
+constexpr int kLd1 = 64 + 4;    // act0 / act1 (64 channels)
+constexpr int kLd2 = 128 + 4;   // act2 (128 channels)
 
 // A fragment of v_mfma_f32_32x32x2_f32 for K-block kb (8 k values): lane (row = l&31, h = l>>5)
 // holds k = 8kb + 4h + j in element j; MFMA step j consumes element j of A and B.
-__device__ __forceinline__ f32x4 lds_a(const float* act, int ld, int m0, int kb, int lane) {
-    const int row = m0 + (lane & 31);
-    return *reinterpret_cast<const f32x4*>(act + row * ld + (((2 * kb + (lane >> 5)) ^ (row & 15)) << 2));
+// abase = act + (lane&31)*LD + 4*(lane>>5).
+template <int LD>
+__device__ __forceinline__ f32x4 lds_frag(const float* abase, int mt, int kb) {
+    return *reinterpret_cast<const f32x4*>(abase + mt * 32 * LD + 8 * kb);
 }
 
 // B fragment from the packed weight image: ((nt*KB + kb)*64 + lane)*4.
@@ -64,15 +66,16 @@ __device__ __forceinline__ float max16(f32x16 c) {
 }
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5).
-__device__ __forceinline__ int c_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ constexpr int c_row_i(int i) { return (i & 3) + 8 * (i >> 2); }
+__device__ __forceinline__ int c_row(int i, int lane) { return c_row_i(i) + 4 * (lane >> 5); }
 
 struct ChainArgs {
     const float* clouds;       // strides below, in floats
     int ps, cs, cl;            // point, channel, cloud stride
     const float* centers;      // (nclouds,3)
-    const int32_t* region_id;  // (nclouds,N)
-    const uint16_t* rank;      // (nclouds,N) rank of a point inside its region
-    const int32_t* rsize;      // (nclouds,R)
+    const uint16_t* sorted_pts;  // (nclouds,N) point indices grouped by region (ascending inside a region)
+    const int32_t* roff;         // (nclouds,R+1) start of each region in sorted_pts
+    const int32_t* item_order;   // (items) launch order (largest coalitions first) or null
     const uint64_t* keep;      // (items) or null = keep everything       [kFstn/kTrunk]
     const int32_t* cloud_of;   // (items) or null                          [kFstn/kTrunk]
     const float* trans;        // (items,9) input transform                [kFstn/kTrunk]
@@ -85,12 +88,14 @@ struct ChainArgs {
     const float* b3;
     float* out;                // (items,1024)
     int N, R, items, nclouds, with_centre;
+    unsigned long long* stamps;  // diagnostic build only
 };
 
+// ---- L3: 128 -> 1024 for one 64-row chunk; wave `wave` owns the n-tiles q*4 + wave ------------
+// Variant 0: B fragments two K-blocks ahead in a small register ring, compiler-scheduled.
 template <int MTS>
-__device__ __forceinline__ void l3_pass(const float* __restrict__ w3, const float* act2, int wave, int lane,
-                                        float (&runmax)[8]) {
-    // B fragments run two K-blocks ahead of the MFMAs, across n-tile boundaries as well.
+__device__ __forceinline__ void l3_pass_v0(const float* __restrict__ w3, const float* abase, int wave, int lane,
+                                           float (&runmax)[8]) {
     const float* wq = w3 + (size_t)wave * 16 * 256;
     f32x4 b0 = glb_b(wq, lane);
     f32x4 b1 = glb_b(wq + 256, lane);
@@ -101,12 +106,8 @@ __device__ __forceinline__ void l3_pass(const float* __restrict__ w3, const floa
 #pragma unroll 4
         for (int kb = 0; kb < 16; ++kb) {
             const f32x4 bn = (kb + 2 < 16) ? glb_b(wq + (kb + 2) * 256, lane) : glb_b(wnext + (kb + 2 - 16) * 256, lane);
-            const f32x4 a0 = lds_a(act2, 128, 0, kb, lane);
-            acc0 = mfma4(a0, b0, acc0);
-            if (MTS == 2) {
-                const f32x4 a1 = lds_a(act2, 128, 32, kb, lane);
-                acc1 = mfma4(a1, b0, acc1);
-            }
+            acc0 = mfma4(lds_frag<kLd2>(abase, 0, kb), b0, acc0);
+            if (MTS == 2) acc1 = mfma4(lds_frag<kLd2>(abase, 1, kb), b0, acc1);
             b0 = b1;
             b1 = bn;
         }
@@ -118,16 +119,99 @@ __device__ __forceinline__ void l3_pass(const float* __restrict__ w3, const floa
     }
 }
 
-template <int MODE>
+// Variant 2: an 8-deep register ring of B fragments (32 VGPRs) that runs 8 K-blocks (4 096 MFMA
+// cycles) ahead and never drains: it rolls over n-tile boundaries and, through `ring`, over chunk
+// boundaries (the last n-tile of a chunk prefetches the first K-blocks of n-tile 0).  A fragments are
+// double-buffered one K-block ahead.  sched_group_barrier pins the issue order inside each K-block:
+// LDS reads of the next block, the MFMAs of this one, one ring refill.
+struct BRing {
+    f32x4 r[8];
+};
+
+__device__ __forceinline__ void bring_init(BRing& ring, const float* __restrict__ w3, int wave, int lane) {
+    const float* wq = w3 + (size_t)wave * 16 * 256 + lane * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ring.r[i] = *reinterpret_cast<const f32x4*>(wq + i * 256);
+}
+
+template <int MTS>
+__device__ __forceinline__ void l3_pass_v2(const float* __restrict__ w3, const float* abase, int wave, int lane,
+                                           float (&runmax)[8], BRing& ring) {
+    const float* w0 = w3 + (size_t)wave * 16 * 256 + lane * 4;
+    const float* wq = w0;
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {
+        const float* wn = (q < 7) ? wq + 4 * 16 * 256 : w0;
+        f32x16 acc0 = {0}, acc1 = {0};
+        f32x4 a0n = lds_frag<kLd2>(abase, 0, 0), a1n = a0n;
+        if (MTS == 2) a1n = lds_frag<kLd2>(abase, 1, 0);
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            const f32x4 a0 = a0n, a1 = a1n;
+            if (kb + 1 < 16) {
+                a0n = lds_frag<kLd2>(abase, 0, kb + 1);
+                if (MTS == 2) a1n = lds_frag<kLd2>(abase, 1, kb + 1);
+            }
+            const f32x4 bk = ring.r[kb & 7];
+            acc0 = mfma4(a0, bk, acc0);
+            if (MTS == 2) acc1 = mfma4(a1, bk, acc1);
+            ring.r[kb & 7] = *reinterpret_cast<const f32x4*>((kb < 8 ? wq + (kb + 8) * 256 : wn + (kb - 8) * 256));
+            if (kb + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, MTS, 0);  // DS reads of K-block kb+1
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * MTS, 0);               // MFMAs of K-block kb
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // ring refill
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float m = max16(acc0);
+        if (MTS == 2) m = fmaxf(m, max16(acc1));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? fmaxf(runmax[i], m) : runmax[i];
+        wq = wn;
+    }
+}
+
+// Row i of a coalition's compacted point list -> point index (N = the centre).  kstart[r] is the
+// position of region r's first point in the list (kept regions only advance it); a row past the
+// kept points is the centre when one is appended, else a replica of the last kept row (padding:
+// duplicates never change a max).
+__device__ __forceinline__ int row_to_point(int i, int nkept, bool add_centre, const int* kstart, int R,
+                                            const uint16_t* __restrict__ sorted_pts, const int32_t* __restrict__ roff,
+                                            int N) {
+    if (i >= nkept) {
+        if (add_centre) return N;
+        i = nkept - 1;
+    }
+    int r = 0;
+    for (int j = 1; j < R; ++j) r += (kstart[j] <= i);
+    return sorted_pts[roff[r] + (i - kstart[r])];
+}
+
+// Diagnostic build only (STAMP): per-phase shader-clock sums, added to a.stamps by lane 0 of every wave.
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define IQ_STAMP(slot)                                              \
+    do {                                                            \
+        if (STAMP) {                                                \
+            const unsigned long long t_ = stamp_now();              \
+            tsum[slot] += (unsigned)(t_ - tlast);                   \
+            tlast = t_;                                             \
+        }                                                           \
+    } while (0)
+
+template <int MODE, int L3V, bool STAMP = false>
 __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
-    __shared__ __attribute__((aligned(16))) float bufA[kMC * 128];  // act0 (ld 64) then act2 (ld 128)
-    __shared__ __attribute__((aligned(16))) float bufB[kMC * 64];   // act1
-    __shared__ __attribute__((aligned(16))) float xs[kMC * 3];      // transformed inputs; aliased by prefix[]
-    __shared__ int16_t rows[kMaxN + kMC];
+    __shared__ __attribute__((aligned(16))) float bufA[kMC * kLd2];  // act0 (ld 68) then act2 (ld 132)
+    __shared__ __attribute__((aligned(16))) float bufB[kMC * kLd1];  // act1
+    __shared__ __attribute__((aligned(16))) float xs[kMC * 3];       // transformed inputs of the chunk
+    __shared__ int kstart[IQ_MAX_REGIONS];
     __shared__ int nkept_s;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int item = blockIdx.x;
+    const int item = a.item_order ? a.item_order[blockIdx.x] : blockIdx.x;
     const int N = a.N, R = a.R;
 
     int cloud;
@@ -144,27 +228,23 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
         const uint64_t full = R >= 64 ? ~0ull : ((1ull << R) - 1);
         keep = (a.keep ? a.keep[item] : ~0ull) & full;
     }
+    const int32_t* roff = a.roff + (size_t)cloud * (R + 1);
+    const uint16_t* sorted_pts = a.sorted_pts + (size_t)cloud * N;
 
-    // ---- row list: kept points compacted by region, then the centre, then padding ----------
-    int* prefix = reinterpret_cast<int*>(xs);
+    // ---- compacted row list of the coalition: prefix sums of the kept regions' sizes ---------
     if (wave == 0) {
-        const int sz = (lane < R && ((keep >> lane) & 1)) ? a.rsize[cloud * R + lane] : 0;
+        const int sz = (lane < R && ((keep >> lane) & 1)) ? roff[lane + 1] - roff[lane] : 0;
         int inc = sz;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(inc, off);
             if (lane >= off) inc += t;
         }
-        prefix[lane] = inc - sz;
+        kstart[lane] = inc - sz;
         if (lane == 63) nkept_s = inc;
     }
     __syncthreads();
-    for (int p = tid; p < N; p += kThreads) {
-        const int r = a.region_id[(size_t)cloud * N + p];
-        if ((keep >> r) & 1) rows[prefix[r] + a.rank[(size_t)cloud * N + p]] = (int16_t)p;
-    }
     const int nkept = nkept_s;
-    __syncthreads();
     if (MODE != kPrepool) add_centre = nkept < N;
     const int nrows = nkept + (add_centre ? 1 : 0);
     float* outp = a.out + (size_t)item * kFeat;
@@ -172,109 +252,146 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
         for (int c = tid; c < kFeat; c += kThreads) outp[c] = -INFINITY;
         return;
     }
-    const int npad = (nrows + kMC - 1) / kMC * kMC;
-    {
-        const int16_t padval = add_centre ? (int16_t)N : rows[nkept - 1];
-        for (int i = nkept + tid; i < npad; i += kThreads) rows[i] = padval;
-    }
-    // (visibility of rows[] padding is covered by the barrier after stage 0a)
+    const int nchunks = (nrows + kMC - 1) / kMC;
 
     const int c0 = tid & 63, rg = tid >> 6;
     const f32x4 win = *reinterpret_cast<const f32x4*>(a.w_in + c0 * 4);
-    float t9[9];
-    if (MODE != kPrepool) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) t9[i] = a.trans[(size_t)item * 9 + i];
-    }
     const float* w1 = (MODE == kTrunk) ? a.w1 + (size_t)item * 4096 : a.w1;
+    // per-lane bases: A-fragment reads and C-tile writes are base + immediate everywhere below
+    const int frag_lane = (lane & 31), frag_h = lane >> 5;
+    const float* a1base_A = bufA + frag_lane * kLd1 + 4 * frag_h;   // act0 in bufA
+    const float* a1base_B = bufB + frag_lane * kLd1 + 4 * frag_h;   // act1 in bufB
+    const float* a2base = bufA + frag_lane * kLd2 + 4 * frag_h;     // act2 in bufA
+    float* c1base = bufB + (4 * frag_h) * kLd1 + frag_lane;         // C tiles of L1 -> act1
+    float* c2base = bufA + (4 * frag_h) * kLd2 + frag_lane;         // C tiles of L2 -> act2
 
     float runmax[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) runmax[q] = -INFINITY;
 
-    __syncthreads();
-    for (int ch = 0; ch * kMC < npad; ++ch) {
+    // Input points travel one chunk ahead in registers: lanes 0..15 of each wave own 16 rows of the
+    // chunk, so the two dependent global loads (index, coordinates) of chunk c+1 are in flight during
+    // the MFMA phases of chunk c.
+    const bool fetcher = lane < 16;
+    const int frow = wave * 16 + lane;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    auto fetch = [&](int ch) {
+        const int p = row_to_point(ch * kMC + frow, nkept, add_centre, kstart, R, sorted_pts, roff, N);
+        if (p == N) {
+            px = a.centers[cloud * 3]; py = a.centers[cloud * 3 + 1]; pz = a.centers[cloud * 3 + 2];
+        } else {
+            const float* src = a.clouds + (size_t)cloud * a.cl + (size_t)p * a.ps;
+            px = src[0]; py = src[a.cs]; pz = src[2 * a.cs];
+        }
+    };
+    if (fetcher) fetch(0);
+
+    BRing ring;
+    if (L3V == 2) bring_init(ring, a.w3, wave, lane);
+    unsigned tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = STAMP ? stamp_now() : 0ull;
+    for (int ch = 0; ch < nchunks; ++ch) {
         const int rows_here = min(kMC, nrows - ch * kMC);
         const int mts = rows_here > 32 ? 2 : 1;
 
-        // ---- stage 0a: fetch + input transform (models/pointnet.py:67-69) ------------------
-        if (tid < kMC) {
-            const int p = rows[ch * kMC + tid];
-            float x, y, z;
-            if (p == N) {
-                x = a.centers[cloud * 3]; y = a.centers[cloud * 3 + 1]; z = a.centers[cloud * 3 + 2];
-            } else {
-                const float* src = a.clouds + (size_t)cloud * a.cl + (size_t)p * a.ps;
-                x = src[0]; y = src[a.cs]; z = src[2 * a.cs];
-            }
+        // ---- stage 0a: input transform (models/pointnet.py:67-69) --------------------------
+        if (fetcher) {
+            float x = px, y = py, z = pz;
             if (MODE != kPrepool) {
+                const float* t9 = a.trans + (size_t)item * 9;  // uniform -> scalar loads
                 const float x2 = fmaf(z, t9[6], fmaf(y, t9[3], x * t9[0]));
                 const float y2 = fmaf(z, t9[7], fmaf(y, t9[4], x * t9[1]));
                 const float z2 = fmaf(z, t9[8], fmaf(y, t9[5], x * t9[2]));
                 x = x2; y = y2; z = z2;
             }
-            xs[tid * 3] = x; xs[tid * 3 + 1] = y; xs[tid * 3 + 2] = z;
+            xs[frow * 3] = x; xs[frow * 3 + 1] = y; xs[frow * 3 + 2] = z;
         }
-        __syncthreads();
+        IQ_STAMP(0);
+        __syncthreads();  // also orders the previous chunk's L3 reads of bufA before stage 0b rewrites it
+        IQ_STAMP(1);
+        if (fetcher && ch + 1 < nchunks) fetch(ch + 1);
         // ---- stage 0b: 3 -> 64 (+bn, relu), thread = (channel c0, 16 rows) -----------------
         {
-            float* dst = (MODE == kPrepool) ? bufB : bufA;
+            float* dst = ((MODE == kPrepool) ? bufB : bufA) + rg * 16 * kLd1 + c0;
 #pragma unroll 4
             for (int i = 0; i < 16; ++i) {
                 const int r = rg * 16 + i;
                 const float f = fmaf(win[2], xs[r * 3 + 2], fmaf(win[1], xs[r * 3 + 1], win[0] * xs[r * 3])) + win[3];
-                dst[swz(r, c0, 64)] = fmaxf(f, 0.f);
+                dst[i * kLd1] = fmaxf(f, 0.f);
             }
         }
-        __syncthreads();
         // ---- L1: 64 -> 64 ------------------------------------------------------------------
         if (MODE != kPrepool) {
             const int mt = wave & 1, nt = wave >> 1;
+            const float* wq = w1 + (size_t)nt * 8 * 256;
+            f32x4 bw[8];  // weight fragments are requested before the barrier, consumed after it
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) bw[kb] = glb_b(wq + kb * 256, lane);
+            IQ_STAMP(2);
+            __syncthreads();
+            IQ_STAMP(3);
             if (mt < mts) {
                 f32x16 acc = {0};
-                const float* wq = w1 + (size_t)nt * 8 * 256;
-#pragma unroll 2
-                for (int kb = 0; kb < 8; ++kb)
-                    acc = mfma4(lds_a(bufA, 64, mt * 32, kb, lane), glb_b(wq + kb * 256, lane), acc);
-                const int col = nt * 32 + (lane & 31);
-                const float bias = (MODE == kFstn) ? a.b1[col] : 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) {
+                    acc = mfma4(lds_frag<kLd1>(a1base_A + mt * 32 * kLd1, 0, kb), bw[kb], acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float bias = (MODE == kFstn) ? a.b1[nt * 32 + frag_lane] : 0.f;
+                float* dst = c1base + mt * 32 * kLd1 + nt * 32;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     float v = acc[i] + bias;
                     if (MODE == kFstn) v = fmaxf(v, 0.f);
-                    bufB[swz(mt * 32 + c_row(i, lane), col, 64)] = v;
+                    dst[c_row_i(i) * kLd1] = v;
                 }
             }
-            __syncthreads();
         }
-        // ---- L2: 64 -> 128 (+bn, relu) -----------------------------------------------------
+        // ---- L2: 64 -> 128 (+bn, relu): two passes (n-tiles nt0, nt0+2); the second pass's weights
+        //      are requested while the first pass computes ------------------------------------
         {
-            const int mt = wave & 1, nt0 = wave >> 1, nt1 = nt0 + 2;
-            if (mt < mts) {
-                f32x16 acc0 = {0}, acc1 = {0};
-                const float* wq0 = a.w2 + (size_t)nt0 * 8 * 256;
-                const float* wq1 = a.w2 + (size_t)nt1 * 8 * 256;
-#pragma unroll 2
-                for (int kb = 0; kb < 8; ++kb) {
-                    const f32x4 av = lds_a(bufB, 64, mt * 32, kb, lane);
-                    acc0 = mfma4(av, glb_b(wq0 + kb * 256, lane), acc0);
-                    acc1 = mfma4(av, glb_b(wq1 + kb * 256, lane), acc1);
-                }
-                const int col0 = nt0 * 32 + (lane & 31), col1 = nt1 * 32 + (lane & 31);
-                const float bias0 = a.b2[col0], bias1 = a.b2[col1];
+            const int mt = wave & 1, nt0 = wave >> 1;
+            const float* wq0 = a.w2 + (size_t)nt0 * 8 * 256;
+            f32x4 bw[8];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = mt * 32 + c_row(i, lane);
-                    bufA[swz(row, col0, 128)] = fmaxf(acc0[i] + bias0, 0.f);
-                    bufA[swz(row, col1, 128)] = fmaxf(acc1[i] + bias1, 0.f);
+            for (int kb = 0; kb < 8; ++kb) bw[kb] = glb_b(wq0 + kb * 256, lane);
+            IQ_STAMP(4);
+            __syncthreads();
+            IQ_STAMP(3);
+            if (mt < mts) {
+                const float* arow = a1base_B + mt * 32 * kLd1;
+                float* dst = c2base + mt * 32 * kLd2 + nt0 * 32;
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    f32x16 acc = {0};
+#pragma unroll
+                    for (int kb = 0; kb < 8; ++kb) {
+                        acc = mfma4(lds_frag<kLd1>(arow, 0, kb), bw[kb], acc);
+                        if (pass == 0) bw[kb] = glb_b(wq0 + (2 * 8 + kb) * 256, lane);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const float bias = a.b2[nt0 * 32 + pass * 64 + frag_lane];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) dst[c_row_i(i) * kLd2 + pass * 64] = fmaxf(acc[i] + bias, 0.f);
                 }
             }
         }
+        IQ_STAMP(5);
         __syncthreads();
+        IQ_STAMP(3);
         // ---- L3: 128 -> 1024, running column max -------------------------------------------
-        if (mts == 2) l3_pass<2>(a.w3, bufA, wave, lane, runmax);
-        else          l3_pass<1>(a.w3, bufA, wave, lane, runmax);
-        // the barrier after the next chunk's stage 0a orders these reads before bufA is rewritten
+        if (L3V == 0) {
+            if (mts == 2) l3_pass_v0<2>(a.w3, a2base, wave, lane, runmax);
+            else          l3_pass_v0<1>(a.w3, a2base, wave, lane, runmax);
+        } else {
+            if (mts == 2) l3_pass_v2<2>(a.w3, a2base, wave, lane, runmax, ring);
+            else          l3_pass_v2<1>(a.w3, a2base, wave, lane, runmax, ring);
+        }
+        IQ_STAMP(6);
+    }
+    if (STAMP && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&a.stamps[i], (unsigned long long)tsum[i]);
     }
 
     // max commutes with the (monotone) per-column bias add and relu
@@ -289,30 +406,75 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
     }
 }
 
-// ---- per-cloud region tables ---------------------------------------------------------------
+// ---- per-cloud region tables: points grouped by region (counting sort) ------------------------
 __global__ __launch_bounds__(kThreads) void pn_prepare_kernel(const int32_t* __restrict__ region_id,
-                                                              uint16_t* __restrict__ rank,
-                                                              int32_t* __restrict__ rsize, int N, int R) {
+                                                              uint16_t* __restrict__ sorted_pts,
+                                                              int32_t* __restrict__ roff, int N, int R) {
     __shared__ int16_t rid[kMaxN];
-    __shared__ int cnt[IQ_MAX_REGIONS];
+    __shared__ int cnt[IQ_MAX_REGIONS + 1];
     const int cloud = blockIdx.x;
-    if (threadIdx.x < IQ_MAX_REGIONS) cnt[threadIdx.x] = 0;
+    if (threadIdx.x <= IQ_MAX_REGIONS) cnt[threadIdx.x] = 0;
     for (int p = threadIdx.x; p < N; p += kThreads) rid[p] = (int16_t)region_id[(size_t)cloud * N + p];
     __syncthreads();
+    for (int p = threadIdx.x; p < N; p += kThreads) atomicAdd(&cnt[rid[p]], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // exclusive scan, R <= 64
+        int run = 0;
+        for (int r = 0; r <= R; ++r) { const int c = r < R ? cnt[r] : 0; cnt[r] = run; run += c; }
+    }
+    __syncthreads();
+    if (threadIdx.x <= R) roff[(size_t)cloud * (R + 1) + threadIdx.x] = cnt[threadIdx.x];
     for (int p = threadIdx.x; p < N; p += kThreads) {
         const int r = rid[p];
         int k = 0;
-        for (int q = 0; q < p; ++q) k += (rid[q] == r);
-        rank[(size_t)cloud * N + p] = (uint16_t)k;
-        atomicAdd(&cnt[r], 1);
+        for (int q = 0; q < p; ++q) k += (rid[q] == r);   // rank inside the region: ascending point index
+        sorted_pts[(size_t)cloud * N + cnt[r] + k] = (uint16_t)p;
     }
-    __syncthreads();
-    if (threadIdx.x < R) rsize[cloud * R + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// ---- launch order: largest coalitions first (LPT), a counting sort on the chunk count ---------
+constexpr int kBins = kMaxN / kMC + 2;
+
+__device__ __forceinline__ int item_rows(const int32_t* __restrict__ roff, uint64_t keep, int R, int N, int with_centre) {
+    int nkept = 0;
+    for (int r = 0; r < R; ++r)
+        if ((keep >> r) & 1) nkept += roff[r + 1] - roff[r];
+    return nkept + ((with_centre && nkept < N) ? 1 : 0);
+}
+
+__global__ __launch_bounds__(kThreads) void pn_order_count_kernel(const int32_t* __restrict__ roff_all,
+                                                                  const uint64_t* __restrict__ keep,
+                                                                  const int32_t* __restrict__ cloud_of,
+                                                                  int32_t* __restrict__ bin_of, int32_t* __restrict__ hist,
+                                                                  int B, int N, int R, int nclouds, int with_centre) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= B) return;
+    const int cloud = cloud_of ? cloud_of[item] : (nclouds == 1 ? 0 : item);
+    const uint64_t full = R >= 64 ? ~0ull : ((1ull << R) - 1);
+    const int rows = item_rows(roff_all + (size_t)cloud * (R + 1), (keep ? keep[item] : ~0ull) & full, R, N, with_centre);
+    const int bin = kBins - 1 - min(kBins - 1, (rows + kMC - 1) / kMC);  // bin 0 = most chunks
+    bin_of[item] = bin;
+    atomicAdd(&hist[bin], 1);
+}
+
+__global__ void pn_order_scan_kernel(int32_t* __restrict__ hist) {
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int b = 0; b < kBins; ++b) { const int c = hist[b]; hist[b] = run; run += c; }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void pn_order_scatter_kernel(const int32_t* __restrict__ bin_of,
+                                                                    int32_t* __restrict__ cursor,
+                                                                    int32_t* __restrict__ order, int B) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= B) return;
+    order[atomicAdd(&cursor[bin_of[item]], 1)] = item;
 }
 
 // ---- pooled input-STN feature of a coalition: max over kept regions (+ centre) -------------
 __global__ __launch_bounds__(kThreads) void pn_stn_gather_kernel(const float* __restrict__ G,
-                                                                 const int32_t* __restrict__ rsize,
+                                                                 const int32_t* __restrict__ roff_all,
                                                                  const uint64_t* __restrict__ keep,
                                                                  const int32_t* __restrict__ cloud_of,
                                                                  float* __restrict__ out, int N, int R,
@@ -324,10 +486,11 @@ __global__ __launch_bounds__(kThreads) void pn_stn_gather_kernel(const float* __
     const int per = R + with_centre;
     const f32x4* g4 = reinterpret_cast<const f32x4*>(G) + (size_t)cloud * per * (kFeat / 4) + threadIdx.x;
     f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const int32_t* roff = roff_all + (size_t)cloud * (R + 1);
     int nkept = 0;
     for (int r = 0; r < R; ++r) {
         if ((k >> r) & 1) {
-            nkept += rsize[cloud * R + r];
+            nkept += roff[r + 1] - roff[r];
             const f32x4 v = g4[(size_t)r * (kFeat / 4)];
             m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
         }
@@ -415,6 +578,17 @@ __global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __rest
     }
 }
 
+template <int MODE>
+void launch_chain(const ChainArgs& a, hipStream_t st) {
+    const size_t extra_lds = (size_t)iq::tuning(iq::kTuneExtraLds);  // experiment: lower the occupancy
+    if (a.stamps && MODE == kFstn)
+        hipLaunchKernelGGL((pn_chain_kernel<kFstn, 2, true>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
+    else if (iq::tuning(iq::kTuneL3Variant) == 0)
+        hipLaunchKernelGGL((pn_chain_kernel<MODE, 0>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
+    else
+        hipLaunchKernelGGL((pn_chain_kernel<MODE, 2>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
+}
+
 int launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,
                   hipStream_t st) {
     if (M == 0) return IQ_OK;
@@ -433,8 +607,11 @@ int launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, 
 }
 
 struct Workspace {
-    uint16_t* rank;
-    int32_t* rsize;
+    uint16_t* sorted_pts;
+    int32_t* roff;
+    int32_t* order;    // (B) launch order
+    int32_t* bin_of;   // (B)
+    int32_t* hist;     // (kBins)
     float* G;
     float* gbuf;
     float* h1;
@@ -452,8 +629,11 @@ Workspace carve(void* base, int B, int nclouds, int N, int R) {
         off = iq::align_up(off + bytes, 256);
         return reinterpret_cast<char*>(base) + o;
     };
-    w.rank = reinterpret_cast<uint16_t*>(take((size_t)nclouds * N * sizeof(uint16_t)));
-    w.rsize = reinterpret_cast<int32_t*>(take((size_t)nclouds * IQ_MAX_REGIONS * sizeof(int32_t)));
+    w.sorted_pts = reinterpret_cast<uint16_t*>(take((size_t)nclouds * N * sizeof(uint16_t)));
+    w.roff = reinterpret_cast<int32_t*>(take((size_t)nclouds * (IQ_MAX_REGIONS + 1) * sizeof(int32_t)));
+    w.order = reinterpret_cast<int32_t*>(take((size_t)B * sizeof(int32_t)));
+    w.bin_of = reinterpret_cast<int32_t*>(take((size_t)B * sizeof(int32_t)));
+    w.hist = reinterpret_cast<int32_t*>(take((size_t)kBins * sizeof(int32_t)));
     w.G = reinterpret_cast<float*>(take((size_t)nclouds * (R + 1) * kFeat * sizeof(float)));
     w.gbuf = reinterpret_cast<float*>(take((size_t)B * kFeat * sizeof(float)));
     w.h1 = reinterpret_cast<float*>(take((size_t)B * 512 * sizeof(float)));
@@ -465,6 +645,32 @@ Workspace carve(void* base, int B, int nclouds, int N, int R) {
 }
 
 }  // namespace
+
+namespace { unsigned long long* g_stamps = nullptr; }
+
+// Diagnostic: phase stamps of the feature-STN chain (STAMP build).  enable allocates/zeroes a
+// device buffer of 8 counters; read copies them to the host (synchronises the device).
+extern "C" int iq_debug_stamps(int enable, unsigned long long* out_host /*8 or null*/) {
+    if (out_host && g_stamps) {
+        if (hipDeviceSynchronize() != hipSuccess) return IQ_ELAUNCH;
+        if (hipMemcpy(out_host, g_stamps, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return IQ_ELAUNCH;
+    }
+    if (enable) {
+        if (!g_stamps && hipMalloc(&g_stamps, 8 * sizeof(unsigned long long)) != hipSuccess) return IQ_ELAUNCH;
+        if (hipMemset(g_stamps, 0, 8 * sizeof(unsigned long long)) != hipSuccess) return IQ_ELAUNCH;
+    } else if (g_stamps) {
+        (void)hipFree(g_stamps);
+        g_stamps = nullptr;
+    }
+    return IQ_OK;
+}
+
+extern "C" int iq_debug_chain_occupancy(void) {
+    int n0 = -1, n2 = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, pn_chain_kernel<kFstn, 0>, kThreads, 0) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, pn_chain_kernel<kFstn, 2>, kThreads, 0) != hipSuccess) return -1;
+    return n0 * 100 + n2;
+}
 
 extern "C" size_t iq_pointnet_workspace_bytes(int B, int nclouds, int N, int R) {
     if (B < 0 || nclouds < 0 || N < 0 || R < 0) return 0;
@@ -501,18 +707,31 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
     int rc;
     iq::ProfileSpan call_span(iq::kSlotCall, st);
 
-    hipLaunchKernelGGL(pn_prepare_kernel, dim3(nclouds), dim3(kThreads), 0, st, region_id, ws.rank, ws.rsize, N, R);
+    hipLaunchKernelGGL(pn_prepare_kernel, dim3(nclouds), dim3(kThreads), 0, st, region_id, ws.sorted_pts, ws.roff, N, R);
     if ((rc = iq::check_launch("pn_prepare_kernel"))) return rc;
+    // launch order of the coalition chains: most rows first, so the grid drains evenly
+    const bool lpt = iq::tuning(iq::kTuneNoLpt) == 0;
+    if (lpt) {
+        if (hipMemsetAsync(ws.hist, 0, kBins * sizeof(int32_t), st) != hipSuccess)
+            return iq::fail(IQ_ELAUNCH, "iq_pointnet_coalitions: memset failed");
+        hipLaunchKernelGGL(pn_order_count_kernel, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0, st, ws.roff,
+                           keep, cloud_of, ws.bin_of, ws.hist, B, N, R, nclouds, with_centre);
+        hipLaunchKernelGGL(pn_order_scan_kernel, dim3(1), dim3(64), 0, st, ws.hist);
+        hipLaunchKernelGGL(pn_order_scatter_kernel, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
+                           ws.bin_of, ws.hist, ws.order, B);
+        if ((rc = iq::check_launch("pn_order kernels"))) return rc;
+    }
 
     ChainArgs a{};
     a.clouds = clouds;
     if (channel_first) { a.ps = 1; a.cs = N; } else { a.ps = 3; a.cs = 1; }
     a.cl = 3 * N;
     a.centers = centers;
-    a.region_id = region_id;
-    a.rank = ws.rank;
-    a.rsize = ws.rsize;
+    a.sorted_pts = ws.sorted_pts;
+    a.roff = ws.roff;
+    a.item_order = nullptr;
     a.N = N; a.R = R; a.nclouds = nclouds; a.with_centre = with_centre;
+    a.stamps = g_stamps;
 
     // 1. input-STN chain, pre-pooled per (cloud, region) [+ centre]
     a.keep = nullptr; a.cloud_of = nullptr; a.trans = nullptr;
@@ -524,11 +743,11 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
     a.items = nclouds * (R + with_centre);
     {
         iq::ProfileSpan span(iq::kSlotPrepool, st);
-        hipLaunchKernelGGL(pn_chain_kernel<kPrepool>, dim3(a.items), dim3(kThreads), 0, st, a);
+        launch_chain<kPrepool>(a, st);
     }
     if ((rc = iq::check_launch("pn_chain_kernel<prepool>"))) return rc;
 
-    hipLaunchKernelGGL(pn_stn_gather_kernel, dim3(B), dim3(kThreads), 0, st, ws.G, ws.rsize, keep, cloud_of, ws.gbuf,
+    hipLaunchKernelGGL(pn_stn_gather_kernel, dim3(B), dim3(kThreads), 0, st, ws.G, ws.roff, keep, cloud_of, ws.gbuf,
                        N, R, nclouds, with_centre);
     if ((rc = iq::check_launch("pn_stn_gather_kernel"))) return rc;
     if ((rc = launch_linear(ws.gbuf, kFeat, w->stn_fc1, ws.h1, 512, B, 1, st))) return rc;
@@ -537,6 +756,7 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
 
     // 2. feature-STN chain over each coalition's distinct points
     a.keep = keep; a.cloud_of = cloud_of; a.trans = ws.trans;
+    a.item_order = lpt ? ws.order : nullptr;
     a.w_in = w->feat_in;
     a.w1 = w->fstn_c1.w; a.b1 = w->fstn_c1.b;
     a.w2 = w->fstn_c2.w; a.b2 = w->fstn_c2.b;
@@ -545,7 +765,7 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
     a.items = B;
     {
         iq::ProfileSpan span(iq::kSlotFstn, st);
-        hipLaunchKernelGGL(pn_chain_kernel<kFstn>, dim3(B), dim3(kThreads), 0, st, a);
+        launch_chain<kFstn>(a, st);
     }
     if ((rc = iq::check_launch("pn_chain_kernel<fstn>"))) return rc;
     float* tfp = trans_feat_packed ? trans_feat_packed : ws.tfp;
@@ -559,7 +779,7 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
     a.w3 = w->feat_c3.w; a.b3 = w->feat_c3.b;
     {
         iq::ProfileSpan span(iq::kSlotTrunk, st);
-        hipLaunchKernelGGL(pn_chain_kernel<kTrunk>, dim3(B), dim3(kThreads), 0, st, a);
+        launch_chain<kTrunk>(a, st);
     }
     if ((rc = iq::check_launch("pn_chain_kernel<trunk>"))) return rc;
     if ((rc = launch_linear(ws.gbuf, kFeat, w->cls_fc1, ws.h1, 512, B, 1, st))) return rc;
