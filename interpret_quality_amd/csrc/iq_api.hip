@@ -19,7 +19,7 @@ bool g_enabled = false;
 
 bool profile_enabled() { return g_enabled; }
 
-namespace { int g_tune[kTuneCount] = {0}; }
+namespace { int g_tune[kTuneCount] = {2, 0, 0, 0, 0, 0, 0, 0}; }  // default: L3 variant 2 (B-fragment ring)
 int tuning(int key) { return (key >= 0 && key < kTuneCount) ? g_tune[key] : 0; }
 void set_tuning(int key, int value) { if (key >= 0 && key < kTuneCount) g_tune[key] = value; }
 

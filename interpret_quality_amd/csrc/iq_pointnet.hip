@@ -27,6 +27,7 @@ constexpr int kFeat = IQ_NUM_FEAT;
 constexpr int kMC = 64;        // rows per chunk
 constexpr int kMaxN = 1024;    // points per cloud supported by the chain kernel
 constexpr int kThreads = 256;
+constexpr int kRowCap = kMaxN + kMC;  // row-list stride per item (uint16)
 
 enum ChainMode { kPrepool = 0, kFstn = 1, kTrunk = 2 };
 
@@ -73,10 +74,9 @@ struct ChainArgs {
     const float* clouds;       // strides below, in floats
     int ps, cs, cl;            // point, channel, cloud stride
     const float* centers;      // (nclouds,3)
-    const uint16_t* sorted_pts;  // (nclouds,N) point indices grouped by region (ascending inside a region)
-    const int32_t* roff;         // (nclouds,R+1) start of each region in sorted_pts
+    const uint16_t* rows;        // (items,kRowCap) compacted point list of every item (pn_rows_kernel)
+    const int32_t* nrows;        // (items) row count | centre flag << 16
     const int32_t* item_order;   // (items) launch order (largest coalitions first) or null
-    const uint64_t* keep;      // (items) or null = keep everything       [kFstn/kTrunk]
     const int32_t* cloud_of;   // (items) or null                          [kFstn/kTrunk]
     const float* trans;        // (items,9) input transform                [kFstn/kTrunk]
     const float* w_in;         // [64][4] folded 3->64 layer
@@ -169,22 +169,6 @@ __device__ __forceinline__ void l3_pass_v2(const float* __restrict__ w3, const f
     }
 }
 
-// Row i of a coalition's compacted point list -> point index (N = the centre).  kstart[r] is the
-// position of region r's first point in the list (kept regions only advance it); a row past the
-// kept points is the centre when one is appended, else a replica of the last kept row (padding:
-// duplicates never change a max).
-__device__ __forceinline__ int row_to_point(int i, int nkept, bool add_centre, const int* kstart, int R,
-                                            const uint16_t* __restrict__ sorted_pts, const int32_t* __restrict__ roff,
-                                            int N) {
-    if (i >= nkept) {
-        if (add_centre) return N;
-        i = nkept - 1;
-    }
-    int r = 0;
-    for (int j = 1; j < R; ++j) r += (kstart[j] <= i);
-    return sorted_pts[roff[r] + (i - kstart[r])];
-}
-
 // Diagnostic build only (STAMP): per-phase shader-clock sums, added to a.stamps by lane 0 of every wave.
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
@@ -206,47 +190,16 @@ template <int MODE, int L3V, bool STAMP = false>
 __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float bufA[kMC * kLd2];  // act0 (ld 68) then act2 (ld 132)
     __shared__ __attribute__((aligned(16))) float bufB[kMC * kLd1];  // act1
-    __shared__ __attribute__((aligned(16))) float xs[kMC * 3];       // transformed inputs of the chunk
-    __shared__ int kstart[IQ_MAX_REGIONS];
-    __shared__ int nkept_s;
+    __shared__ __attribute__((aligned(16))) float xs[kMC * 4];       // transformed inputs of the chunk (x,y,z,-)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int item = a.item_order ? a.item_order[blockIdx.x] : blockIdx.x;
-    const int N = a.N, R = a.R;
-
+    const int N = a.N;
     int cloud;
-    uint64_t keep;
-    bool add_centre = false;
-    if (MODE == kPrepool) {
-        const int per = R + a.with_centre;
-        cloud = item / per;
-        const int r = item - cloud * per;
-        keep = r < R ? (1ull << r) : 0ull;
-        add_centre = (r == R);
-    } else {
-        cloud = a.cloud_of ? a.cloud_of[item] : (a.nclouds == 1 ? 0 : item);
-        const uint64_t full = R >= 64 ? ~0ull : ((1ull << R) - 1);
-        keep = (a.keep ? a.keep[item] : ~0ull) & full;
-    }
-    const int32_t* roff = a.roff + (size_t)cloud * (R + 1);
-    const uint16_t* sorted_pts = a.sorted_pts + (size_t)cloud * N;
+    if (MODE == kPrepool) cloud = item / (a.R + a.with_centre);
+    else cloud = a.cloud_of ? a.cloud_of[item] : (a.nclouds == 1 ? 0 : item);
 
-    // ---- compacted row list of the coalition: prefix sums of the kept regions' sizes ---------
-    if (wave == 0) {
-        const int sz = (lane < R && ((keep >> lane) & 1)) ? roff[lane + 1] - roff[lane] : 0;
-        int inc = sz;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(inc, off);
-            if (lane >= off) inc += t;
-        }
-        kstart[lane] = inc - sz;
-        if (lane == 63) nkept_s = inc;
-    }
-    __syncthreads();
-    const int nkept = nkept_s;
-    if (MODE != kPrepool) add_centre = nkept < N;
-    const int nrows = nkept + (add_centre ? 1 : 0);
+    const int nrows = a.nrows[item] & 0xffff;
     float* outp = a.out + (size_t)item * kFeat;
     if (nrows == 0) {  // empty region in the pre-pool: identity of max
         for (int c = tid; c < kFeat; c += kThreads) outp[c] = -INFINITY;
@@ -269,14 +222,14 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) runmax[q] = -INFINITY;
 
-    // Input points travel one chunk ahead in registers: lanes 0..15 of each wave own 16 rows of the
-    // chunk, so the two dependent global loads (index, coordinates) of chunk c+1 are in flight during
-    // the MFMA phases of chunk c.
+    // Input points travel ahead in registers: lanes 0..15 of each wave own 16 rows of a chunk.  The
+    // row index of chunk c+2 and the coordinates of chunk c+1 are requested while chunk c computes, so
+    // neither of the two dependent global loads is ever waited for.
     const bool fetcher = lane < 16;
     const int frow = wave * 16 + lane;
+    const uint16_t* rowp = a.rows + (size_t)item * kRowCap + frow;
     float px = 0.f, py = 0.f, pz = 0.f;
-    auto fetch = [&](int ch) {
-        const int p = row_to_point(ch * kMC + frow, nkept, add_centre, kstart, R, sorted_pts, roff, N);
+    auto load_point = [&](int p) {
         if (p == N) {
             px = a.centers[cloud * 3]; py = a.centers[cloud * 3 + 1]; pz = a.centers[cloud * 3 + 2];
         } else {
@@ -284,7 +237,11 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
             px = src[0]; py = src[a.cs]; pz = src[2 * a.cs];
         }
     };
-    if (fetcher) fetch(0);
+    int pnext = 0;
+    if (fetcher) {
+        load_point(rowp[0]);
+        if (nchunks > 1) pnext = rowp[kMC];
+    }
 
     BRing ring;
     if (L3V == 2) bring_init(ring, a.w3, wave, lane);
@@ -304,19 +261,22 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
                 const float z2 = fmaf(z, t9[8], fmaf(y, t9[5], x * t9[2]));
                 x = x2; y = y2; z = z2;
             }
-            xs[frow * 3] = x; xs[frow * 3 + 1] = y; xs[frow * 3 + 2] = z;
+            *reinterpret_cast<f32x4*>(xs + frow * 4) = (f32x4){x, y, z, 0.f};
         }
         IQ_STAMP(0);
         __syncthreads();  // also orders the previous chunk's L3 reads of bufA before stage 0b rewrites it
         IQ_STAMP(1);
-        if (fetcher && ch + 1 < nchunks) fetch(ch + 1);
+        if (fetcher && ch + 1 < nchunks) {
+            load_point(pnext);
+            if (ch + 2 < nchunks) pnext = rowp[(ch + 2) * kMC];
+        }
         // ---- stage 0b: 3 -> 64 (+bn, relu), thread = (channel c0, 16 rows) -----------------
         {
             float* dst = ((MODE == kPrepool) ? bufB : bufA) + rg * 16 * kLd1 + c0;
 #pragma unroll 4
             for (int i = 0; i < 16; ++i) {
-                const int r = rg * 16 + i;
-                const float f = fmaf(win[2], xs[r * 3 + 2], fmaf(win[1], xs[r * 3 + 1], win[0] * xs[r * 3])) + win[3];
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + (rg * 16 + i) * 4);
+                const float f = fmaf(win[2], xv[2], fmaf(win[1], xv[1], win[0] * xv[0])) + win[3];
                 dst[i * kLd1] = fmaxf(f, 0.f);
             }
         }
@@ -432,26 +392,74 @@ __global__ __launch_bounds__(kThreads) void pn_prepare_kernel(const int32_t* __r
     }
 }
 
+// ---- compacted row list of every work item (one wave per item) --------------------------------
+// Coalition items: keep[item] (null = everything), centre appended iff a point is masked.
+// Pre-pool items (prepool != 0): item = cloud*(R+with_centre) + r; r < R keeps region r only (no
+// centre), r == R is the centre alone.  The list is padded to a multiple of kMC with replicas of a
+// valid row (duplicates never change a max).
+__global__ __launch_bounds__(64) void pn_rows_kernel(const uint16_t* __restrict__ sorted_all,
+                                                     const int32_t* __restrict__ roff_all,
+                                                     const uint64_t* __restrict__ keep_all,
+                                                     const int32_t* __restrict__ cloud_of, uint16_t* __restrict__ rows_all,
+                                                     int32_t* __restrict__ nrows_all, int N, int R, int nclouds,
+                                                     int with_centre, int prepool) {
+    const int item = blockIdx.x, lane = threadIdx.x;
+    int cloud;
+    uint64_t keep;
+    bool add_centre;
+    if (prepool) {
+        const int per = R + with_centre;
+        cloud = item / per;
+        const int r = item - cloud * per;
+        keep = r < R ? (1ull << r) : 0ull;
+        add_centre = (r == R);
+    } else {
+        cloud = cloud_of ? cloud_of[item] : (nclouds == 1 ? 0 : item);
+        const uint64_t full = R >= 64 ? ~0ull : ((1ull << R) - 1);
+        keep = (keep_all ? keep_all[item] : ~0ull) & full;
+        add_centre = false;
+    }
+    const int32_t* roff = roff_all + (size_t)cloud * (R + 1);
+    const uint16_t* sorted_pts = sorted_all + (size_t)cloud * N;
+    uint16_t* rows = rows_all + (size_t)item * kRowCap;
+
+    const int sz = (lane < R && ((keep >> lane) & 1)) ? roff[lane + 1] - roff[lane] : 0;
+    int inc = sz;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    const int kst = inc - sz;
+    const int nkept = __shfl(inc, 63);
+    if (!prepool) add_centre = with_centre && nkept < N;
+    const int nrows = nkept + (add_centre ? 1 : 0);
+    for (int r = 0; r < R; ++r) {
+        if (!((keep >> r) & 1)) continue;
+        const int ks = __shfl(kst, r), off = roff[r], n = roff[r + 1] - off;
+        for (int j = lane; j < n; j += 64) rows[ks + j] = sorted_pts[off + j];
+    }
+    // padding value: the centre if present, else the last kept point
+    int padval = N;
+    if (!add_centre && nkept > 0) {
+        const unsigned long long last = __ballot(sz > 0 && kst + sz == nkept);
+        const int rl = __ffsll((long long)last) - 1;
+        padval = sorted_pts[roff[rl + 1] - 1];
+    }
+    const int npad = (nrows + kMC - 1) / kMC * kMC;
+    for (int i = nkept + lane; i < npad; i += 64) rows[i] = (uint16_t)padval;
+    if (lane == 0) nrows_all[item] = nrows | (add_centre ? (1 << 16) : 0);
+}
+
 // ---- launch order: largest coalitions first (LPT), a counting sort on the chunk count ---------
 constexpr int kBins = kMaxN / kMC + 2;
 
-__device__ __forceinline__ int item_rows(const int32_t* __restrict__ roff, uint64_t keep, int R, int N, int with_centre) {
-    int nkept = 0;
-    for (int r = 0; r < R; ++r)
-        if ((keep >> r) & 1) nkept += roff[r + 1] - roff[r];
-    return nkept + ((with_centre && nkept < N) ? 1 : 0);
-}
-
-__global__ __launch_bounds__(kThreads) void pn_order_count_kernel(const int32_t* __restrict__ roff_all,
-                                                                  const uint64_t* __restrict__ keep,
-                                                                  const int32_t* __restrict__ cloud_of,
+__global__ __launch_bounds__(kThreads) void pn_order_count_kernel(const int32_t* __restrict__ nrows_all,
                                                                   int32_t* __restrict__ bin_of, int32_t* __restrict__ hist,
-                                                                  int B, int N, int R, int nclouds, int with_centre) {
+                                                                  int B) {
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= B) return;
-    const int cloud = cloud_of ? cloud_of[item] : (nclouds == 1 ? 0 : item);
-    const uint64_t full = R >= 64 ? ~0ull : ((1ull << R) - 1);
-    const int rows = item_rows(roff_all + (size_t)cloud * (R + 1), (keep ? keep[item] : ~0ull) & full, R, N, with_centre);
+    const int rows = nrows_all[item] & 0xffff;
     const int bin = kBins - 1 - min(kBins - 1, (rows + kMC - 1) / kMC);  // bin 0 = most chunks
     bin_of[item] = bin;
     atomicAdd(&hist[bin], 1);
@@ -474,11 +482,11 @@ __global__ __launch_bounds__(kThreads) void pn_order_scatter_kernel(const int32_
 
 // ---- pooled input-STN feature of a coalition: max over kept regions (+ centre) -------------
 __global__ __launch_bounds__(kThreads) void pn_stn_gather_kernel(const float* __restrict__ G,
-                                                                 const int32_t* __restrict__ roff_all,
+                                                                 const int32_t* __restrict__ nrows_all,
                                                                  const uint64_t* __restrict__ keep,
                                                                  const int32_t* __restrict__ cloud_of,
-                                                                 float* __restrict__ out, int N, int R,
-                                                                 int nclouds, int with_centre) {
+                                                                 float* __restrict__ out, int R, int nclouds,
+                                                                 int with_centre) {
     const int item = blockIdx.x;
     const int cloud = cloud_of ? cloud_of[item] : (nclouds == 1 ? 0 : item);
     const uint64_t full = R >= 64 ? ~0ull : ((1ull << R) - 1);
@@ -486,16 +494,13 @@ __global__ __launch_bounds__(kThreads) void pn_stn_gather_kernel(const float* __
     const int per = R + with_centre;
     const f32x4* g4 = reinterpret_cast<const f32x4*>(G) + (size_t)cloud * per * (kFeat / 4) + threadIdx.x;
     f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    const int32_t* roff = roff_all + (size_t)cloud * (R + 1);
-    int nkept = 0;
     for (int r = 0; r < R; ++r) {
         if ((k >> r) & 1) {
-            nkept += roff[r + 1] - roff[r];
             const f32x4 v = g4[(size_t)r * (kFeat / 4)];
             m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
         }
     }
-    if (with_centre && nkept < N) {
+    if (nrows_all[item] >> 16) {  // a centre row exists (something was masked)
         const f32x4 v = g4[(size_t)R * (kFeat / 4)];
         m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
     }
@@ -609,6 +614,10 @@ int launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, 
 struct Workspace {
     uint16_t* sorted_pts;
     int32_t* roff;
+    uint16_t* rows_pre;  // (nclouds*(R+1), kRowCap)
+    int32_t* nrows_pre;
+    uint16_t* rows;      // (B, kRowCap)
+    int32_t* nrows;      // (B)
     int32_t* order;    // (B) launch order
     int32_t* bin_of;   // (B)
     int32_t* hist;     // (kBins)
@@ -631,6 +640,10 @@ Workspace carve(void* base, int B, int nclouds, int N, int R) {
     };
     w.sorted_pts = reinterpret_cast<uint16_t*>(take((size_t)nclouds * N * sizeof(uint16_t)));
     w.roff = reinterpret_cast<int32_t*>(take((size_t)nclouds * (IQ_MAX_REGIONS + 1) * sizeof(int32_t)));
+    w.rows_pre = reinterpret_cast<uint16_t*>(take((size_t)nclouds * (R + 1) * kRowCap * sizeof(uint16_t)));
+    w.nrows_pre = reinterpret_cast<int32_t*>(take((size_t)nclouds * (R + 1) * sizeof(int32_t)));
+    w.rows = reinterpret_cast<uint16_t*>(take((size_t)B * kRowCap * sizeof(uint16_t)));
+    w.nrows = reinterpret_cast<int32_t*>(take((size_t)B * sizeof(int32_t)));
     w.order = reinterpret_cast<int32_t*>(take((size_t)B * sizeof(int32_t)));
     w.bin_of = reinterpret_cast<int32_t*>(take((size_t)B * sizeof(int32_t)));
     w.hist = reinterpret_cast<int32_t*>(take((size_t)kBins * sizeof(int32_t)));
@@ -709,13 +722,19 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
 
     hipLaunchKernelGGL(pn_prepare_kernel, dim3(nclouds), dim3(kThreads), 0, st, region_id, ws.sorted_pts, ws.roff, N, R);
     if ((rc = iq::check_launch("pn_prepare_kernel"))) return rc;
+    const int pre_items = nclouds * (R + with_centre);
+    hipLaunchKernelGGL(pn_rows_kernel, dim3(pre_items), dim3(64), 0, st, ws.sorted_pts, ws.roff, nullptr, nullptr,
+                       ws.rows_pre, ws.nrows_pre, N, R, nclouds, with_centre, 1);
+    hipLaunchKernelGGL(pn_rows_kernel, dim3(B), dim3(64), 0, st, ws.sorted_pts, ws.roff, keep, cloud_of, ws.rows,
+                       ws.nrows, N, R, nclouds, with_centre, 0);
+    if ((rc = iq::check_launch("pn_rows_kernel"))) return rc;
     // launch order of the coalition chains: most rows first, so the grid drains evenly
     const bool lpt = iq::tuning(iq::kTuneNoLpt) == 0;
     if (lpt) {
         if (hipMemsetAsync(ws.hist, 0, kBins * sizeof(int32_t), st) != hipSuccess)
             return iq::fail(IQ_ELAUNCH, "iq_pointnet_coalitions: memset failed");
-        hipLaunchKernelGGL(pn_order_count_kernel, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0, st, ws.roff,
-                           keep, cloud_of, ws.bin_of, ws.hist, B, N, R, nclouds, with_centre);
+        hipLaunchKernelGGL(pn_order_count_kernel, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0, st, ws.nrows,
+                           ws.bin_of, ws.hist, B);
         hipLaunchKernelGGL(pn_order_scan_kernel, dim3(1), dim3(64), 0, st, ws.hist);
         hipLaunchKernelGGL(pn_order_scatter_kernel, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
                            ws.bin_of, ws.hist, ws.order, B);
@@ -727,35 +746,36 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
     if (channel_first) { a.ps = 1; a.cs = N; } else { a.ps = 3; a.cs = 1; }
     a.cl = 3 * N;
     a.centers = centers;
-    a.sorted_pts = ws.sorted_pts;
-    a.roff = ws.roff;
+    a.rows = ws.rows_pre;
+    a.nrows = ws.nrows_pre;
     a.item_order = nullptr;
     a.N = N; a.R = R; a.nclouds = nclouds; a.with_centre = with_centre;
     a.stamps = g_stamps;
 
     // 1. input-STN chain, pre-pooled per (cloud, region) [+ centre]
-    a.keep = nullptr; a.cloud_of = nullptr; a.trans = nullptr;
+    a.cloud_of = nullptr; a.trans = nullptr;
     a.w_in = w->stn_in;
     a.w1 = nullptr; a.b1 = nullptr;
     a.w2 = w->stn_c2.w; a.b2 = w->stn_c2.b;
     a.w3 = w->stn_c3.w; a.b3 = w->stn_c3.b;
     a.out = ws.G;
-    a.items = nclouds * (R + with_centre);
+    a.items = pre_items;
     {
         iq::ProfileSpan span(iq::kSlotPrepool, st);
         launch_chain<kPrepool>(a, st);
     }
     if ((rc = iq::check_launch("pn_chain_kernel<prepool>"))) return rc;
 
-    hipLaunchKernelGGL(pn_stn_gather_kernel, dim3(B), dim3(kThreads), 0, st, ws.G, ws.roff, keep, cloud_of, ws.gbuf,
-                       N, R, nclouds, with_centre);
+    hipLaunchKernelGGL(pn_stn_gather_kernel, dim3(B), dim3(kThreads), 0, st, ws.G, ws.nrows, keep, cloud_of, ws.gbuf,
+                       R, nclouds, with_centre);
     if ((rc = iq::check_launch("pn_stn_gather_kernel"))) return rc;
     if ((rc = launch_linear(ws.gbuf, kFeat, w->stn_fc1, ws.h1, 512, B, 1, st))) return rc;
     if ((rc = launch_linear(ws.h1, 512, w->stn_fc2, ws.h2, 256, B, 1, st))) return rc;
     if ((rc = launch_linear(ws.h2, 256, w->stn_fc3, ws.trans, 9, B, 0, st))) return rc;
 
     // 2. feature-STN chain over each coalition's distinct points
-    a.keep = keep; a.cloud_of = cloud_of; a.trans = ws.trans;
+    a.cloud_of = cloud_of; a.trans = ws.trans;
+    a.rows = ws.rows; a.nrows = ws.nrows;
     a.item_order = lpt ? ws.order : nullptr;
     a.w_in = w->feat_in;
     a.w1 = w->fstn_c1.w; a.b1 = w->fstn_c1.b;
