@@ -1,0 +1,196 @@
+"""Stage 1 of scripts/exp_shapley.sh - host-side mirror of final_shapley_value.py (and of the
+pre-stage final_save_fps.py): region ids, norm factor, 1000 sampled permutations and the region
+Shapley values of every cloud at its original pose.
+
+Same artefacts as the reference: region_id.npy, norm_factor.npy, all_orders.npy,
+shapley/<i>_<count>.npy, region_shapley/<i>_<count>.npy, region_sv_all.npy.  The reference issues
+one 33-cloud forward per permutation with a host sync each (final_shapley_value.py:138-150); here
+all permutations of a cloud go through ONE fused launch per rank and the float64 accumulation runs
+on the device in permutation order (bit-identical order of adds).
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from . import dist as iqdist
+from . import final_common, hip_ops
+from .final_util import (NUM_POINTS, NUM_REGIONS, NUM_SAMPLES_SAVE, IOStream, exp_folder, get_folder_name_list,
+                         load_model, mkdir, set_model_args, set_random, synthetic_loader)
+
+SAMPLE_NUMS = [100, 200, 300, 400, 500, 600, 700, 800, 900, 1000, 2000, 3000, 4000, 5000]  # final_shapley_value.py:111
+
+
+def farthest_point_sample(xyz, npoint):
+    """final_save_fps.py:10-31.  xyz (B,N,3) GPU tensor -> (B,npoint) int64."""
+    return hip_ops.fps(xyz.contiguous(), npoint).long()
+
+
+def fps_index_path(args):
+    return "fps_%s_%d_%d_index_final30.npy" % (args.dataset, args.num_points, args.num_regions)
+
+
+def save_fps(args, loader=None):
+    """final_save_fps.py:34-54 -> fps_<dataset>_<N>_<R>_index_final30.npy (30,R) int64."""
+    loader = loader if loader is not None else data_loader(args)
+    rows = [farthest_point_sample(data.to(args.device), args.num_regions).cpu().numpy() for data, _ in loader]
+    out = np.concatenate(rows)
+    np.save(fps_index_path(args), out)
+    return out
+
+
+def data_loader(args):
+    """The reference's 30-cloud loaders need the datasets (final_data_shapley.py:47-179), which are
+    not available offline; ``--synthetic`` substitutes the seeded synthetic clouds."""
+    if getattr(args, "synthetic", False):
+        return synthetic_loader(args)
+    raise FileNotFoundError("dataset loaders are out of scope of this build (SURVEY.md §2 row 9); run with --synthetic")
+
+
+def cal_region_id(data, fps_index, result_path, save=True):
+    """final_shapley_value.py:20-35.  data (1,N,3), fps_index (R,) -> (N,) int64 ndarray."""
+    idx = hip_ops.as_i32(fps_index, data.device)
+    region_id = hip_ops.region_assign(data[0].contiguous(), idx).cpu().numpy().astype(np.int64)
+    if save:
+        np.save(result_path + "region_id.npy", region_id)
+    return region_id
+
+
+def cal_norm_factor(model, data, lbl, center, result_path, args, save=True):
+    """final_shapley_value.py:39-56: v(N) - v(empty)."""
+    empty = center.view(1, 1, 3).expand(data.shape[0], args.num_points, 3).clone()
+    v_n, _ = final_common.cal_reward(model, data, lbl, args)
+    v_0, _ = final_common.cal_reward(model, empty, lbl, args)
+    norm_factor = (v_n - v_0).cpu().item()
+    if save:
+        np.save(result_path + "norm_factor.npy", norm_factor)
+    return norm_factor
+
+
+def generate_all_orders(result_path, args, save=True):
+    """final_shapley_value.py:59-72 - host NumPy global RNG, so the stream (and all_orders.npy) is
+    the reference's for the same seed."""
+    rows = [np.random.permutation(np.arange(0, args.num_regions, 1)).reshape((1, -1))
+            for _ in range(args.num_samples_save)]
+    all_orders = np.concatenate(rows, axis=0)
+    if save:
+        np.save(result_path + "all_orders.npy", all_orders)
+    return all_orders
+
+
+def mask_data(masked_data, center, order, region_id):
+    """final_shapley_value.py:74-88 (one order)."""
+    ns = argparse.Namespace(num_regions=len(order))
+    return final_common.mask_data_batch(masked_data, center, np.asarray(order)[None, :], region_id, ns)
+
+
+def save_shapley(region_shap_value, pc_idx, count, result_path, region_id, args):
+    """final_shapley_value.py:91-106."""
+    shap_value = np.zeros((args.num_points,))
+    mkdir(result_path + "shapley/")
+    mkdir(result_path + "region_shapley/")
+    for k in range(args.num_regions):
+        shap_value[region_id == k] = region_shap_value[k] / count
+    np.save(result_path + "shapley/%s.npy" % (str(pc_idx) + "_" + str(count)), shap_value)
+    np.save(result_path + "region_shapley/%s.npy" % (str(pc_idx) + "_" + str(count)), region_shap_value / count)
+
+
+def shapley_all_orders(model, data, lbl, region_id, all_orders, args):
+    """Loop A for one cloud (final_shapley_value.py:138-156), sharded over ranks by permutation.
+    Returns (running sums at SAMPLE_NUMS {count: (R,)}, region_sv_all (S,R) float64, total (R,))."""
+    s = len(all_orders)
+
+    def rewards(lo, hi):  # this rank's permutations -> (hi-lo, R+1) rewards
+        if hi == lo:
+            return torch.zeros((0, args.num_regions + 1), dtype=torch.float32, device=data.device)
+        logits = final_common.shapley_logits(model, data, lbl, region_id, all_orders[lo:hi], args)
+        return final_common.get_reward(logits, lbl, args).reshape(hi - lo, args.num_regions + 1)
+
+    v = iqdist.sharded_rows(s, rewards).reshape(-1)  # one gather per cloud
+    counts = [c for c in SAMPLE_NUMS if c <= s]
+    total, rows, snaps = hip_ops.shapley_accum(v.contiguous(), hip_ops.as_i32(all_orders, v.device), snap_counts=counts)
+    snaps = snaps.cpu().numpy() if snaps is not None else np.zeros((0, args.num_regions))
+    return {c: snaps[k] for k, c in enumerate(counts)}, rows.cpu().numpy(), total.cpu().numpy()
+
+
+def shap_sampling(model, dataloader, args, folder_name_list):
+    """final_shapley_value.py:110-156."""
+    with torch.no_grad():
+        fps_indices = np.load(fps_index_path(args))
+        for i, (data, lbl) in enumerate(dataloader):
+            result_path = args.exp_folder + "%s/" % folder_name_list[i]
+            mkdir(result_path)
+            data, lbl = data.to(args.device), lbl.to(args.device)
+            write = iqdist.rank() == 0
+            region_id = cal_region_id(data, fps_indices[i], result_path, save=write)
+            center = torch.mean(data, dim=1).squeeze()
+            cal_norm_factor(model, data, lbl, center, result_path, args, save=write)
+            all_orders = generate_all_orders(result_path, args, save=write)  # same RNG stream on every rank
+            print("pointcloud:%s, index:%d, samples:%d" % (folder_name_list[i], i, len(all_orders)))
+            snaps, region_sv_all, _ = shapley_all_orders(model, data, lbl, region_id, all_orders, args)
+            if write:
+                for count, running in snaps.items():
+                    save_shapley(running, i, count, result_path, region_id, args)
+                np.save(result_path + "region_sv_all.npy", region_sv_all)
+
+
+def test(args):
+    """final_shapley_value.py:159-174."""
+    model = load_model(args)
+    folder_name_list = get_folder_name_list(args)
+    if not os.path.exists(fps_index_path(args)):
+        save_fps(args)  # the reference runs final_save_fps.py by hand before exp_shapley.sh
+    shap_sampling(model, data_loader(args), args, folder_name_list)
+
+
+def build_parser(default_model="pointconv", default_dataset="shapenet"):
+    """Flags of final_shapley_value.py:178-187, verbatim, plus additive ones for offline use."""
+    p = argparse.ArgumentParser(description="Point Cloud Recognition")
+    p.add_argument("--model", type=str, default=default_model, metavar="N",
+                   choices=["pointnet", "dgcnn", "gcnn", "pointnet2", "pointconv", "gcnn_adv"])
+    p.add_argument("--dataset", type=str, default=default_dataset, metavar="N", choices=["modelnet10", "shapenet"])
+    p.add_argument("--test_batch_size", type=int, default=1, metavar="batch_size", help="Size of batch)")
+    p.add_argument("--no_cuda", type=bool, default=False, help="enables CUDA training")
+    p.add_argument("--seed", type=int, default=1, metavar="S", help="random seed (default: 1)")
+    p.add_argument("--device_id", type=int, default=0, help="gpu id to use")
+    p.add_argument("--softmax_type", type=str, default="modified", choices=["normal", "modified"])
+    # additive (not in the reference)
+    p.add_argument("--synthetic", action="store_true", help="synthetic clouds/weights (no datasets or checkpoints offline)")
+    p.add_argument("--num_clouds", type=int, default=30)
+    return p
+
+
+def finish_args(args):
+    """Common tail of every stage's main() (final_shapley_value.py:189-203)."""
+    args.num_points = NUM_POINTS
+    args.num_regions = getattr(args, "num_regions", None) or NUM_REGIONS
+    args.exp_folder = exp_folder(args)
+    _, world, local_rank = iqdist.init_from_env("cuda")
+    if world == 1:
+        os.environ.setdefault("HIP_VISIBLE_DEVICES", str(args.device_id))  # CUDA_VISIBLE_DEVICES of the reference
+        local_rank = 0
+    if args.no_cuda or not torch.cuda.is_available():
+        raise SystemExit("this build has no CPU path: a GPU is required (the reference's --no_cuda is not supported)")
+    torch.cuda.set_device(local_rank)
+    args.cuda = True
+    args.device = torch.device("cuda", local_rank)
+    mkdir("checkpoints")
+    mkdir(args.exp_folder)
+    set_random(args.seed)
+    set_model_args(args)
+    print("Using GPU : %d from %d devices" % (torch.cuda.current_device(), torch.cuda.device_count()))
+    return args
+
+
+def main(argv=None):
+    parser = build_parser()
+    parser.add_argument("--num_samples_save", type=int, default=NUM_SAMPLES_SAVE)  # additive
+    parser.add_argument("--num_regions", type=int, default=NUM_REGIONS)            # additive
+    args = parser.parse_args(argv)
+    finish_args(args)
+    test(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,195 @@
+"""GPU: the host-side mirror of the reference interface (same function names / argument meaning)
+and the drop-in stage scripts, end to end, against golden vectors and the CPU oracle."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from interpret_quality_amd import final_common, hip_ops, interaction, pose_sweep, shapley_stage, synth
+from interpret_quality_amd.pointnet import PointNetCls
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import ref_cpu
+    return ref_cpu
+
+
+@pytest.fixture(scope="module")
+def model(pointnet_sd):
+    m = PointNetCls(None)
+    m.load_state_dict(pointnet_sd)
+    return m.to(dev()).eval()
+
+
+def ns(**kw):
+    base = dict(model="pointnet", softmax_type="modified", num_points=1024, verbose=False)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+@pytest.mark.parametrize("num_regions", [8, 32])
+def test_shap_sampling_all_regions_batch_matches_reference(model, num_regions):
+    g = load_golden("pointnet_shapley_R%d.npz" % num_regions)
+    args = ns(num_regions=num_regions, num_samples=int(g["num_samples"]), shapley_batch_size=int(g["bs"]))
+    for ci in g["cloud_ids"]:
+        p = "c%d_" % ci
+        pts, label = synth.make_cloud(int(ci))
+        data = torch.from_numpy(pts).unsqueeze(0).to(dev())
+        lbl = torch.tensor([label], device=dev())
+        phi, logits = final_common.shap_sampling_all_regions_batch(model, data, lbl, g[p + "region_id"], g[p + "orders"], args)
+        assert isinstance(phi, np.ndarray) and phi.dtype == np.float64 and phi.shape == (num_regions,)
+        assert rel_err(logits.cpu().numpy(), g[p + "logits"]) < RTOL
+        assert np.abs(phi - g[p + "phi"]).max() < RTOL * np.abs(g[p + "phi"]).max()
+    bad = ns(num_regions=num_regions, num_samples=8, shapley_batch_size=3)
+    with pytest.raises(Exception):
+        final_common.shap_sampling_all_regions_batch(model, data, lbl, g[p + "region_id"], g[p + "orders"], bad)
+
+
+def test_mask_data_batch_inplace_and_cal_reward(model, oracle):
+    g = load_golden("pointnet_shapley_R32.npz")
+    pts, label = synth.make_cloud(0)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    center = torch.mean(data, dim=1).squeeze()
+    orders = g["c0_orders"][:4]
+    want = oracle.shapley_masked_batch(data, center, orders, g["c0_region_id"])
+    masked = data.to(dev()).expand(33 * 4, 1024, 3).clone()
+    out = final_common.mask_data_batch(masked, center.to(dev()), orders, g["c0_region_id"], ns(num_regions=32))
+    assert out.data_ptr() == masked.data_ptr() and torch.equal(masked.cpu(), want)
+    m1 = data.to(dev()).expand(33, 1024, 3).clone()
+    shapley_stage.mask_data(m1, center.to(dev()), orders[0], g["c0_region_id"])
+    assert torch.equal(m1.cpu(), want[:33])
+    v, logits = final_common.cal_reward(model, masked, torch.tensor([label], device=dev()), ns())
+    assert rel_err(v.cpu().numpy(), g["c0_v_batch0"]) < RTOL
+
+
+def test_shapley_over_poses_matches_oracle(model, oracle, pointnet_sd):
+    num_regions, s = 8, 4
+    pts, label = synth.make_cloud(1)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    lbl = torch.tensor([label])
+    region_id = oracle.cal_region_id(data, oracle.farthest_point_sample(data, num_regions)[0])
+    orders = synth.make_orders(s, num_regions, seed=7)
+    poses = [oracle.rotate_xyz(data, torch.tensor([0.3, -0.2, 0.6])), oracle.translate_pc(data, torch.tensor([0.2, 0.1, -0.3])),
+             oracle.scale_pc(data, torch.tensor(1.5))]
+    args = ns(num_regions=num_regions, num_samples=s, shapley_batch_size=2)
+    phi, logits = pose_sweep.shapley_over_poses(model, torch.cat(poses).to(dev()), lbl.to(dev()), region_id, orders, args,
+                                                pose_batch=2)
+    om = oracle.PointNetOracle(pointnet_sd)
+    for k, pose in enumerate(poses):
+        o_phi, o_logits = oracle.shap_sampling_all_regions_batch(om, pose, lbl, region_id, orders, s, 2, num_regions)
+        assert rel_err(logits[k].cpu().numpy(), o_logits.numpy()) < RTOL
+        assert np.abs(phi[k].cpu().numpy() - o_phi).max() < RTOL * np.abs(o_phi).max()
+    # device-side perturbations agree with the oracle's
+    assert rel_err(pose_sweep.rotate_xyz(data.to(dev()), torch.tensor([0.3, -0.2, 0.6], device=dev())).cpu().numpy(),
+                   poses[0].numpy()) < 1e-6
+
+
+def test_interaction_functions_match_reference(model):
+    g = load_golden("pointnet_interaction_R32.npz")
+    pts, label = synth.make_cloud(int(g["cloud_id"]))
+    data = torch.from_numpy(pts).unsqueeze(0).to(dev())
+    lbl = torch.tensor([label], device=dev())
+    args = ns(num_regions=32, interaction_batch_size=int(g["bs"]))
+    for tag in ("ratio0", "ratio4", "ratio50", "ratio100"):
+        logits = interaction.compute_order_interaction_logits(model, data, g["region_id"], g["pairs"], g[tag + "_contexts"], args)
+        assert logits.shape == g[tag + "_logits"].shape
+        assert rel_err(logits.cpu().numpy(), g[tag + "_logits"]) < RTOL
+        inter = interaction.compute_order_interaction(torch.from_numpy(g[tag + "_logits"]).to(dev()), lbl, args)
+        assert inter.dtype == np.float64
+        np.testing.assert_allclose(inter, g[tag + "_interaction"], rtol=0, atol=2e-6)
+        # |dI| <= 1e-4 max|v| when the logits come from the HIP path (differences of 4 near-equal rewards)
+        mine = interaction.compute_order_interaction(logits, lbl, args)
+        vmax = np.abs(hip_ops.reward(torch.from_numpy(g[tag + "_logits"]).reshape(-1, 10).to(dev()), label).cpu().numpy()).max()
+        assert np.abs(mine - g[tag + "_interaction"]).max() < RTOL * vmax
+    empty = interaction.compute_order_interaction_logits(model, data, g["region_id"], np.zeros((0, 2), dtype=np.int64),
+                                                         np.zeros((0, 6, 15), dtype=np.int64), args)
+    assert tuple(empty.shape) == (0, 24, 10)
+
+
+def test_stage_scripts_end_to_end(tmp_path, monkeypatch, oracle, pointnet_sd):
+    """exp_shapley.sh stage 1 + the scale sweep + exp_interaction.sh stages 2-3 on synthetic data:
+    artefact names/shapes of SURVEY.md §8b, efficiency axiom, values against the oracle."""
+    monkeypatch.chdir(tmp_path)
+    common = ["--model", "pointnet", "--dataset", "modelnet10", "--synthetic", "--num_clouds", "1"]
+    shapley_stage.main(common + ["--num_samples_save", "100", "--num_regions", "8"])
+    root = "checkpoints/exp_MODEL_pointnet_DATA_modelnet10_POINTNUM_1024_REGIONNUM_8_shapley_test/synthetic_00/"
+    region_id = np.load(root + "region_id.npy")
+    orders = np.load(root + "all_orders.npy")
+    nf = float(np.load(root + "norm_factor.npy"))
+    sv_all = np.load(root + "region_sv_all.npy")
+    assert region_id.shape == (1024,) and region_id.dtype == np.int64 and orders.shape == (100, 8) and sv_all.shape == (100, 8)
+    assert np.array_equal(orders, synth.make_orders(100, 8, seed=1))          # the reference's RNG stream
+    np.testing.assert_allclose(sv_all.sum(1), nf, rtol=0, atol=2e-4)          # efficiency, every permutation
+    phi100 = np.load(root + "region_shapley/0_100.npy")
+    pts, label = synth.make_cloud(0)
+    data, lbl = torch.from_numpy(pts).unsqueeze(0), torch.tensor([label])
+    o_total, _ = oracle.shap_sampling_stage1(oracle.PointNetOracle(pointnet_sd), data, lbl, region_id, orders[:20], 8)
+    assert np.abs(sv_all[:20].sum(0) - o_total).max() < RTOL * np.abs(o_total).max()
+    np.testing.assert_allclose(phi100, sv_all.sum(0) / 100, rtol=1e-12)
+    per_point = np.load(root + "shapley/0_100.npy")
+    assert per_point.shape == (1024,) and np.allclose(per_point, phi100[region_id])
+    assert os.path.exists("fps_modelnet10_1024_8_index_final30.npy")
+
+
+def test_pose_sweep_and_interaction_scripts(tmp_path, monkeypatch, oracle):
+    monkeypatch.chdir(tmp_path)
+    common = ["--model", "pointnet", "--dataset", "modelnet10", "--synthetic", "--num_clouds", "1"]
+    shapley_stage.main(common + ["--num_samples_save", "100"])
+    root = "checkpoints/exp_MODEL_pointnet_DATA_modelnet10_POINTNUM_1024_REGIONNUM_32_shapley_test/synthetic_00/"
+    pose_sweep.main_scale(common)
+    phi = np.load(root + "scale_all/region_shapley_value.npy")
+    logits = torch.load(root + "scale_all/all_logits.pt")
+    assert phi.shape == (30, 32) and tuple(logits.shape) == (30, 3300, 10)
+    assert np.load(root + "scale_all/scale.npy").shape == (30,)
+    orig = np.load(root + "scale_all/orig_shapley_value.npy")
+    k = int(np.argmin(np.abs(np.load(root + "scale_all/scale.npy") - 1.0)))
+    assert orig.shape == (32,) and os.path.exists(root + "scale_all/log.txt")
+    # efficiency per pose: sum phi = mean over permutations of v(N) - v(empty)
+    v = hip_ops.reward(logits.reshape(-1, 10).cuda().contiguous(), 0, True).reshape(30, 100, 33)
+    np.testing.assert_allclose(phi.sum(1), (v[:, :, 32] - v[:, :, 0]).double().mean(1).cpu().numpy(), atol=2e-4)
+    assert k >= 0
+    # interaction: hand-made stage-1 artefacts (final_gen_pair.py is a "next" row)
+    inter = root + "interaction_seed1/"
+    os.makedirs(inter + "normal")
+    os.makedirs(inter + "rotate_adv")
+    rng = np.random.default_rng(0)
+    pairs = np.array([[1, 5], [7, 30], [0, 31]])
+    np.save(inter + "region_pair_list.npy", pairs)
+    ratios = interaction.DEFAULT_RATIOS
+    for ratio in ratios:
+        m = int(30 * ratio)
+        c = 1 if m in (0, 30) else 3
+        ctx = np.zeros((3, c, m), dtype=np.int64)
+        for p in range(3):
+            rest = [r for r in range(32) if r not in pairs[p]]
+            for j in range(c):
+                ctx[p, j] = rng.choice(rest, m, replace=False)
+        np.save(inter + "ratio%d_context_list.npy" % int(ratio * 100), ctx)
+    np.save(inter + "rotate_adv/transform_params.npy", np.array([0.4, -0.3, 0.2]))
+    np.save(inter + "rotate_adv/pred_labels.npy", np.array([0, 3]))
+    interaction.main_logits(common)
+    interaction.main_cal(common)
+    for sub, lab in (("normal/", 0), ("rotate_adv/", 3)):
+        for ratio in (0.0, 0.5, 1.0):
+            tag = "ratio%d" % int(ratio * 100)
+            lg = torch.load(inter + sub + tag + "_all_logits.pt")
+            got = np.load(inter + sub + tag + "_pred_interaction.npy")
+            want = oracle.compute_order_interaction(lg.cpu(), torch.tensor([lab]))
+            assert got.shape == want.shape == (3, lg.shape[1] // 4)
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)

@@ -1,0 +1,122 @@
+"""CPU: host-side logic of the drop-in drivers (mask construction, batch-size knobs, pose grids,
+sharding) and the world_size-2 gloo path."""
+import argparse
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import load_golden
+from interpret_quality_amd import dist as iqdist
+from interpret_quality_amd import final_common, final_util, interaction, pose_sweep, synth
+
+
+def test_prefix_keep_masks_match_reference_row_semantics():
+    orders = synth.make_orders(5, 32, seed=4)
+    keep = final_common.prefix_keep_masks(orders, 32).reshape(5, 33)
+    for o in range(5):
+        assert keep[o, 0] == 0 and keep[o, 32] == (1 << 32) - 1          # row 0 all masked, row R untouched
+        for i in range(33):
+            assert keep[o, i] == sum(1 << int(r) for r in orders[o][:i])   # row i keeps orders[o][:i]
+
+
+def test_context_keep_masks_row_order_and_empty_context():
+    pairs = np.array([[3, 7], [0, 31]])
+    ctx = np.array([[[1, 2], [4, 5]], [[8, 9], [10, 11]]])
+    k = interaction.context_keep_masks(pairs, ctx).reshape(2, 2, 4)
+    s = (1 << 1) | (1 << 2)
+    assert list(k[0, 0]) == [s | 8 | 128, s | 8, s | 128, s]               # S+{i,j}, S+{i}, S+{j}, S
+    k0 = interaction.context_keep_masks(pairs, np.zeros((2, 1, 0), dtype=np.int64)).reshape(2, 1, 4)
+    assert list(k0[1, 0]) == [1 | (1 << 31), 1, 1 << 31, 0]               # m = 0: empty context
+
+
+def test_batch_size_knobs_follow_config():
+    for model, sb, ib in (("pointnet", 50, 100), ("gcnn_adv", 10, 50), ("pointnet2", 5, 25)):
+        a = argparse.Namespace(model=model, dataset="modelnet10")
+        final_util.set_model_args(a)
+        final_util.set_shapley_batch_size(a)
+        final_util.set_interaction_batch_size(a)
+        assert (a.shapley_batch_size, a.interaction_batch_size) == (sb, ib)
+    assert a.model_path.endswith("exp_MODEL_pointnet2_DATA_modelnet10_POINTNUM_1024_clean/models/model_best.t7")
+    with pytest.raises(Exception):
+        final_util.set_model_args(argparse.Namespace(model="pointnet", dataset="nope"))
+
+
+def test_pose_grids_and_perturbations_match_reference():
+    g = load_golden("geometry.npz")
+    a = argparse.Namespace(angle_threshold=pose_sweep.ANGLE_THRESHOLD, num_grid_enum_rotate=6, trans_dist_threshold=0.5,
+                           num_grid_enum_trans=6, scale_lower=0.5, scale_upper=2.0, num_grid_enum_scale=30)
+    np.testing.assert_array_equal(pose_sweep.generate_rotate_angle(a, "cpu").numpy(), g["rotate_grid"])
+    np.testing.assert_array_equal(pose_sweep.generate_trans_vector(a, "cpu").numpy(), g["trans_grid"])
+    np.testing.assert_array_equal(pose_sweep.generate_scale(a, "cpu").numpy(), g["scale_grid"])
+    data = torch.from_numpy(synth.make_cloud(3)[0]).unsqueeze(0)
+    out = pose_sweep.rotate_xyz(data, torch.from_numpy(g["rotate_in_angle"]))
+    np.testing.assert_array_equal(out[0, :4].numpy(), g["rotate_out_first4"])
+
+
+def test_shard_range_partitions():
+    assert iqdist.shard_counts(300, 8) == [38, 38, 38, 38, 37, 37, 37, 37]
+    assert iqdist.shard_counts(100, 8) == [13, 13, 13, 13, 12, 12, 12, 12]
+    for n in (0, 1, 7, 33):
+        spans = [iqdist.shard_range(n, r, 4) for r in range(4)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(3))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _gloo_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import ref_cpu as O
+    num_regions, s = 8, 5  # 5 permutations over 2 ranks: ragged shards (3, 2)
+    sd = synth.to_torch(synth.pointnet_state_dict(0))
+    model = O.PointNetOracle(sd)
+    pts, label = synth.make_cloud(0)
+    data, lbl = torch.from_numpy(pts).unsqueeze(0), torch.tensor([label])
+    region_id = O.cal_region_id(data, O.farthest_point_sample(data, num_regions)[0])
+    orders = synth.make_orders(s, num_regions, seed=1)
+    center = torch.mean(data, dim=1).squeeze()
+
+    def rewards(lo, hi):  # the oracle stands in for the HIP path (no GPU here)
+        if hi == lo:
+            return torch.zeros((0, num_regions + 1))
+        masked = O.shapley_masked_batch(data, center, orders[lo:hi], region_id)
+        v, _ = O.cal_reward(model, masked, lbl)
+        return v.reshape(hi - lo, num_regions + 1)
+
+    v = iqdist.sharded_rows(s, rewards)
+    empty = iqdist.sharded_rows(1, lambda lo, hi: torch.full((hi - lo, 2), float(rank)))  # rank 1 holds nothing
+    if rank == 0:
+        torch.save({"v": v, "empty": empty}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_sharded_shapley_matches_single_process(tmp_path):
+    from oracle import ref_cpu as O
+    out = str(tmp_path / "gathered.pt")
+    mp.spawn(_gloo_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    num_regions, s = 8, 5
+    sd = synth.to_torch(synth.pointnet_state_dict(0))
+    pts, label = synth.make_cloud(0)
+    data, lbl = torch.from_numpy(pts).unsqueeze(0), torch.tensor([label])
+    region_id = O.cal_region_id(data, O.farthest_point_sample(data, num_regions)[0])
+    orders = synth.make_orders(s, num_regions, seed=1)
+    masked = O.shapley_masked_batch(data, torch.mean(data, dim=1).squeeze(), orders, region_id)
+    v, _ = O.cal_reward(O.PointNetOracle(sd), masked, lbl)
+    # rows are independent in eval mode, so sharding cannot change them (allow last-bit batch effects)
+    np.testing.assert_allclose(got["v"].numpy(), v.reshape(s, num_regions + 1).numpy(), rtol=1e-5, atol=1e-5)
+    assert got["empty"].shape == (1, 2) and float(got["empty"][0, 0]) == 0.0
