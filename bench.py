@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--perms", type=int, default=NUM_PERMS, help="permutations per cloud per step")
     ap.add_argument("--regions", type=int, default=NUM_REGIONS)
     ap.add_argument("--cpu-baseline", type=int, default=1, help="time the CPU oracle on rank 0 at N=1")
-    ap.add_argument("--cpu-perms", type=int, default=20, help="permutations of the bounded CPU sample")
+    ap.add_argument("--cpu-perms", type=int, default=40, help="permutations of the bounded CPU sample")
     return ap.parse_args()
 
 

@@ -138,7 +138,7 @@ def _stn(x, sd, p, k):
     h = F.relu(_bn(_fc(h, sd, p + ".fc1"), sd, p + ".bn4"))
     h = F.relu(_bn(_fc(h, sd, p + ".fc2"), sd, p + ".bn5"))
     h = _fc(h, sd, p + ".fc3")
-    h = h + torch.eye(k, dtype=h.dtype).reshape(1, k * k)
+    h = h + torch.eye(k, dtype=h.dtype, device=h.device).reshape(1, k * k)
     return h.reshape(-1, k, k)
 
 
