@@ -96,4 +96,46 @@ def pointnet_state_dict(seed=0):
 
 def to_torch(sd):
     import torch
-    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    return {k: (torch.tensor(v) if np.ndim(v) == 0 else torch.from_numpy(np.ascontiguousarray(v))) for k, v in sd.items()}
+
+
+# --------------------------------------------------------------------------------------------
+# PointNet++ MSG (models/pointnet2.py:244-276): 163 tensors
+# --------------------------------------------------------------------------------------------
+PN2_SA1 = dict(npoint=512, radius=[0.1, 0.2, 0.4], nsample=[16, 32, 128], in_channel=0,
+               mlp=[[32, 32, 64], [64, 64, 128], [64, 96, 128]])
+PN2_SA2 = dict(npoint=128, radius=[0.2, 0.4, 0.8], nsample=[32, 64, 128], in_channel=320,
+               mlp=[[64, 64, 128], [128, 128, 256], [128, 128, 256]])
+PN2_SA3_MLP = [256, 512, 1024]
+
+
+def _conv2d(sd, name, cout, cin, seed, gain):
+    w = _rng_for(name + ".weight", seed).standard_normal((cout, cin)) * (gain / np.sqrt(cin))
+    b = _rng_for(name + ".bias", seed).standard_normal((cout,)) * 0.05
+    sd[name + ".weight"] = w.astype(np.float32).reshape(cout, cin, 1, 1)
+    sd[name + ".bias"] = b.astype(np.float32)
+
+
+def pointnet2_state_dict(seed=0):
+    """Reference-keyed PointNet2ClsMsg state dict as numpy arrays."""
+    sd = {}
+    g = np.sqrt(2.0)
+    for sa, cfg in (("sa1", PN2_SA1), ("sa2", PN2_SA2)):
+        for i, mlp in enumerate(cfg["mlp"]):
+            last = cfg["in_channel"] + 3
+            for j, c in enumerate(mlp):
+                # relative coordinates are small (radius-scaled): larger first-layer gain keeps signal alive
+                _conv2d(sd, "%s.conv_blocks.%d.%d" % (sa, i, j), c, last, seed, g * (4.0 if (sa == "sa1" and j == 0) else 1.0))
+                _bn(sd, "%s.bn_blocks.%d.%d" % (sa, i, j), c, seed)
+                last = c
+    last = 640 + 3
+    for j, c in enumerate(PN2_SA3_MLP):
+        _conv2d(sd, "sa3.mlp_convs.%d" % j, c, last, seed, g)
+        _bn(sd, "sa3.mlp_bns.%d" % j, c, seed)
+        last = c
+    _linear(sd, "fc1", 512, 1024, seed, False, g)
+    _bn(sd, "bn1", 512, seed)
+    _linear(sd, "fc2", 256, 512, seed, False, g)
+    _bn(sd, "bn2", 256, seed)
+    _linear(sd, "fc3", NUM_CLASSES, 256, seed, False, 0.7)
+    return sd

@@ -321,3 +321,95 @@ def compute_order_interaction(all_logits, lbl, softmax_type="modified"):
         v = get_reward(all_logits[i], lbl, softmax_type).reshape(c, 4)
         out[i] = (v[:, 0] + v[:, 3] - v[:, 1] - v[:, 2]).double().numpy()
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# PointNet++ MSG (models/pointnet2.py)
+# --------------------------------------------------------------------------------------------
+
+def index_points(points, idx):
+    """models/pointnet2.py:27-43 - batched gather.  points (B,N,C), idx (B,...) -> (B,...,C)."""
+    b = points.shape[0]
+    batch = torch.arange(b, device=points.device).reshape([b] + [1] * (idx.dim() - 1)).expand_as(idx)
+    return points[batch, idx, :]
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """models/pointnet2.py:70-91 - the K LOWEST-INDEX points with d^2 <= r^2 (expanded-form
+    distance), padded with the first hit.  -> (B,S,K) int64."""
+    b, n, _ = xyz.shape
+    s = new_xyz.shape[1]
+    idx = torch.arange(n, dtype=torch.long).reshape(1, 1, n).repeat(b, s, 1)
+    d = square_distance(new_xyz, xyz)
+    idx[d > radius ** 2] = n
+    idx = idx.sort(dim=-1)[0][:, :, :nsample]
+    first = idx[:, :, 0].reshape(b, s, 1).repeat(1, 1, nsample)
+    pad = idx == n
+    idx[pad] = first[pad]
+    return idx
+
+
+def _conv2d_bn_relu(x, sd, conv, bn):
+    y = F.conv2d(x, sd[conv + ".weight"], sd[conv + ".bias"])
+    y = F.batch_norm(y, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"], sd[bn + ".bias"],
+                     False, 0.0, BN_EPS)
+    return F.relu(y)
+
+
+def set_abstraction_msg(sd, name, npoint, radius_list, nsample_list, n_layers, xyz_cf, points_cf, return_aux=False):
+    """models/pointnet2.py:201-240.  xyz_cf (B,3,N), points_cf (B,D,N) or None ->
+    (new_xyz (B,3,S), new_points (B,D',S)).  Features first, relative xyz last (:226)."""
+    xyz = xyz_cf.permute(0, 2, 1)
+    points = points_cf.permute(0, 2, 1) if points_cf is not None else None
+    b, n, c = xyz.shape
+    fps = farthest_point_sample(xyz, npoint)
+    new_xyz = index_points(xyz, fps)
+    outs, aux = [], {"fps": fps, "group_idx": []}
+    for i, radius in enumerate(radius_list):
+        k = nsample_list[i]
+        gidx = query_ball_point(radius, k, xyz, new_xyz)
+        aux["group_idx"].append(gidx)
+        g_xyz = index_points(xyz, gidx) - new_xyz.reshape(b, npoint, 1, c)
+        g = torch.cat([index_points(points, gidx), g_xyz], dim=-1) if points is not None else g_xyz
+        g = g.permute(0, 3, 2, 1)  # (B, D, K, S)
+        for j in range(n_layers[i]):
+            g = _conv2d_bn_relu(g, sd, "%s.conv_blocks.%d.%d" % (name, i, j), "%s.bn_blocks.%d.%d" % (name, i, j))
+        outs.append(torch.max(g, 2)[0])
+    res = (new_xyz.permute(0, 2, 1), torch.cat(outs, dim=1))
+    return res + (aux,) if return_aux else res
+
+
+def set_abstraction_all(sd, name, n_layers, xyz_cf, points_cf):
+    """models/pointnet2.py:153-178 with group_all: [xyz, features] (xyz FIRST, absolute, :132-135)."""
+    xyz = xyz_cf.permute(0, 2, 1)
+    b, n, c = xyz.shape
+    g = torch.cat([xyz.reshape(b, 1, n, c), points_cf.permute(0, 2, 1).reshape(b, 1, n, -1)], dim=-1)
+    g = g.permute(0, 3, 2, 1)
+    for j in range(n_layers):
+        g = _conv2d_bn_relu(g, sd, "%s.mlp_convs.%d" % (name, j), "%s.mlp_bns.%d" % (name, j))
+    return torch.max(g, 2)[0]
+
+
+def pointnet2_forward(sd, xyz_cf, return_aux=False):
+    """models/pointnet2.py:264-276 - eval-mode PointNet2ClsMsg.  (B,3,N) -> logits (B,10)."""
+    b = xyz_cf.shape[0]
+    r1 = set_abstraction_msg(sd, "sa1", 512, [0.1, 0.2, 0.4], [16, 32, 128], [3, 3, 3], xyz_cf, None, return_aux)
+    r2 = set_abstraction_msg(sd, "sa2", 128, [0.2, 0.4, 0.8], [32, 64, 128], [3, 3, 3], r1[0], r1[1], return_aux)
+    l3 = set_abstraction_all(sd, "sa3", 3, r2[0], r2[1])
+    x = l3.reshape(b, 1024)
+    x = F.relu(_bn(_fc(x, sd, "fc1"), sd, "bn1"))
+    x = F.relu(_bn(_fc(x, sd, "fc2"), sd, "bn2"))
+    logits = _fc(x, sd, "fc3")
+    if return_aux:
+        return logits, {"sa1": r1[2], "sa2": r2[2], "l1_xyz": r1[0], "l1_points": r1[1], "l2_xyz": r2[0], "l2_points": r2[1]}
+    return logits
+
+
+class PointNet2Oracle:
+    def __init__(self, state_dict):
+        self.sd = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v)))
+                   for k, v in state_dict.items()}
+
+    def __call__(self, x):
+        with torch.no_grad():
+            return pointnet2_forward(self.sd, x)

@@ -103,3 +103,25 @@ def test_geometry_matches_reference():
     np.testing.assert_array_equal(O.generate_scale().numpy(), g["scale_grid"])
     np.testing.assert_array_equal(O.translate_pc(data, torch.tensor([0.1, -0.2, 0.3]))[0, :4].numpy(), g["translate_out_first4"])
     np.testing.assert_array_equal(O.scale_pc(data, torch.tensor(1.7))[0, :4].numpy(), g["scale_out_first4"])
+
+
+def test_pointnet2_oracle_matches_reference():
+    g = load_golden("pointnet2.npz")
+    sd = synth.to_torch(synth.pointnet2_state_dict(0))
+    pts, label = synth.make_cloud(0)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    center = torch.mean(data, dim=1).squeeze()
+    masked = O.shapley_masked_batch(data, center, g["orders"], g["region_id"])
+    x = masked.permute(0, 2, 1).contiguous()
+    sel = list(g["sel"])
+    with torch.no_grad():
+        logits, aux = O.pointnet2_forward(sd, x[sel], return_aux=True)
+    assert np.array_equal(aux["sa1"]["fps"].numpy(), g["fps1"][sel])
+    assert np.array_equal(aux["sa2"]["fps"].numpy(), g["fps2"][sel])
+    for i, r in enumerate((0.1, 0.2, 0.4)):
+        assert np.array_equal(aux["sa1"]["group_idx"][i].numpy(), g["sa1_ball_r%g" % r])
+    for i, r in enumerate((0.2, 0.4, 0.8)):
+        assert np.array_equal(aux["sa2"]["group_idx"][i].numpy(), g["sa2_ball_r%g" % r])
+    np.testing.assert_allclose(aux["l1_points"][:, :, :8].numpy(), g["l1_points_rows"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(aux["l2_points"][:, :, :8].numpy(), g["l2_points_rows"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(logits.numpy(), g["logits"][sel], rtol=1e-5, atol=1e-5)
