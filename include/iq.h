@@ -168,6 +168,41 @@ int iq_pointnet_coalitions(const iq_pointnet_weights* w /*host struct of device 
  * N = 1024), the basis of bench.py's roofline figures. */
 double iq_pointnet_flops_per_coalition(int N);
 
+/* ---------------------------------------------------------------------------------------------
+ * PointNet++ MSG (models/pointnet2.py:12-276)
+ * ------------------------------------------------------------------------------------------- */
+
+/* models/pointnet2.py:70-91 (query_ball_point): for every centroid the K LOWEST-INDEX points with
+ * squared distance <= radius^2 (expanded form -2 c.p + |c|^2 + |p|^2), padded with the first hit.
+ * xyz (B,N,3), new_xyz (B,S,3) -> idx (B,S,K) int32. */
+int iq_ball_query(const float* xyz, const float* new_xyz, float radius, int K, int32_t* idx,
+                  int B, int N, int S, iq_stream_t stream);
+
+/* One scale of a multi-scale set abstraction: layer 1 = relu(w1x . (x_p - c) [+ U_p]), then the
+ * dense layers l2, l3 (BN folded, packed), max over the `nsample` members. */
+typedef struct iq_pn2_scale {
+    const float* w1x;      /* [C1][4] = (wx0, wx1, wx2, bias); bias = 0 when the per-point part U carries it */
+    iq_dense_layer l2, l3;
+    float radius;
+    int32_t nsample;
+} iq_pn2_scale;
+
+typedef struct iq_pointnet2_weights {
+    iq_pn2_scale sa1[3];
+    iq_dense_layer sa2_u;  /* 320 -> 64+128+128: feature part of layer 1 of the three sa2 scales (+bias) */
+    iq_pn2_scale sa2[3];
+    iq_dense_layer sa3_l1, sa3_l2, sa3_l3;  /* 643 (zero-padded to 648: [xyz, features]) -> 256 -> 512 -> 1024 */
+    iq_dense_layer fc1, fc2, fc3;
+} iq_pointnet2_weights;
+
+size_t iq_pointnet2_workspace_bytes(int B);
+
+/* Eval-mode PointNet2ClsMsg.forward (models/pointnet2.py:264-276) on B materialised clouds.
+ * xyz (B,N,3) channel-LAST (what iq_mask_* writes with channel_first = 0) -> logits (B,10). */
+int iq_pointnet2_forward(const iq_pointnet2_weights* w /*host struct of device pointers*/, const float* xyz,
+                         float* logits, void* workspace, size_t workspace_bytes, int B, int N,
+                         iq_stream_t stream);
+
 /* Optional HIP-event profiler (bench.py's roofline leg).  While enabled, iq_pointnet_coalitions
  * brackets its chain-kernel launches with hipEvents recorded on the launch stream.
  * iq_profile_read(slot) synchronises on the recorded events of that slot, returns their summed

@@ -35,6 +35,17 @@ class PointNetWeights(ctypes.Structure):
     ]
 
 
+class Pn2Scale(ctypes.Structure):
+    _fields_ = [("w1x", ctypes.c_void_p), ("l2", DenseLayer), ("l3", DenseLayer), ("radius", ctypes.c_float),
+                ("nsample", ctypes.c_int32)]
+
+
+class PointNet2Weights(ctypes.Structure):
+    _fields_ = [("sa1", Pn2Scale * 3), ("sa2_u", DenseLayer), ("sa2", Pn2Scale * 3),
+                ("sa3_l1", DenseLayer), ("sa3_l2", DenseLayer), ("sa3_l3", DenseLayer),
+                ("fc1", DenseLayer), ("fc2", DenseLayer), ("fc3", DenseLayer)]
+
+
 _I = ctypes.c_int
 _P = ctypes.c_void_p
 _SZ = ctypes.c_size_t
@@ -59,6 +70,9 @@ SIGNATURES = {
     "iq_pointnet_coalitions": (_I, [ctypes.POINTER(PointNetWeights), _P, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                     _I, _I, _I, _I, _I, _P]),
     "iq_pointnet_flops_per_coalition": (ctypes.c_double, [_I]),
+    "iq_ball_query": (_I, [_P, _P, ctypes.c_float, _I, _P, _I, _I, _I, _P]),
+    "iq_pointnet2_workspace_bytes": (_SZ, [_I]),
+    "iq_pointnet2_forward": (_I, [ctypes.POINTER(PointNet2Weights), _P, _P, _P, _SZ, _I, _I, _P]),
     "iq_profile_enable": (_I, [_I]),
     "iq_set_tuning": (_I, [_I, _I]),
     "iq_debug_chain_occupancy": (_I, []),

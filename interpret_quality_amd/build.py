@@ -15,6 +15,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libiq_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "iq.h")
 ARCH = "gfx950"
+# Index-valued kernels (FPS, ball query, region assignment) need individually rounded operations:
+# hipcc's default -ffp-contract=fast fuses a*b+c into fma even through the __f*_rn intrinsics.
+NO_CONTRACT = ("iq_geom.hip", "iq_pointnet2.hip")
 
 
 def sources():
@@ -45,6 +48,8 @@ def build(force=False, verbose=True, extra_flags=()):
         if force or not newer:
             cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
                    "-Wall", "-Wno-unused-function"] + list(extra_flags)
+            if os.path.basename(src) in NO_CONTRACT:
+                cmd.append("-ffp-contract=off")
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

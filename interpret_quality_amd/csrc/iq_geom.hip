@@ -4,6 +4,11 @@
 // operations (__fmul_rn/__fadd_rn: no FMA contraction) in the order the reference's PyTorch
 // expressions evaluate them; ties resolve to the lowest index like the CPU argmin/argmax.
 #include "iq_common.h"
+#include "iq_mfma.h"
+
+// Index-valued results depend on individually rounded operations: forbid the compiler from fusing
+// a*b+c into an fma anywhere in this file (explicit fmaf / MFMA calls are unaffected).
+#pragma clang fp contract(off)
 
 namespace {
 
@@ -49,8 +54,12 @@ __device__ inline void argmax_combine(float& v, int& i, float ov, int oi) {
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
 
+// n_unique (optional): number of sampled points before the running max distance reaches 0, i.e.
+// before every remaining point coincides with an already sampled one; from then on arg-max returns
+// index 0 forever (CPU tie rule), so the loop stops and the tail is filled with 0.
 __global__ __launch_bounds__(kFpsThreads) void fps_kernel(const float* __restrict__ xyz,
-                                                          int32_t* __restrict__ idx, int N, int S) {
+                                                          int32_t* __restrict__ idx,
+                                                          int32_t* __restrict__ n_unique, int N, int S) {
     extern __shared__ float lds[];
     float* px = lds;           // N
     float* py = px + N;        // N
@@ -96,10 +105,17 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(const float* __restric
             float v = wv[0];
             int i = wi[0];
             for (int w = 1; w < kFpsThreads / 64; ++w) argmax_combine(v, i, wv[w], wi[w]);
-            far_s = i;
+            far_s = (v == 0.f) ? -1 - it : i;  // negative = exhausted after `it + 1` samples
         }
         __syncthreads();
+        if (far_s < 0) {
+            const int done = it + 1;
+            for (int j = done + threadIdx.x; j < S; j += kFpsThreads) idx[(size_t)blockIdx.x * S + j] = 0;
+            if (threadIdx.x == 0 && n_unique) n_unique[blockIdx.x] = done;
+            return;
+        }
     }
+    if (threadIdx.x == 0 && n_unique) n_unique[blockIdx.x] = S;
 }
 
 }  // namespace
@@ -113,11 +129,15 @@ extern "C" int iq_region_assign(const float* cloud, const int32_t* fps_idx, int3
     return iq::check_launch("region_assign_kernel");
 }
 
-extern "C" int iq_fps(const float* xyz, int32_t* idx, int B, int N, int S, iq_stream_t stream) {
+int iq::launch_fps(const float* xyz, int32_t* idx, int32_t* n_unique, int B, int N, int S, hipStream_t st) {
     IQ_REQUIRE(B >= 0 && N > 0 && N <= 8192 && S >= 1, "iq_fps: B=%d N=%d S=%d", B, N, S);
     if (B == 0) return IQ_OK;
     IQ_REQUIRE(xyz && idx, "iq_fps: null pointer");
     const size_t lds = (size_t)N * 4 * sizeof(float);
-    hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(kFpsThreads), lds, iq::as_stream(stream), xyz, idx, N, S);
+    hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(kFpsThreads), lds, st, xyz, idx, n_unique, N, S);
     return iq::check_launch("fps_kernel");
+}
+
+extern "C" int iq_fps(const float* xyz, int32_t* idx, int B, int N, int S, iq_stream_t stream) {
+    return iq::launch_fps(xyz, idx, nullptr, B, N, S, iq::as_stream(stream));
 }

@@ -1,0 +1,50 @@
+// fp32 MFMA building blocks shared by the model kernels (gfx950, v_mfma_f32_32x32x2_f32).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/iq.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// A fragment for K-block kb (8 k values): lane (row = l&31, h = l>>5) holds k = 8kb + 4h + j in
+// element j; MFMA step j consumes element j of A and B.  abase = act + (lane&31)*LD + 4*(lane>>5)
+// for a row-major activation image whose row stride LD is padded by 4 floats (conflict-free
+// ds_read_b128: a 16-lane group reads 16 rows at bank offsets 4*row mod 64).
+template <int LD>
+__device__ __forceinline__ f32x4 lds_frag(const float* abase, int mt, int kb) {
+    return *reinterpret_cast<const f32x4*>(abase + mt * 32 * LD + 8 * kb);
+}
+
+// B fragment from the packed weight image (iq_pack_weight): ((nt*KB + kb)*64 + lane)*4.
+__device__ __forceinline__ f32x4 glb_b(const float* wp, int lane) {
+    return *reinterpret_cast<const f32x4*>(wp + lane * 4);
+}
+
+__device__ __forceinline__ f32x16 mfma4(f32x4 a, f32x4 b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+}
+
+__device__ __forceinline__ float max16(f32x16 c) {
+    float m0 = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
+    float m1 = fmaxf(fmaxf(c[4], c[5]), fmaxf(c[6], c[7]));
+    float m2 = fmaxf(fmaxf(c[8], c[9]), fmaxf(c[10], c[11]));
+    float m3 = fmaxf(fmaxf(c[12], c[13]), fmaxf(c[14], c[15]));
+    return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+}
+
+// C/D layout of the 32x32 MFMA: col = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5).
+__device__ __forceinline__ constexpr int c_row_i(int i) { return (i & 3) + 8 * (i >> 2); }
+__device__ __forceinline__ int c_row(int i, int lane) { return c_row_i(i) + 4 * (lane >> 5); }
+
+namespace iq {
+// Batched dense layer out = act(A W^T + b) on packed weights (iq_pointnet.hip).
+int launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,
+                  hipStream_t st);
+// Farthest point sampling (iq_geom.hip); n_unique may be null.
+int launch_fps(const float* xyz, int32_t* idx, int32_t* n_unique, int B, int N, int S, hipStream_t st);
+}  // namespace iq

@@ -68,10 +68,12 @@ def shapley_logits(model, data, lbl, region_id, orders, args, center=None):
                                       keep, None, num_regions=r)
     bs = args.shapley_batch_size
     chunks = []
+    points_api = hasattr(model, "forward_points")  # consumes (B,N,3) directly: no transpose
     for i in range(0, len(orders), bs):
         o = hip_ops.as_i32(np.asarray(orders[i:i + bs]), dev)
-        x = hip_ops.mask_shapley(data[0].contiguous(), rid, o, center.reshape(3).contiguous(), channel_first=True)
-        chunks.append(model(x))
+        x = hip_ops.mask_shapley(data[0].contiguous(), rid, o, center.reshape(3).contiguous(),
+                                 channel_first=not points_api)
+        chunks.append(model.forward_points(x) if points_api else model(x))
     return torch.cat(chunks, dim=0)
 
 

@@ -123,13 +123,17 @@ def load_model(args):
     """tools/final_util.py:236-262: build the module, load the `.t7` state dict (stripping the
     DataParallel ``module.`` prefix), eval mode.  ``args.synthetic`` (additive flag of the drop-in
     scripts) substitutes the deterministic synthetic weights when no checkpoint exists offline."""
-    if args.model != "pointnet":
-        raise IqError("model %r is not on the HIP path yet (PointNet is; see DESIGN.md 'next')" % args.model)
-    from .pointnet import PointNetCls
-    model = PointNetCls(args).to(args.device)
+    from . import synth
+    if args.model == "pointnet":
+        from .pointnet import PointNetCls
+        model, synth_sd = PointNetCls(args).to(args.device), synth.pointnet_state_dict
+    elif args.model == "pointnet2":
+        from .pointnet2 import PointNet2ClsMsg
+        model, synth_sd = PointNet2ClsMsg(args).to(args.device), synth.pointnet2_state_dict
+    else:
+        raise IqError("model %r is not on the HIP path yet (see DESIGN.md 'next')" % args.model)
     if getattr(args, "synthetic", False) and not os.path.exists(args.model_path):
-        from . import synth
-        state_dict = synth.to_torch(synth.pointnet_state_dict(0))
+        state_dict = synth.to_torch(synth_sd(0))
     else:
         state_dict = torch.load(args.model_path, map_location=args.device)
     new_state_dict = OrderedDict()

@@ -140,3 +140,14 @@ def fps(xyz, npoint):
     out = torch.empty((b, npoint), dtype=torch.int32, device=xyz.device)
     _lib.check(lib.iq_fps(_dev(xyz, torch.float32, "xyz"), _p(out), b, n, npoint, _stream()), "iq_fps")
     return out
+
+
+def ball_query(xyz, new_xyz, radius, nsample):
+    """xyz (B,N,3), new_xyz (B,S,3) f32 -> (B,S,nsample) i32 (models/pointnet2.py:70-91)."""
+    lib = _lib.load()
+    b, n, _ = xyz.shape
+    s = new_xyz.shape[1]
+    out = torch.empty((b, s, nsample), dtype=torch.int32, device=xyz.device)
+    _lib.check(lib.iq_ball_query(_dev(xyz, torch.float32, "xyz"), _dev(new_xyz, torch.float32, "new_xyz"),
+                                 ctypes.c_float(radius), nsample, _p(out), b, n, s, _stream()), "iq_ball_query")
+    return out

@@ -1,0 +1,175 @@
+"""PointNet++ MSG classifier on the HIP path.
+
+Host-side mirror of models/pointnet2.py:244-276 (PointNet2ClsMsg): same constructor argument, same
+``state_dict`` keys (163 tensors), same call ``model(xyz: (B,3,N)) -> logits (B,10)``.  The torch
+modules only hold parameters; FPS, ball query, grouping, the shared MLPs and the pooling run in
+libiq_hip.so (csrc/iq_pointnet2.hip, iq_geom.hip).
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .pointnet import BN_EPS, _np
+
+SA1 = dict(npoint=512, radius=[0.1, 0.2, 0.4], nsample=[16, 32, 128], in_channel=0,
+           mlp=[[32, 32, 64], [64, 64, 128], [64, 96, 128]])                         # models/pointnet2.py:253
+SA2 = dict(npoint=128, radius=[0.2, 0.4, 0.8], nsample=[32, 64, 128], in_channel=320,
+           mlp=[[64, 64, 128], [128, 128, 256], [128, 128, 256]])                    # :254
+SA3_MLP = [256, 512, 1024]                                                           # :255
+
+
+def fold_conv_bn(sd, conv, bn):
+    w = _np(sd[conv + ".weight"])
+    w = w.reshape(w.shape[0], -1)
+    b = _np(sd[conv + ".bias"])
+    if bn is not None:
+        s = _np(sd[bn + ".weight"]) / np.sqrt(_np(sd[bn + ".running_var"]) + BN_EPS)
+        w = w * s[:, None]
+        b = (b - _np(sd[bn + ".running_mean"])) * s + _np(sd[bn + ".bias"])
+    return w, b  # float64
+
+
+class PackedWeights2:
+    def __init__(self, sd, device):
+        lib = _lib.load()
+        self._keep = []
+        self.struct = _lib.PointNet2Weights()
+
+        def dev(arr):
+            t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device)
+            self._keep.append(t)
+            return t
+
+        def dense(w, b):
+            cout, cin = w.shape
+            w32 = np.ascontiguousarray(w, dtype=np.float32)
+            out = np.empty(lib.iq_packed_floats(cout, cin), dtype=np.float32)
+            _lib.check(lib.iq_pack_weight(w32.ctypes.data, out.ctypes.data, cout, cin), "iq_pack_weight")
+            bp = np.zeros(lib.iq_padded_cout(cout), dtype=np.float32)
+            bp[:cout] = b
+            wt, bt = dev(out), dev(bp)
+            return _lib.DenseLayer(wt.data_ptr(), bt.data_ptr(), cin, cout)
+
+        def scale(dst, sa, i, cfg, feat_in):
+            w0, b0 = fold_conv_bn(sd, "%s.conv_blocks.%d.0" % (sa, i), "%s.bn_blocks.%d.0" % (sa, i))
+            wx = w0[:, feat_in:feat_in + 3]                       # relative xyz comes LAST (models/pointnet2.py:226)
+            bias = b0 if feat_in == 0 else np.zeros_like(b0)      # with features the bias travels in U
+            dst.w1x = dev(np.concatenate([wx, bias[:, None]], axis=1)).data_ptr()
+            dst.l2 = dense(*fold_conv_bn(sd, "%s.conv_blocks.%d.1" % (sa, i), "%s.bn_blocks.%d.1" % (sa, i)))
+            dst.l3 = dense(*fold_conv_bn(sd, "%s.conv_blocks.%d.2" % (sa, i), "%s.bn_blocks.%d.2" % (sa, i)))
+            dst.radius = cfg["radius"][i]
+            dst.nsample = cfg["nsample"][i]
+            return w0[:, :feat_in], b0
+
+        for i in range(3):
+            scale(self.struct.sa1[i], "sa1", i, SA1, 0)
+        uw, ub = [], []
+        for i in range(3):
+            wf, b0 = scale(self.struct.sa2[i], "sa2", i, SA2, 320)
+            uw.append(wf)
+            ub.append(b0)
+        self.struct.sa2_u = dense(np.concatenate(uw, axis=0), np.concatenate(ub, axis=0))
+        w, b = fold_conv_bn(sd, "sa3.mlp_convs.0", "sa3.mlp_bns.0")   # input = [xyz, features] (xyz FIRST, :132-135)
+        wpad = np.zeros((w.shape[0], 648))
+        wpad[:, :643] = w
+        self.struct.sa3_l1 = dense(wpad, b)
+        self.struct.sa3_l2 = dense(*fold_conv_bn(sd, "sa3.mlp_convs.1", "sa3.mlp_bns.1"))
+        self.struct.sa3_l3 = dense(*fold_conv_bn(sd, "sa3.mlp_convs.2", "sa3.mlp_bns.2"))
+        self.struct.fc1 = dense(*fold_conv_bn(sd, "fc1", "bn1"))
+        self.struct.fc2 = dense(*fold_conv_bn(sd, "fc2", "bn2"))
+        self.struct.fc3 = dense(*fold_conv_bn(sd, "fc3", None))
+        self.num_classes = int(sd["fc3.weight"].shape[0])
+
+
+class PointNet2Engine:
+    def __init__(self, state_dict, device):
+        if torch.device(device).type != "cuda":
+            raise _lib.IqError("PointNet2Engine needs a GPU device (no CPU fallback)")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.weights = PackedWeights2(state_dict, self.device)
+        self._ws = None
+
+    def forward_points(self, xyz):
+        """xyz (B,N,3) contiguous float32 on the GPU -> logits (B,10)."""
+        if not xyz.is_cuda or xyz.dtype != torch.float32 or not xyz.is_contiguous():
+            raise _lib.IqError("xyz must be a contiguous float32 GPU tensor (B,N,3)")
+        b, n, _ = xyz.shape
+        need = self.lib.iq_pointnet2_workspace_bytes(b)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        logits = torch.empty((b, self.weights.num_classes), dtype=torch.float32, device=self.device)
+        rc = self.lib.iq_pointnet2_forward(ctypes.byref(self.weights.struct), ctypes.c_void_p(xyz.data_ptr()),
+                                           ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(self._ws.data_ptr()),
+                                           self._ws.numel(), b, n, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "iq_pointnet2_forward")
+        return logits
+
+
+def _holder_msg(cfg):
+    m = nn.Module()
+    m.conv_blocks, m.bn_blocks = nn.ModuleList(), nn.ModuleList()
+    for mlp in cfg["mlp"]:
+        convs, bns = nn.ModuleList(), nn.ModuleList()
+        last = cfg["in_channel"] + 3
+        for c in mlp:
+            convs.append(nn.Conv2d(last, c, 1))
+            bns.append(nn.BatchNorm2d(c))
+            last = c
+        m.conv_blocks.append(convs)
+        m.bn_blocks.append(bns)
+    return m
+
+
+class PointNet2ClsMsg(nn.Module):
+    """Parameter container with the reference's state-dict layout; forward runs on the HIP path."""
+
+    max_clouds_per_call = 2048  # bounds the workspace (2.9 MB per cloud)
+
+    def __init__(self, args=None):
+        super().__init__()
+        self.args = args
+        self.output_channels = 40 if getattr(args, "dataset", "modelnet10") == "modelnet40" else 10
+        self.sa1, self.sa2 = _holder_msg(SA1), _holder_msg(SA2)
+        sa3 = nn.Module()
+        sa3.mlp_convs, sa3.mlp_bns = nn.ModuleList(), nn.ModuleList()
+        last = 640 + 3
+        for c in SA3_MLP:
+            sa3.mlp_convs.append(nn.Conv2d(last, c, 1))
+            sa3.mlp_bns.append(nn.BatchNorm2d(c))
+            last = c
+        self.sa3 = sa3
+        self.fc1, self.bn1 = nn.Linear(1024, 512), nn.BatchNorm1d(512)
+        self.fc2, self.bn2 = nn.Linear(512, 256), nn.BatchNorm1d(256)
+        self.fc3 = nn.Linear(256, self.output_channels)
+        self._engine = None
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def engine(self):
+        if self.training:
+            raise _lib.IqError("the HIP PointNet++ path implements eval mode only")
+        if self._engine is None:
+            self._engine = PointNet2Engine(self.state_dict(), self.fc3.weight.device)
+        return self._engine
+
+    def forward_points(self, xyz):
+        """(B,N,3) channel-last clouds (what the mask kernel writes) -> logits."""
+        eng = self.engine()
+        step = self.max_clouds_per_call
+        if xyz.shape[0] <= step:
+            return eng.forward_points(xyz)
+        return torch.cat([eng.forward_points(xyz[i:i + step].contiguous()) for i in range(0, xyz.shape[0], step)], dim=0)
+
+    def forward(self, xyz):
+        """xyz (B,3,N) as in the reference -> logits (B,10)."""
+        return self.forward_points(xyz.permute(0, 2, 1).contiguous())

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Coalitions/s of the Shapley path for the models that consume materialised masked clouds
+(BASELINE.json configs[2..]: PointNet++ ...).  Not the headline bench (bench.py); used for tuning and
+for the numbers quoted in DESIGN.md.
+
+    python tools/bench_models.py --model pointnet2 [--perms 100] [--batch 10] [--steps 5]
+"""
+import argparse
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from interpret_quality_amd import _lib, final_common, hip_ops, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="pointnet2")
+ap.add_argument("--perms", type=int, default=100)
+ap.add_argument("--batch", type=int, default=20, help="permutations per forward batch (config.py knob)")
+ap.add_argument("--regions", type=int, default=32)
+ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+if a.model == "pointnet2":
+    from interpret_quality_amd.pointnet2 import PointNet2ClsMsg
+    model = PointNet2ClsMsg(None)
+    model.load_state_dict(synth.to_torch(synth.pointnet2_state_dict(0)))
+else:
+    raise SystemExit("unknown model")
+model = model.to(dev).eval()
+pts, label = synth.make_cloud(0)
+data = torch.from_numpy(pts).unsqueeze(0).to(dev)
+lbl = torch.tensor([label], device=dev)
+R, S = a.regions, a.perms
+region_id = hip_ops.region_assign(data[0].contiguous(), hip_ops.fps(data, R)[0].contiguous()).cpu().numpy()
+orders = synth.make_orders(S, R, seed=1)
+args = argparse.Namespace(model=a.model, softmax_type="modified", num_points=1024, num_regions=R, num_samples=S,
+                          shapley_batch_size=a.batch, verbose=False)
+
+
+def read(slot):
+    ms, n = ctypes.c_double(0), ctypes.c_int(0)
+    lib.iq_profile_read(slot, ctypes.byref(ms), ctypes.byref(n))
+    return ms.value
+
+
+final_common.shap_sampling_all_regions_batch(model, data, lbl, region_id, orders, args)
+torch.cuda.synchronize()
+lib.iq_profile_enable(1)
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    phi, logits = final_common.shap_sampling_all_regions_batch(model, data, lbl, region_id, orders, args)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+lib.iq_profile_enable(0)
+n = S * (R + 1) * a.steps
+sa1, sa2, sa3, call = read(0), read(1), read(2), read(3)
+print("%s: %d coalitions in %.3f s = %.0f coalitions/s | per step: sa1 groups %.1f ms, sa2 groups %.1f ms, sa3 %.1f ms, "
+      "whole forward calls %.1f ms of %.1f ms" % (a.model, n, dt, n / dt, sa1 / a.steps, sa2 / a.steps, sa3 / a.steps,
+                                                   call / a.steps, dt / a.steps * 1e3))
