@@ -41,6 +41,43 @@ __device__ __forceinline__ float max16(f32x16 c) {
 __device__ __forceinline__ constexpr int c_row_i(int i) { return (i & 3) + 8 * (i >> 2); }
 __device__ __forceinline__ int c_row(int i, int lane) { return c_row_i(i) + 4 * (lane >> 5); }
 
+// ---- software-pipelined n-tile: B fragments in a 4-deep register ring, A fragments one K-block ahead ----
+// The ring runs 4 K-blocks ahead of the MFMAs and rolls into the next tile's weights (wnext), so only
+// the very first tile of a sequence pays a load latency (prime it before the barrier that precedes
+// its use).  KB must be a multiple of 4.  sched_group_barrier pins the issue order inside a K-block.
+struct WRing {
+    f32x4 r[4];
+};
+
+__device__ __forceinline__ void wring_prime(WRing& w, const float* wq, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w.r[i] = glb_b(wq + i * 256, lane);
+}
+
+template <int LD, int KB, int MTS>
+__device__ __forceinline__ void mfma_ntile(const float* abase, const float* wcur, const float* wnext, int lane,
+                                           WRing& ring, f32x16& acc0, f32x16& acc1) {
+    static_assert(KB % 4 == 0, "KB must be a multiple of 4");
+    f32x4 a0n = lds_frag<LD>(abase, 0, 0), a1n = a0n;
+    if (MTS == 2) a1n = lds_frag<LD>(abase, 1, 0);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const f32x4 a0 = a0n, a1 = a1n;
+        if (kb + 1 < KB) {
+            a0n = lds_frag<LD>(abase, 0, kb + 1);
+            if (MTS == 2) a1n = lds_frag<LD>(abase, 1, kb + 1);
+        }
+        const f32x4 bk = ring.r[kb & 3];
+        acc0 = mfma4(a0, bk, acc0);
+        if (MTS == 2) acc1 = mfma4(a1, bk, acc1);
+        ring.r[kb & 3] = glb_b(kb + 4 < KB ? wcur + (kb + 4) * 256 : wnext + (kb + 4 - KB) * 256, lane);
+        if (kb + 1 < KB) __builtin_amdgcn_sched_group_barrier(0x100, MTS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MTS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 namespace iq {
 // Batched dense layer out = act(A W^T + b) on packed weights (iq_pointnet.hip).
 int launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,

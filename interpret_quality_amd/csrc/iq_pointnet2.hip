@@ -10,6 +10,11 @@
 //     grouped kernel gathers U rows and adds the 3-term xyz part.  16-128x fewer MACs for that layer.
 //   * duplicate centroids: once FPS has exhausted the distinct locations it returns index 0 forever
 //     (iq_geom.hip), so groups s >= n_unique are copies of group 0 and are filled, not recomputed.
+//   * padded members: a ball usually holds far fewer than K points (K = 128 at r = 0.4 sees ~65 of 1024
+//     points) and the reference pads the list with copies of the first hit.  Copies cannot change a
+//     max, so every group is processed as ceil(count/16) blocks of 16 rows instead of K rows; the
+//     blocks of a cloud are compacted (pn2_blocks_kernel) and each block's column max is merged into
+//     the group's output with an integer atomicMax (post-ReLU values are >= 0, so float order = int order).
 // Grouped kernel: 64-row chunks -> LDS act1 -> MFMA C1->C2 -> LDS act2 -> MFMA C2->C3 -> group max in
 // registers.  Index-valued steps (ball query) use explicitly rounded arithmetic in the reference's
 // evaluation order.
@@ -48,6 +53,11 @@ struct BallArgs {
     float r2[3];
     int K[3];
     void* idx[3];          // (B,S,K) each
+    int32_t* cnt[3];       // (B,S) number of true hits per list (optional)
+    const int32_t* n_eff;  // (B) optional: only points p < n_eff[b] are candidates.  Used for sa2, whose
+                           // 512 input points end with copies of point 0 once FPS has run out of distinct
+                           // locations: the copies come last in index order and equal a point that is
+                           // already a member whenever they are in range, so they never add a new row.
 };
 
 template <typename IdxT>
@@ -72,7 +82,8 @@ __global__ __launch_bounds__(kThreads) void ball_query_kernel(BallArgs a) {
 #pragma unroll
     for (int q = 0; q < 3; ++q)
         out[q] = q < a.nr ? reinterpret_cast<IdxT*>(a.idx[q]) + ((size_t)b * a.S + (live ? s : 0)) * a.K[q] : nullptr;
-    for (int p = 0; p < a.N; ++p) {
+    const int n_eff = a.n_eff ? min(a.N, a.n_eff[b]) : a.N;
+    for (int p = 0; p < n_eff; ++p) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(pts + p * 4);
         float dot = __fmul_rn(cx, v[0]);
         dot = __fmaf_rn(cy, v[1], dot);
@@ -96,93 +107,181 @@ __global__ __launch_bounds__(kThreads) void ball_query_kernel(BallArgs a) {
     for (int q = 0; q < 3; ++q) {
         if (q >= a.nr) continue;
         for (int j = cnt[q]; j < a.K[q]; ++j) out[q][j] = first[q];  // pad with the first hit (:88-90)
+        if (a.cnt[q]) a.cnt[q][(size_t)b * a.S + s] = cnt[q];
     }
 }
 
-// ---- grouped MLP + max ----------------------------------------------------------------------------
+// ---- block table: group g of cloud b owns ceil(cnt/16) blocks of 16 rows (0 if g >= n_unique) -------
+constexpr int kBlk = 16;
+
+__global__ __launch_bounds__(kThreads) void pn2_blocks_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ n_unique,
+                                                              int32_t* __restrict__ block_start /*(B,S+1)*/,
+                                                              uint16_t* __restrict__ blockmap /*(B,maxblocks)*/, int S,
+                                                              int maxblocks) {
+    __shared__ int part[kThreads];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int nu = n_unique ? n_unique[b] : S;
+    const int per = (S + kThreads - 1) / kThreads;  // groups per thread, contiguous
+    int nb[4];
+    int sum = 0;
+    for (int i = 0; i < per; ++i) {
+        const int g = t * per + i;
+        nb[i] = (g < S && g < nu) ? (cnt[(size_t)b * S + g] + kBlk - 1) / kBlk : 0;
+        sum += nb[i];
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < kThreads; off <<= 1) {  // Hillis-Steele inclusive scan
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - sum;
+    for (int i = 0; i < per; ++i) {
+        const int g = t * per + i;
+        if (g < S) {
+            block_start[(size_t)b * (S + 1) + g] = run;
+            for (int j = 0; j < nb[i]; ++j) blockmap[(size_t)b * maxblocks + run + j] = (uint16_t)g;
+            run += nb[i];
+        }
+    }
+    if (t == kThreads - 1) block_start[(size_t)b * (S + 1) + S] = part[t];
+}
+
+// ---- grouped MLP + max over ragged 16-row blocks ------------------------------------------------------
 struct GroupArgs {
     const float* xyz;        // (B,N,ldx) member coordinates (first 3 floats of each row)
     int ldx;
     const float* new_xyz;    // (B,S,ldc) centroids
     int ldc;
     const int16_t* idx;      // (B,S,K)
+    const int32_t* cnt;      // (B,S) true hits
+    const int32_t* block_start;  // (B,S+1)
+    const uint16_t* blockmap;    // (B,maxblocks)
+    int maxblocks;
     const float* U;          // (B,N,ldu) per-point part of layer 1 (bias included) or null
     int ldu;
     const float* w1x;        // [C1][4] = (wx0, wx1, wx2, bias)
     const float* w2; const float* b2;  // packed C1->C2
     const float* w3; const float* b3;  // packed C2->C3
-    float* out;              // (B,S,ldo) at the scale's column offset
+    float* out;              // (B,S,ldo) at the scale's column offset, zero-initialised
     int ldo;
-    const int32_t* n_unique; // (B) or null
-    int N, S, K, groups_per_wg;
+    int N, S, K, blocks_per_wg;
 };
+
+__device__ __forceinline__ void merge_max(float* addr, float v) {
+    atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));  // v >= +0: float order == int order
+}
+
+__device__ __forceinline__ float max8(f32x16 c, int half) {
+    return half == 0 ? fmaxf(fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])), fmaxf(fmaxf(c[4], c[5]), fmaxf(c[6], c[7])))
+                     : fmaxf(fmaxf(fmaxf(c[8], c[9]), fmaxf(c[10], c[11])), fmaxf(fmaxf(c[12], c[13]), fmaxf(c[14], c[15])));
+}
+
+// column max of the two 16-row halves of a 32x32 accumulator tile -> the groups that own them
+__device__ __forceinline__ void emit_tile(f32x16 acc, float bias, int g_lo, int g_hi, float* orow, int ldo, int fh) {
+    float lo = max8(acc, 0), hi = max8(acc, 1);   // rows 0-15 live in registers 0-7, rows 16-31 in 8-15
+    lo = fmaxf(lo, __shfl_xor(lo, 32));
+    hi = fmaxf(hi, __shfl_xor(hi, 32));
+    if (fh != 0) return;
+    lo = fmaxf(lo + bias, 0.f);
+    hi = fmaxf(hi + bias, 0.f);
+    if (g_lo == g_hi) {
+        if (g_lo >= 0) merge_max(orow + (size_t)g_lo * ldo, fmaxf(lo, hi));
+    } else {
+        if (g_lo >= 0) merge_max(orow + (size_t)g_lo * ldo, lo);
+        if (g_hi >= 0) merge_max(orow + (size_t)g_hi * ldo, hi);
+    }
+}
 
 template <int C1, int C2, int C3>
 __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
     constexpr int LD1 = C1 + 4, LD2 = C2 + 4;
     constexpr int KB1 = C1 / 8, KB2 = C2 / 8, NT2 = C2 / 32, NT3 = C3 / 32;
-    constexpr int NQ3 = NT3 >= 4 ? NT3 / 4 : 1;
     __shared__ __attribute__((aligned(16))) float act1[kMC * LD1];
     __shared__ __attribute__((aligned(16))) float act2[kMC * LD2];
-    __shared__ __attribute__((aligned(16))) float rel[kMC * 4];  // dx,dy,dz, member index (bits)
+    __shared__ __attribute__((aligned(16))) float rel[2 * kMC * 4];  // dx,dy,dz, member index (bits); double-buffered
+    __shared__ int blk_group[2 * (kMC / kBlk)];                      // owner group of a chunk's 4 blocks (-1 = none)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const int K = a.K;
-    const int g0 = blockIdx.x * a.groups_per_wg;
-    const int gend_all = min(a.S, g0 + a.groups_per_wg);
-    const int gend = a.n_unique ? min(gend_all, a.n_unique[b]) : gend_all;  // computed groups
-    if (g0 >= gend) return;
-    const int rows_total = (gend - g0) * K;
-    const int nchunks = (rows_total + kMC - 1) / kMC;
+    const int32_t* bstart = a.block_start + (size_t)b * (a.S + 1);
+    const int nblocks = bstart[a.S];
+    const int j0 = blockIdx.x * a.blocks_per_wg;
+    if (j0 >= nblocks) return;
+    const int jend = min(nblocks, j0 + a.blocks_per_wg);
+    const int nchunks = (jend - j0 + (kMC / kBlk) - 1) / (kMC / kBlk);
+    const uint16_t* bmap = a.blockmap + (size_t)b * a.maxblocks;
 
     const int fl = lane & 31, fh = lane >> 5;
     const float* a1base = act1 + fl * LD1 + 4 * fh;
     const float* a2base = act2 + fl * LD2 + 4 * fh;
     float* c2base = act2 + (4 * fh) * LD2 + fl;
-    float runmax[NQ3];
-#pragma unroll
-    for (int q = 0; q < NQ3; ++q) runmax[q] = -INFINITY;
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int row0 = ch * kMC;
-        // ---- stage 0a: member -> relative coordinates (x_p - c, rounded like the reference's `-=`) --
+    // Stage 0a (member -> relative coordinates) of chunk c+1 runs before the barrier that precedes L3
+    // of chunk c, and the per-point layer-1 rows U[p] of chunk c+1 are requested right after that
+    // barrier, so the gather latency hides behind the L3 MFMAs.  rel / blk_group are double-buffered.
+    constexpr int NR = kMC * C1 / kThreads;  // rows per thread in stage 0b
+    const int chn = tid % C1, rsub = tid / C1;
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.w1x + chn * 4);
+    float ureg[NR];
+    auto stage0a = [&](int ch, int buf) {
         if (tid < kMC) {
-            int rr = row0 + tid;
-            if (rr >= rows_total) rr = rows_total - 1;  // padding rows replicate a valid row
-            const int g = g0 + rr / K, k = rr - (rr / K) * K;
-            const int p = a.idx[((size_t)b * a.S + g) * K + k];
+            int j = j0 + ch * (kMC / kBlk) + tid / kBlk;
+            const bool live = j < jend;
+            if (!live) j = jend - 1;                 // padding blocks replicate a valid one (never emitted)
+            const int g = bmap[j];
+            int m = (j - bstart[g]) * kBlk + (tid % kBlk);
+            if (m >= a.cnt[(size_t)b * a.S + g]) m = 0;  // tail of the last block: copies of the first hit
+            const int p = a.idx[((size_t)b * a.S + g) * K + m];
             const float* x = a.xyz + ((size_t)b * a.N + p) * a.ldx;
             const float* c = a.new_xyz + ((size_t)b * a.S + g) * a.ldc;
             f32x4 v;
-            v[0] = __fsub_rn(x[0], c[0]); v[1] = __fsub_rn(x[1], c[1]); v[2] = __fsub_rn(x[2], c[2]);
+            v[0] = x[0] - c[0]; v[1] = x[1] - c[1]; v[2] = x[2] - c[2];  // rounded like the reference's `-=`
             v[3] = __int_as_float(p);
-            *reinterpret_cast<f32x4*>(rel + tid * 4) = v;
+            *reinterpret_cast<f32x4*>(rel + (buf * kMC + tid) * 4) = v;
+            if (tid % kBlk == 0) blk_group[buf * (kMC / kBlk) + tid / kBlk] = live ? g : -1;
         }
-        __syncthreads();  // also: previous chunk's readers of act1/act2 are done
+    };
+    auto gather_u = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = rsub + i * (kThreads / C1);
+            const int p = __float_as_int(rel[(buf * kMC + r) * 4 + 3]);
+            ureg[i] = a.U ? a.U[((size_t)b * a.N + p) * a.ldu + chn] : 0.f;
+        }
+    };
+    stage0a(0, 0);
+    __syncthreads();
+    gather_u(0);
+
+    WRing ring2, ring3;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cur = ch & 1, nxt = cur ^ 1;
+        const int mts = (jend - (j0 + ch * (kMC / kBlk))) > 2 ? 2 : 1;  // second m-tile holds live blocks?
+        const int ga = blk_group[cur * 4], gb = blk_group[cur * 4 + 1], gc = blk_group[cur * 4 + 2], gd = blk_group[cur * 4 + 3];
+        if (NT2 >= 4) wring_prime(ring2, a.w2 + (size_t)wave * KB1 * 256, lane);  // in flight across stage 0b
         // ---- stage 0b: layer 1 -> act1 -------------------------------------------------------------
-        {
-            const int chn = tid % C1;
-            const f32x4 w = *reinterpret_cast<const f32x4*>(a.w1x + chn * 4);
-            for (int r = tid / C1; r < kMC; r += kThreads / C1) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(rel + r * 4);
-                float h = fmaf(w[2], v[2], fmaf(w[1], v[1], w[0] * v[0])) + w[3];
-                if (a.U) h += a.U[((size_t)b * a.N + __float_as_int(v[3])) * a.ldu + chn];
-                act1[r * LD1 + chn] = fmaxf(h, 0.f);
-            }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = rsub + i * (kThreads / C1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rel + (cur * kMC + r) * 4);
+            const float h = fmaf(w1[2], v[2], fmaf(w1[1], v[1], w1[0] * v[0])) + w1[3] + ureg[i];
+            act1[r * LD1 + chn] = fmaxf(h, 0.f);
         }
-        __syncthreads();
+        __syncthreads();  // act1 complete; every wave has finished L3 of the previous chunk (act2 is free)
         // ---- layer 2: C1 -> C2 (+bn, relu) -> act2 -------------------------------------------------
         if (NT2 >= 4) {
-            for (int nt = wave; nt < NT2; nt += 4) {
+#pragma unroll
+            for (int q = 0; q < NT2 / 4; ++q) {
+                const int nt = q * 4 + wave;
                 f32x16 acc0 = {0}, acc1 = {0};
                 const float* wq = a.w2 + (size_t)nt * KB1 * 256;
-#pragma unroll 4
-                for (int kb = 0; kb < KB1; ++kb) {
-                    const f32x4 bw = glb_b(wq + kb * 256, lane);
-                    acc0 = mfma4(lds_frag<LD1>(a1base, 0, kb), bw, acc0);
-                    acc1 = mfma4(lds_frag<LD1>(a1base, 1, kb), bw, acc1);
-                }
+                const float* wn = a.w2 + (size_t)(q + 1 < NT2 / 4 ? nt + 4 : nt) * KB1 * 256;
+                if (mts == 2) mfma_ntile<LD1, KB1, 2>(a1base, wq, wn, lane, ring2, acc0, acc1);
+                else          mfma_ntile<LD1, KB1, 1>(a1base, wq, wn, lane, ring2, acc0, acc1);
                 const float bias = a.b2[nt * 32 + fl];
                 float* dst = c2base + nt * 32;
 #pragma unroll
@@ -192,7 +291,7 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
                 }
             }
         } else {
-            for (int t = wave; t < 2 * NT2; t += 4) {
+            for (int t = wave; t < mts * NT2; t += 4) {
                 const int mt = t / NT2, nt = t - mt * NT2;
                 f32x16 acc = {0};
                 const float* wq = a.w2 + (size_t)nt * KB1 * 256;
@@ -205,46 +304,27 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
                 for (int i = 0; i < 16; ++i) dst[c_row_i(i) * LD2] = fmaxf(acc[i] + bias, 0.f);
             }
         }
-        __syncthreads();
-        // ---- layer 3: C2 -> C3 (+bn, relu), max over each group's K rows ---------------------------
+        if (NT3 >= 4) wring_prime(ring3, a.w3 + (size_t)wave * KB2 * 256, lane);  // in flight across the barrier
+        if (ch + 1 < nchunks) stage0a(ch + 1, nxt);
+        __syncthreads();  // act2 complete; rel[nxt] visible
+        if (ch + 1 < nchunks) gather_u(nxt);  // consumed after L3
+        // ---- layer 3: C2 -> C3 (+bn, relu), block maxima merged into the owning groups ---------------
         if (NT3 >= 4) {
 #pragma unroll
-            for (int q = 0; q < NQ3; ++q) {
+            for (int q = 0; q < NT3 / 4; ++q) {
                 const int nt = q * 4 + wave;
                 f32x16 acc0 = {0}, acc1 = {0};
                 const float* wq = a.w3 + (size_t)nt * KB2 * 256;
-#pragma unroll 4
-                for (int kb = 0; kb < KB2; ++kb) {
-                    const f32x4 bw = glb_b(wq + kb * 256, lane);
-                    acc0 = mfma4(lds_frag<LD2>(a2base, 0, kb), bw, acc0);
-                    acc1 = mfma4(lds_frag<LD2>(a2base, 1, kb), bw, acc1);
-                }
+                const float* wn = a.w3 + (size_t)(q + 1 < NT3 / 4 ? nt + 4 : nt) * KB2 * 256;
+                if (mts == 2) mfma_ntile<LD2, KB2, 2>(a2base, wq, wn, lane, ring3, acc0, acc1);
+                else          mfma_ntile<LD2, KB2, 1>(a2base, wq, wn, lane, ring3, acc0, acc1);
                 const float bias = a.b3[nt * 32 + fl];
                 float* orow = a.out + (size_t)b * a.S * a.ldo + nt * 32 + fl;
-                if (K >= 64) {
-                    // one group per chunk (K = 64) or per two chunks (K = 128)
-                    float m = fmaxf(max16(acc0), max16(acc1));
-                    m = fmaxf(m, __shfl_xor(m, 32));
-                    runmax[q] = fmaxf(runmax[q], m);
-                    const int rows_done = row0 + kMC;
-                    if (rows_done % K == 0 || ch == nchunks - 1) {
-                        const int g = g0 + (rows_done - 1) / K;
-                        if (g < gend && fh == 0) orow[(size_t)g * a.ldo] = fmaxf(runmax[q] + bias, 0.f);
-                        runmax[q] = -INFINITY;
-                    }
-                } else {  // K = 32: one group per m-tile
-                    float m0 = max16(acc0), m1 = max16(acc1);
-                    m0 = fmaxf(m0, __shfl_xor(m0, 32));
-                    m1 = fmaxf(m1, __shfl_xor(m1, 32));
-                    const int ga = g0 + row0 / 32;
-                    if (fh == 0) {
-                        if (ga < gend) orow[(size_t)ga * a.ldo] = fmaxf(m0 + bias, 0.f);
-                        if (ga + 1 < gend) orow[(size_t)(ga + 1) * a.ldo] = fmaxf(m1 + bias, 0.f);
-                    }
-                }
+                emit_tile(acc0, bias, ga, gb, orow, a.ldo, fh);
+                if (mts == 2) emit_tile(acc1, bias, gc, gd, orow, a.ldo, fh);
             }
-        } else {  // few n-tiles (C3 = 64): one (m-tile, n-tile) pair per wave; K is 16 or 32 here
-            for (int t = wave; t < 2 * NT3; t += 4) {
+        } else {
+            for (int t = wave; t < mts * NT3; t += 4) {
                 const int mt = t / NT3, nt = t - mt * NT3;
                 f32x16 acc = {0};
                 const float* wq = a.w3 + (size_t)nt * KB2 * 256;
@@ -253,27 +333,9 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
                     acc = mfma4(lds_frag<LD2>(a2base + mt * 32 * LD2, 0, kb), glb_b(wq + kb * 256, lane), acc);
                 const float bias = a.b3[nt * 32 + fl];
                 float* orow = a.out + (size_t)b * a.S * a.ldo + nt * 32 + fl;
-                if (K == 16) {  // rows 0-15 live in registers 0-7, rows 16-31 in registers 8-15
-                    float lo = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])),
-                                     fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7])));
-                    float hi = fmaxf(fmaxf(fmaxf(acc[8], acc[9]), fmaxf(acc[10], acc[11])),
-                                     fmaxf(fmaxf(acc[12], acc[13]), fmaxf(acc[14], acc[15])));
-                    lo = fmaxf(lo, __shfl_xor(lo, 32));
-                    hi = fmaxf(hi, __shfl_xor(hi, 32));
-                    const int ga = g0 + (row0 + mt * 32) / 16;
-                    if (fh == 0) {
-                        if (ga < gend) orow[(size_t)ga * a.ldo] = fmaxf(lo + bias, 0.f);
-                        if (ga + 1 < gend) orow[(size_t)(ga + 1) * a.ldo] = fmaxf(hi + bias, 0.f);
-                    }
-                } else {        // K = 32
-                    float m = max16(acc);
-                    m = fmaxf(m, __shfl_xor(m, 32));
-                    const int ga = g0 + (row0 + mt * 32) / 32;
-                    if (fh == 0 && ga < gend) orow[(size_t)ga * a.ldo] = fmaxf(m + bias, 0.f);
-                }
+                emit_tile(acc, bias, mt == 0 ? ga : gc, mt == 0 ? gb : gd, orow, a.ldo, fh);
             }
         }
-        // next chunk's first barrier (after stage 0a) orders these LDS reads before act1/act2 are rewritten
     }
 }
 
@@ -289,13 +351,6 @@ __global__ void fill_dup_rows_kernel(float* __restrict__ out, int ldo, int S, in
     for (int c = threadIdx.x; c < ncols; c += blockDim.x) dst[c] = src[c];
 }
 
-// zero the padding columns [c0, ld) of every row
-__global__ void zero_cols_kernel(float* __restrict__ buf, int ld, int c0, int rows) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    for (int c = c0; c < ld; ++c) buf[(size_t)r * ld + c] = 0.f;
-}
-
 // out[b][c] = max over the S rows of in[b][s][c]
 __global__ void colmax_kernel(const float* __restrict__ in, float* __restrict__ out, int S, int C) {
     const int b = blockIdx.y;
@@ -309,21 +364,25 @@ __global__ void colmax_kernel(const float* __restrict__ in, float* __restrict__ 
 
 template <int C1, int C2, int C3>
 int launch_group_t(const GroupArgs& a, int B, hipStream_t st) {
-    dim3 grid((a.S + a.groups_per_wg - 1) / a.groups_per_wg, B);
+    dim3 grid((a.maxblocks + a.blocks_per_wg - 1) / a.blocks_per_wg, B);  // workgroups past a cloud's block count exit
     hipLaunchKernelGGL((pn2_group_kernel<C1, C2, C3>), grid, dim3(kThreads), 0, st, a);
     return iq::check_launch("pn2_group_kernel");
 }
 
-int launch_group(const iq_pn2_scale& sc, GroupArgs a, int B, hipStream_t st) {
+int launch_group(const iq_pn2_scale& sc, GroupArgs a, const int32_t* n_unique, int B, hipStream_t st) {
     a.w1x = sc.w1x;
     a.w2 = sc.l2.w; a.b2 = sc.l2.b;
     a.w3 = sc.l3.w; a.b3 = sc.l3.b;
     a.K = sc.nsample;
-    // >= 512 rows per workgroup, whole groups
-    a.groups_per_wg = max(1, 512 / a.K);
+    a.blocks_per_wg = 32;  // 512 rows
+    a.maxblocks = a.S * ((a.K + kBlk - 1) / kBlk);
     const int c1 = sc.l2.cin, c2 = sc.l2.cout, c3 = sc.l3.cout;
     IQ_REQUIRE(sc.l3.cin == c2, "pointnet2 scale: layer sizes do not chain");
-    IQ_REQUIRE(a.K == 16 || a.K == 32 || a.K == 64 || a.K == 128, "pointnet2 scale: nsample %d unsupported", a.K);
+    IQ_REQUIRE(a.S <= 4 * kThreads, "pointnet2: S=%d too large for the block scan", a.S);
+    hipLaunchKernelGGL(pn2_blocks_kernel, dim3(B), dim3(kThreads), 0, st, a.cnt, n_unique, const_cast<int32_t*>(a.block_start),
+                       const_cast<uint16_t*>(a.blockmap), a.S, a.maxblocks);
+    int rc = iq::check_launch("pn2_blocks_kernel");
+    if (rc) return rc;
     if (c1 == 32 && c2 == 32 && c3 == 64) return launch_group_t<32, 32, 64>(a, B, st);
     if (c1 == 64 && c2 == 64 && c3 == 128) return launch_group_t<64, 64, 128>(a, B, st);
     if (c1 == 64 && c2 == 96 && c3 == 128) return launch_group_t<64, 96, 128>(a, B, st);
@@ -332,13 +391,15 @@ int launch_group(const iq_pn2_scale& sc, GroupArgs a, int B, hipStream_t st) {
 }
 
 int launch_ball(const float* xyz, const float* new_xyz, int ldc, const iq_pn2_scale* sc, int nr, int16_t* const* idx,
-                int B, int N, int S, hipStream_t st) {
+                int32_t* const* cnt, const int32_t* n_eff, int B, int N, int S, hipStream_t st) {
     BallArgs a{};
+    a.n_eff = n_eff;
     a.xyz = xyz; a.new_xyz = new_xyz; a.ldc = ldc; a.N = N; a.S = S; a.nr = nr;
     for (int q = 0; q < nr; ++q) {
         a.r2[q] = (float)((double)sc[q].radius * (double)sc[q].radius);  // python float r**2, cast by the comparison
         a.K[q] = sc[q].nsample;
         a.idx[q] = idx[q];
+        a.cnt[q] = cnt[q];
     }
     hipLaunchKernelGGL(ball_query_kernel<int16_t>, dim3((S + kThreads - 1) / kThreads, B), dim3(kThreads),
                        (size_t)N * 4 * sizeof(float), st, a);
@@ -349,6 +410,10 @@ struct Ws2 {
     int32_t *fps1, *nu1, *fps2, *nu2;
     float *nx1;            // (B,512,3)
     int16_t* idx1[3];      // (B,512,K)
+    int32_t* cnt1[3];      // (B,512)
+    int32_t* cnt2[3];      // (B,128)
+    int32_t* bstart;       // (B,513) block table of the scale being processed
+    uint16_t* bmap;        // (B,4096)
     float* l1;             // (B,512,320)
     float* U;              // (B,512,320)
     int16_t* idx2[3];      // (B,128,K)
@@ -371,6 +436,9 @@ Ws2 carve2(void* base, int B, const iq_pointnet2_weights* w) {
     s.fps2 = (int32_t*)take(b * 128 * 4); s.nu2 = (int32_t*)take(b * 4);
     s.nx1 = (float*)take(b * 512 * 3 * 4);
     for (int q = 0; q < 3; ++q) s.idx1[q] = (int16_t*)take(b * 512 * (w ? w->sa1[q].nsample : 128) * 2);
+    for (int q = 0; q < 3; ++q) { s.cnt1[q] = (int32_t*)take(b * 512 * 4); s.cnt2[q] = (int32_t*)take(b * 128 * 4); }
+    s.bstart = (int32_t*)take(b * 513 * 4);
+    s.bmap = (uint16_t*)take(b * 4096 * 2);
     s.l1 = (float*)take(b * 512 * 320 * 4);
     s.U = (float*)take(b * 512 * 320 * 4);
     for (int q = 0; q < 3; ++q) s.idx2[q] = (int16_t*)take(b * 128 * (w ? w->sa2[q].nsample : 128) * 2);
@@ -423,15 +491,19 @@ extern "C" int iq_pointnet2_forward(const iq_pointnet2_weights* w, const float* 
     if ((rc = iq::launch_fps(xyz, s.fps1, s.nu1, B, N, S1, st))) return rc;
     hipLaunchKernelGGL(gather_xyz_kernel, dim3((B * S1 + 255) / 256), dim3(256), 0, st, xyz, s.fps1, s.nx1, 3, N, S1, B * S1);
     if ((rc = iq::check_launch("gather_xyz_kernel"))) return rc;
-    if ((rc = launch_ball(xyz, s.nx1, 3, w->sa1, 3, s.idx1, B, N, S1, st))) return rc;
+    if ((rc = launch_ball(xyz, s.nx1, 3, w->sa1, 3, s.idx1, s.cnt1, nullptr, B, N, S1, st))) return rc;
+    if (hipMemsetAsync(s.l1, 0, (size_t)B * S1 * F1 * sizeof(float), st) != hipSuccess)
+        return iq::fail(IQ_ELAUNCH, "iq_pointnet2_forward: memset failed");
     int col = 0;
     for (int q = 0; q < 3; ++q) {
+        IQ_REQUIRE(w->sa1[q].nsample <= 128 && w->sa2[q].nsample <= 128, "pointnet2: nsample > 128");
         GroupArgs a{};
-        a.xyz = xyz; a.ldx = 3; a.new_xyz = s.nx1; a.ldc = 3; a.idx = s.idx1[q];
+        a.xyz = xyz; a.ldx = 3; a.new_xyz = s.nx1; a.ldc = 3; a.idx = s.idx1[q]; a.cnt = s.cnt1[q];
+        a.block_start = s.bstart; a.blockmap = s.bmap;
         a.U = nullptr; a.ldu = 0;
-        a.out = s.l1 + col; a.ldo = F1; a.n_unique = s.nu1; a.N = N; a.S = S1;
+        a.out = s.l1 + col; a.ldo = F1; a.N = N; a.S = S1;
         iq::ProfileSpan span(iq::kSlotPrepool, st);
-        if ((rc = launch_group(w->sa1[q], a, B, st))) return rc;
+        if ((rc = launch_group(w->sa1[q], a, s.nu1, B, st))) return rc;
         col += w->sa1[q].l3.cout;
     }
     IQ_REQUIRE(col == F1, "pointnet2: sa1 output channels %d != 320", col);
@@ -440,20 +512,22 @@ extern "C" int iq_pointnet2_forward(const iq_pointnet2_weights* w, const float* 
 
     // ---- sa2 ---------------------------------------------------------------------------------------
     if ((rc = iq::launch_fps(s.nx1, s.fps2, s.nu2, B, S1, S2, st))) return rc;
+    if (hipMemsetAsync(s.a3, 0, (size_t)B * S2 * LD3 * sizeof(float), st) != hipSuccess)
+        return iq::fail(IQ_ELAUNCH, "iq_pointnet2_forward: memset failed");
     hipLaunchKernelGGL(gather_xyz_kernel, dim3((B * S2 + 255) / 256), dim3(256), 0, st, s.nx1, s.fps2, s.a3, LD3, S1, S2, B * S2);
-    hipLaunchKernelGGL(zero_cols_kernel, dim3((B * S2 + 255) / 256), dim3(256), 0, st, s.a3, LD3, 643, B * S2);
-    if ((rc = iq::check_launch("gather/zero"))) return rc;
-    if ((rc = launch_ball(s.nx1, s.a3, LD3, w->sa2, 3, s.idx2, B, S1, S2, st))) return rc;
+    if ((rc = iq::check_launch("gather_xyz_kernel"))) return rc;
+    if ((rc = launch_ball(s.nx1, s.a3, LD3, w->sa2, 3, s.idx2, s.cnt2, s.nu1, B, S1, S2, st))) return rc;
     if ((rc = iq::launch_linear(s.l1, F1, w->sa2_u, s.U, F1, B * S1, 0, st))) return rc;  // U = W_f f_p + b (all scales)
     col = 0;
     int ucol = 0;
     for (int q = 0; q < 3; ++q) {
         GroupArgs a{};
-        a.xyz = s.nx1; a.ldx = 3; a.new_xyz = s.a3; a.ldc = LD3; a.idx = s.idx2[q];
+        a.xyz = s.nx1; a.ldx = 3; a.new_xyz = s.a3; a.ldc = LD3; a.idx = s.idx2[q]; a.cnt = s.cnt2[q];
+        a.block_start = s.bstart; a.blockmap = s.bmap;
         a.U = s.U + ucol; a.ldu = F1;
-        a.out = s.a3 + 3 + col; a.ldo = LD3; a.n_unique = s.nu2; a.N = S1; a.S = S2;
+        a.out = s.a3 + 3 + col; a.ldo = LD3; a.N = S1; a.S = S2;
         iq::ProfileSpan span(iq::kSlotFstn, st);
-        if ((rc = launch_group(w->sa2[q], a, B, st))) return rc;
+        if ((rc = launch_group(w->sa2[q], a, s.nu2, B, st))) return rc;
         col += w->sa2[q].l3.cout;
         ucol += w->sa2[q].l2.cin;
     }
