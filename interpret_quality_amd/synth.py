@@ -139,3 +139,30 @@ def pointnet2_state_dict(seed=0):
     _bn(sd, "bn2", 256, seed)
     _linear(sd, "fc3", NUM_CLASSES, 256, seed, False, 0.7)
     return sd
+
+
+# --------------------------------------------------------------------------------------------
+# DGCNN / GCNN (models/dgcnn.py:51-194): 70 tensors, BatchNorms registered twice (bnK.* and convK.1.*)
+# --------------------------------------------------------------------------------------------
+DGCNN_CONVS = [(6, 64), (128, 64), (128, 128), (256, 256)]
+
+
+def dgcnn_state_dict(seed=0):
+    """Reference-keyed DGCNN_cls / GCNN_cls state dict (same layout for both) as numpy arrays."""
+    sd = {}
+    g = np.sqrt(2.0)
+    chans = [c for _, c in DGCNN_CONVS] + [1024, 512, 256]
+    for j, c in enumerate(chans, start=1):
+        _bn(sd, "bn%d" % j, c, seed)
+    for j, (cin, cout) in enumerate(DGCNN_CONVS, start=1):
+        w = _rng_for("conv%d.0.weight" % j, seed).standard_normal((cout, cin)) * (g / np.sqrt(cin))
+        sd["conv%d.0.weight" % j] = w.astype(np.float32).reshape(cout, cin, 1, 1)
+    w = _rng_for("conv5.0.weight", seed).standard_normal((1024, 512)) * (g / np.sqrt(512))
+    sd["conv5.0.weight"] = w.astype(np.float32).reshape(1024, 512, 1)
+    for j in range(1, 6):  # the Sequential's BN is the same module object as self.bnJ
+        for f in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
+            sd["conv%d.1.%s" % (j, f)] = sd["bn%d.%s" % (j, f)]
+    sd["linear1.weight"] = (_rng_for("linear1.weight", seed).standard_normal((512, 2048)) * (g / np.sqrt(2048))).astype(np.float32)
+    _linear(sd, "linear2", 256, 512, seed, False, g)
+    _linear(sd, "linear3", NUM_CLASSES, 256, seed, False, 1.0)
+    return sd

@@ -413,3 +413,67 @@ class PointNet2Oracle:
     def __call__(self, x):
         with torch.no_grad():
             return pointnet2_forward(self.sd, x)
+
+
+# --------------------------------------------------------------------------------------------
+# DGCNN / GCNN (models/dgcnn.py)
+# --------------------------------------------------------------------------------------------
+
+def knn(x, k):
+    """models/dgcnn.py:12-18.  x (B,C,N) -> (B,N,k) indices of the k largest of
+    -|x_i|^2 - (-2 x_i.x_j) - |x_j|^2 (self included; expanded form, d(i,i) is not exactly 0)."""
+    inner = torch.matmul(x.transpose(2, 1), x) * -2
+    xx = torch.sum(x ** 2, dim=1, keepdim=True)
+    pairwise = -xx - inner - xx.transpose(2, 1)
+    return pairwise.topk(k=k, dim=-1)[1]
+
+
+def get_graph_feature(x, k=20, idx=None):
+    """models/dgcnn.py:21-47.  x (B,C,N) -> [x_j - x_i ; x_i] (B,2C,N,k)."""
+    b, c, n = x.shape
+    if idx is None:
+        idx = knn(x, k)
+    xt = x.transpose(2, 1).contiguous()                                   # (B,N,C)
+    flat = (idx + torch.arange(b).reshape(-1, 1, 1) * n).reshape(-1)
+    nbr = xt.reshape(b * n, c)[flat].reshape(b, n, k, c)
+    ctr = xt.reshape(b, n, 1, c).expand(b, n, k, c)
+    return torch.cat((nbr - ctr, ctr), dim=3).permute(0, 3, 1, 2)
+
+
+def _edge_conv(x, sd, j, k, idx=None):
+    f = get_graph_feature(x, k, idx)
+    y = F.conv2d(f, sd["conv%d.0.weight" % j])
+    y = F.batch_norm(y, sd["bn%d.running_mean" % j], sd["bn%d.running_var" % j], sd["bn%d.weight" % j],
+                     sd["bn%d.bias" % j], False, 0.0, BN_EPS)
+    return F.leaky_relu(y, 0.2).max(dim=-1)[0]
+
+
+def dgcnn_forward(sd, x, k=20, fixed_graph=False, return_aux=False):
+    """models/dgcnn.py:83-120 (DGCNN_cls) / :156-194 (GCNN_cls, fixed_graph=True: one xyz graph, :163)."""
+    b = x.shape[0]
+    idx = knn(x, k) if fixed_graph else None
+    x1 = _edge_conv(x, sd, 1, k, idx)
+    x2 = _edge_conv(x1, sd, 2, k, idx)
+    x3 = _edge_conv(x2, sd, 3, k, idx)
+    x4 = _edge_conv(x3, sd, 4, k, idx)
+    h = torch.cat((x1, x2, x3, x4), dim=1)
+    h = F.conv1d(h, sd["conv5.0.weight"])
+    h = F.leaky_relu(F.batch_norm(h, sd["bn5.running_mean"], sd["bn5.running_var"], sd["bn5.weight"], sd["bn5.bias"],
+                                  False, 0.0, BN_EPS), 0.2)
+    g = torch.cat((F.adaptive_max_pool1d(h, 1).reshape(b, -1), F.adaptive_avg_pool1d(h, 1).reshape(b, -1)), 1)
+    g = F.leaky_relu(_bn(F.linear(g, sd["linear1.weight"]), sd, "bn6"), 0.2)
+    g = F.leaky_relu(_bn(_fc(g, sd, "linear2"), sd, "bn7"), 0.2)
+    logits = _fc(g, sd, "linear3")
+    if return_aux:
+        return logits, {"x1": x1, "x2": x2, "x3": x3, "x4": x4}
+    return logits
+
+
+class DgcnnOracle:
+    def __init__(self, state_dict, fixed_graph=False, k=20):
+        self.sd = {kk: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))) for kk, v in state_dict.items()}
+        self.fixed_graph, self.k = fixed_graph, k
+
+    def __call__(self, x):
+        with torch.no_grad():
+            return dgcnn_forward(self.sd, x, self.k, self.fixed_graph)

@@ -125,3 +125,47 @@ def test_pointnet2_oracle_matches_reference():
     np.testing.assert_allclose(aux["l1_points"][:, :, :8].numpy(), g["l1_points_rows"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(aux["l2_points"][:, :, :8].numpy(), g["l2_points_rows"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(logits.numpy(), g["logits"][sel], rtol=1e-5, atol=1e-5)
+
+
+def _knn_sets_equal(got, want, dist):
+    """kNN is index-valued with arbitrary tie order: compare neighbour SETS; rows may differ only by
+    swapping candidates whose distances tie (exact duplicates of a masked point)."""
+    bad = 0
+    for b in range(got.shape[0]):
+        for i in range(got.shape[1]):
+            sg, sw = set(got[b, i].tolist()), set(want[b, i].tolist())
+            if sg != sw:
+                dg = sorted(dist[b, i, list(sg - sw)].tolist())
+                dw = sorted(dist[b, i, list(sw - sg)].tolist())
+                assert np.allclose(dg, dw, rtol=0, atol=1e-6), (b, i, dg, dw)
+                bad += 1
+    return bad
+
+
+def test_dgcnn_oracle_matches_reference():
+    g = load_golden("dgcnn.npz")
+    sd = synth.to_torch(synth.dgcnn_state_dict(0))
+    pts, label = synth.make_cloud(0)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    lbl = torch.tensor([label])
+    center = torch.mean(data, dim=1).squeeze()
+    half = data.clone()
+    half[0, g["region_id"] >= 16, :] = center
+    x = torch.cat([data, half], dim=0).permute(0, 2, 1).contiguous()
+    with torch.no_grad():
+        idx = O.knn(x, 20)
+        assert np.array_equal(idx.numpy(), g["knn_xyz"])
+        for name, fixed in (("dgcnn", False), ("gcnn", True)):
+            logits, aux = O.dgcnn_forward(sd, x, 20, fixed, return_aux=True)
+            np.testing.assert_allclose(logits.numpy(), g["raw_logits_" + name], rtol=1e-5, atol=1e-5)
+            if not fixed:
+                np.testing.assert_allclose(aux["x1"][:, :8, :].numpy(), g["x1_first8"], rtol=1e-5, atol=1e-6)
+                assert np.array_equal(O.knn(aux["x1"], 20).numpy(), g["knn_feat64"])
+            model = O.DgcnnOracle(sd, fixed)
+            for ratio in g["ratios"]:
+                tag = "ratio%d" % int(ratio * 100)
+                lg = O.compute_order_interaction_logits(model, data, g["region_id"], g["pairs"], g[tag + "_contexts"], 2,
+                                                        is_pointnet=False)
+                np.testing.assert_allclose(lg.numpy(), g["%s_%s_logits" % (tag, name)], rtol=1e-5, atol=1e-5)
+                inter = O.compute_order_interaction(torch.from_numpy(g["%s_%s_logits" % (tag, name)]), lbl)
+                np.testing.assert_array_equal(inter, g["%s_%s_interaction" % (tag, name)])
