@@ -203,6 +203,34 @@ int iq_pointnet2_forward(const iq_pointnet2_weights* w /*host struct of device p
                          float* logits, void* workspace, size_t workspace_bytes, int B, int N,
                          iq_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * DGCNN / GCNN (models/dgcnn.py:12-194)
+ * ------------------------------------------------------------------------------------------- */
+
+/* models/dgcnn.py:12-18 (knn): the k = 20 largest of -|x_i|^2 - (-2 x_i.x_j) - |x_j|^2 per row, self
+ * included, as an (unordered) index set.  x (B,N,C) row-major with C in {3, 64, 128}; idx (B,N,20)
+ * int32; tmp = scratch of at least B*N*76 + 1024 bytes. */
+int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes, int B, int N, int C, int k,
+           iq_stream_t stream);
+
+/* pq[l]: layer l's EdgeConv as ONE dense layer over the points with 2*Cout outputs
+ * [P = (s.W_a) x ; Q = (s.(W_b - W_a)) x + t] (BN folded; see csrc/iq_dgcnn.hip); conv5/fc1/fc2 are
+ * followed by LeakyReLU(0.2). */
+typedef struct iq_dgcnn_weights {
+    iq_dense_layer pq[4];
+    iq_dense_layer conv5, fc1, fc2, fc3;
+    int32_t k;
+} iq_dgcnn_weights;
+
+size_t iq_dgcnn_workspace_bytes(int B, int N);
+
+/* Eval-mode DGCNN_cls.forward (models/dgcnn.py:83-120; fixed_graph = 0) or GCNN_cls.forward
+ * (:156-194; fixed_graph = 1: one xyz graph for all four EdgeConv layers) on B materialised clouds.
+ * xyz (B,N,3) channel-last -> logits (B,10). */
+int iq_dgcnn_forward(const iq_dgcnn_weights* w /*host struct of device pointers*/, const float* xyz,
+                     float* logits, void* workspace, size_t workspace_bytes, int B, int N,
+                     int fixed_graph, iq_stream_t stream);
+
 /* Optional HIP-event profiler (bench.py's roofline leg).  While enabled, iq_pointnet_coalitions
  * brackets its chain-kernel launches with hipEvents recorded on the launch stream.
  * iq_profile_read(slot) synchronises on the recorded events of that slot, returns their summed

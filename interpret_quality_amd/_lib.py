@@ -46,6 +46,11 @@ class PointNet2Weights(ctypes.Structure):
                 ("fc1", DenseLayer), ("fc2", DenseLayer), ("fc3", DenseLayer)]
 
 
+class DgcnnWeights(ctypes.Structure):
+    _fields_ = [("pq", DenseLayer * 4), ("conv5", DenseLayer), ("fc1", DenseLayer), ("fc2", DenseLayer),
+                ("fc3", DenseLayer), ("k", ctypes.c_int32)]
+
+
 _I = ctypes.c_int
 _P = ctypes.c_void_p
 _SZ = ctypes.c_size_t
@@ -73,6 +78,9 @@ SIGNATURES = {
     "iq_ball_query": (_I, [_P, _P, ctypes.c_float, _I, _P, _I, _I, _I, _P]),
     "iq_pointnet2_workspace_bytes": (_SZ, [_I]),
     "iq_pointnet2_forward": (_I, [ctypes.POINTER(PointNet2Weights), _P, _P, _P, _SZ, _I, _I, _P]),
+    "iq_knn": (_I, [_P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
+    "iq_dgcnn_workspace_bytes": (_SZ, [_I, _I]),
+    "iq_dgcnn_forward": (_I, [ctypes.POINTER(DgcnnWeights), _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "iq_profile_enable": (_I, [_I]),
     "iq_set_tuning": (_I, [_I, _I]),
     "iq_debug_chain_occupancy": (_I, []),

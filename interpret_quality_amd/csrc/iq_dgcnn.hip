@@ -1,0 +1,302 @@
+// DGCNN / GCNN forward (models/dgcnn.py:12-194) on materialised (masked) clouds.
+//
+// EdgeConv restructuring (exact algebra): with W = [W_a | W_b] and BN(eval) y = s.z + t,
+//     max_j LeakyReLU(s.(W_a (x_j - x_i) + W_b x_i) + t) = LeakyReLU( max_j P_j + Q_i ),
+//     P = (s.W_a) x,  Q = (s.(W_b - W_a)) x + t,
+// because the x_i terms are constant over the neighbourhood and LeakyReLU is increasing.  One GEMM
+// over the N points per layer (2*Cout outputs) and a gather-max replace the 20x larger edge tensor.
+//
+// kNN (index-valued): -|x_i|^2 - (-2 x_i.x_j) - |x_j|^2 evaluated in the reference's order, inner
+// products on the fp32 MFMA.  Keys run along the accumulator registers and queries along the lanes,
+// so every lane keeps the running top-20 of its query in registers; ties between exact duplicates
+// (masked points) are harmless because duplicates carry identical features.
+#include "iq_common.h"
+#include "iq_mfma.h"
+#include "iq_profile.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kK = 20;  // K_FOR_DGCNN, tools/final_util.py:19
+
+// ---- pad xyz (B,N,3) -> (B,N,8) -------------------------------------------------------------------
+__global__ void pad_xyz_kernel(const float* __restrict__ xyz, float* __restrict__ out, int total) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    f32x4 a = {xyz[t * 3], xyz[t * 3 + 1], xyz[t * 3 + 2], 0.f}, z = {0.f, 0.f, 0.f, 0.f};
+    reinterpret_cast<f32x4*>(out)[t * 2] = a;
+    reinterpret_cast<f32x4*>(out)[t * 2 + 1] = z;
+}
+
+// ---- xx[i] = sum_c x[i][c]^2 in channel order (torch.sum(x**2, dim=1)) ------------------------------
+__global__ void rownorm_kernel(const float* __restrict__ x, int ldx, int C, float* __restrict__ xx, int rows) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* p = x + (size_t)r * ldx;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += p[c] * p[c];
+    xx[r] = s;
+}
+
+// ---- kNN ------------------------------------------------------------------------------------------
+struct TopK {
+    float v[kK];
+    int i[kK];
+    float minv;
+    int minp;
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int q = 0; q < kK; ++q) { v[q] = -INFINITY; i[q] = 0; }
+        minv = -INFINITY; minp = 0;
+    }
+    __device__ __forceinline__ void offer(float val, int idx) {
+        if (val > minv) {
+#pragma unroll
+            for (int q = 0; q < kK; ++q)
+                if (q == minp) { v[q] = val; i[q] = idx; }
+            minv = v[0]; minp = 0;
+#pragma unroll
+            for (int q = 1; q < kK; ++q)
+                if (v[q] < minv) { minv = v[q]; minp = q; }
+        }
+    }
+};
+
+template <int C>
+__global__ __launch_bounds__(kThreads, 2) void knn_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ xx,
+                                                          int16_t* __restrict__ idx, int N) {
+    constexpr int LD = C + 4, KB = C / 8;
+    __shared__ __attribute__((aligned(16))) float keys[2][32 * LD];
+    __shared__ float kxx[2][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const float* xb = x + (size_t)b * N * ldx;
+    const float* xxb = xx + (size_t)b * N;
+    const int q0 = blockIdx.x * 128 + wave * 32;  // this wave's 32 queries
+    const int fl = lane & 31, fh = lane >> 5;
+
+    // B operand: queries, stationary in registers
+    f32x4 qf[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+        qf[kb] = *reinterpret_cast<const f32x4*>(xb + (size_t)(q0 + fl) * ldx + 8 * kb + 4 * fh);
+    const float xxq = xxb[q0 + fl];
+
+    auto stage = [&](int tile, int buf) {
+        for (int e = tid; e < 32 * C / 4; e += kThreads) {
+            const int row = e / (C / 4), c4 = e - row * (C / 4);
+            *reinterpret_cast<f32x4*>(&keys[buf][row * LD + c4 * 4]) =
+                *reinterpret_cast<const f32x4*>(xb + (size_t)(tile * 32 + row) * ldx + c4 * 4);
+        }
+        if (tid < 32) kxx[buf][tid] = xxb[tile * 32 + tid];
+    };
+
+    TopK top;
+    top.init();
+    const int ntiles = N / 32;
+    stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+        f32x16 acc = {0};
+        const float* abase = keys[buf] + fl * LD + 4 * fh;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) acc = mfma4(lds_frag<LD>(abase, 0, kb), qf[kb], acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jl = c_row(r, lane);
+            const float inner = -2.f * acc[r];                // -2 * matmul
+            const float d = ((-kxx[buf][jl]) - inner) - xxq;  // -xx - inner - xx^T   (models/dgcnn.py:15)
+            top.offer(d, t * 32 + jl);
+        }
+        __syncthreads();
+    }
+    // merge the two half-waves (each saw half of the keys of every tile)
+    float pv[kK];
+    int pi[kK];
+#pragma unroll
+    for (int q = 0; q < kK; ++q) { pv[q] = __shfl_xor(top.v[q], 32); pi[q] = __shfl_xor(top.i[q], 32); }
+#pragma unroll
+    for (int q = 0; q < kK; ++q) top.offer(pv[q], pi[q]);
+    if (fh == 0) {
+        int16_t* o = idx + ((size_t)b * N + q0 + fl) * kK;
+#pragma unroll
+        for (int q = 0; q < kK; ++q) o[q] = (int16_t)top.i[q];
+    }
+}
+
+// ---- out[i][c] = LeakyReLU(max_j P[idx[i][j]][c] + Q[i][c]) ------------------------------------------
+__global__ __launch_bounds__(kThreads) void gather_max_kernel(const float* __restrict__ pq, int Co,
+                                                              const int16_t* __restrict__ idx, float* __restrict__ out,
+                                                              int ldo, int N, int total_pts) {
+    const int per = Co / 4;                               // float4 lanes per point
+    const int t = blockIdx.x * kThreads + threadIdx.x;
+    const int pt = t / per, c4 = t - pt * per;
+    if (pt >= total_pts) return;
+    const int b = pt / N;
+    const int16_t* nb = idx + (size_t)pt * kK;
+    const f32x4* P = reinterpret_cast<const f32x4*>(pq);
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll 4
+    for (int j = 0; j < kK; ++j) {
+        const f32x4 v = P[((size_t)b * N + nb[j]) * (2 * per) + c4];
+        m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+    }
+    const f32x4 q = P[(size_t)pt * (2 * per) + per + c4];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float y = m[e] + q[e];
+        o[e] = y > 0.f ? y : 0.2f * y;
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)pt * ldo + c4 * 4) = o;
+}
+
+// ---- global max and mean pooling over the N rows of (B,N,C) -> (B,2C) ---------------------------------
+__global__ __launch_bounds__(kThreads) void pool_max_avg_kernel(const float* __restrict__ h, float* __restrict__ out,
+                                                                int N, int C) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    const float* p = h + (size_t)b * N * C + c;
+    float m = -INFINITY, s = 0.f;
+    for (int i = 0; i < N; ++i) {
+        const float v = p[(size_t)i * C];
+        m = fmaxf(m, v);
+        s += v;
+    }
+    out[(size_t)b * 2 * C + c] = m;
+    out[(size_t)b * 2 * C + C + c] = s / (float)N;
+}
+
+int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, int B, int N, hipStream_t st) {
+    dim3 grid(N / 128, B);
+    if (C == 8) hipLaunchKernelGGL(knn_kernel<8>, grid, dim3(kThreads), 0, st, x, ldx, xx, idx, N);
+    else if (C == 64) hipLaunchKernelGGL(knn_kernel<64>, grid, dim3(kThreads), 0, st, x, ldx, xx, idx, N);
+    else if (C == 128) hipLaunchKernelGGL(knn_kernel<128>, grid, dim3(kThreads), 0, st, x, ldx, xx, idx, N);
+    else return iq::fail(IQ_EUNSUPPORTED, "knn: C=%d has no kernel instantiation (8, 64, 128)", C);
+    return iq::check_launch("knn_kernel");
+}
+
+struct WsD {
+    float* x0;      // (B,N,8)
+    float* xc;      // (B,N,512)
+    float* pq;      // (B,N,512)
+    float* xx;      // (B,N)
+    int16_t* idx;   // (B,N,20)
+    float* h;       // (B,N,1024)
+    float *g, *f1, *f2;
+    size_t bytes;
+};
+
+WsD carve_d(void* base, int B, int N) {
+    WsD s{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = iq::align_up(off + bytes, 256);
+        return reinterpret_cast<char*>(base) + o;
+    };
+    const size_t r = (size_t)B * N;
+    s.x0 = (float*)take(r * 8 * 4);
+    s.xc = (float*)take(r * 512 * 4);
+    s.pq = (float*)take(r * 512 * 4);
+    s.xx = (float*)take(r * 4);
+    s.idx = (int16_t*)take(r * kK * 2);
+    s.h = (float*)take(r * 1024 * 4);
+    s.g = (float*)take((size_t)B * 2048 * 4);
+    s.f1 = (float*)take((size_t)B * 512 * 4);
+    s.f2 = (float*)take((size_t)B * 256 * 4);
+    s.bytes = off;
+    return s;
+}
+
+__global__ void widen_idx_kernel(const int16_t* __restrict__ in, int32_t* __restrict__ out, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = in[t];
+}
+
+}  // namespace
+
+extern "C" size_t iq_dgcnn_workspace_bytes(int B, int N) {
+    if (B < 0 || N < 0) return 0;
+    return carve_d(nullptr, B, N).bytes;
+}
+
+// Op-level kNN for tests: x (B,N,C) row-major, C in {3, 64, 128}; idx (B,N,20) int32; tmp >= B*N*(8*4+4+40) bytes.
+extern "C" int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes, int B, int N, int C, int k,
+                      iq_stream_t stream) {
+    IQ_REQUIRE(x && idx && tmp, "iq_knn: null pointer");
+    IQ_REQUIRE(k == kK, "iq_knn: k=%d (only k=20, tools/final_util.py:19)", k);
+    IQ_REQUIRE(B >= 1 && N >= 128 && N % 128 == 0 && N <= 32767, "iq_knn: N=%d must be a multiple of 128", N);
+    IQ_REQUIRE(C == 3 || C == 64 || C == 128, "iq_knn: C=%d unsupported", C);
+    const size_t r = (size_t)B * N;
+    IQ_REQUIRE(tmp_bytes >= r * (8 * 4 + 4 + kK * 2) + 1024, "iq_knn: tmp too small");
+    hipStream_t st = iq::as_stream(stream);
+    char* p = reinterpret_cast<char*>(tmp);
+    float* x0 = reinterpret_cast<float*>(p);
+    float* xx = reinterpret_cast<float*>(p + iq::align_up(r * 8 * 4, 256));
+    int16_t* i16 = reinterpret_cast<int16_t*>(p + iq::align_up(r * 8 * 4, 256) + iq::align_up(r * 4, 256));
+    const float* src = x;
+    int ld = C, cpad = C;
+    if (C == 3) {
+        hipLaunchKernelGGL(pad_xyz_kernel, dim3((r + 255) / 256), dim3(256), 0, st, x, x0, (int)r);
+        src = x0; ld = 8; cpad = 8;
+    }
+    hipLaunchKernelGGL(rownorm_kernel, dim3((r + 255) / 256), dim3(256), 0, st, src, ld, C, xx, (int)r);
+    int rc = launch_knn(src, ld, cpad, xx, i16, B, N, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(widen_idx_kernel, dim3((r * kK + 255) / 256), dim3(256), 0, st, i16, idx, r * kK);
+    return iq::check_launch("iq_knn");
+}
+
+extern "C" int iq_dgcnn_forward(const iq_dgcnn_weights* w, const float* xyz, float* logits, void* workspace,
+                                size_t workspace_bytes, int B, int N, int fixed_graph, iq_stream_t stream) {
+    IQ_REQUIRE(w && xyz && logits, "iq_dgcnn_forward: null pointer");
+    IQ_REQUIRE(B >= 0 && N >= 128 && N % 128 == 0 && N <= 32767, "iq_dgcnn_forward: N=%d must be a multiple of 128", N);
+    IQ_REQUIRE(w->k == kK, "iq_dgcnn_forward: k=%d (only 20)", w->k);
+    if (B == 0) return IQ_OK;
+    const size_t need = carve_d(nullptr, B, N).bytes;
+    if (!workspace || workspace_bytes < need)
+        return iq::fail(IQ_EWORKSPACE, "iq_dgcnn_forward: workspace %zu < %zu bytes", workspace_bytes, need);
+    WsD s = carve_d(workspace, B, N);
+    hipStream_t st = iq::as_stream(stream);
+    const int rows = B * N;
+    int rc;
+    iq::ProfileSpan call_span(iq::kSlotCall, st);
+
+    hipLaunchKernelGGL(pad_xyz_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, xyz, s.x0, rows);
+    if ((rc = iq::check_launch("pad_xyz_kernel"))) return rc;
+    const float* src = s.x0;
+    int ld = 8, cin = 8, creal = 3, col = 0;
+    for (int l = 0; l < 4; ++l) {
+        const int co = w->pq[l].cout / 2;
+        IQ_REQUIRE(w->pq[l].cin == cin, "iq_dgcnn_forward: layer %d expects %d inputs, got %d", l, cin, w->pq[l].cin);
+        if (l == 0 || !fixed_graph) {
+            iq::ProfileSpan span(iq::kSlotPrepool, st);
+            hipLaunchKernelGGL(rownorm_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, src, ld, creal, s.xx, rows);
+            if ((rc = launch_knn(src, ld, cin, s.xx, s.idx, B, N, st))) return rc;
+        }
+        {
+            iq::ProfileSpan span(iq::kSlotFstn, st);
+            if ((rc = iq::launch_linear(src, ld, w->pq[l], s.pq, 2 * co, rows, 0, st))) return rc;
+            const int nthreads = rows * (co / 4);
+            hipLaunchKernelGGL(gather_max_kernel, dim3((nthreads + kThreads - 1) / kThreads), dim3(kThreads), 0, st, s.pq, co,
+                               s.idx, s.xc + col, 512, N, rows);
+            if ((rc = iq::check_launch("gather_max_kernel"))) return rc;
+        }
+        src = s.xc + col; ld = 512; cin = co; creal = co; col += co;
+    }
+    IQ_REQUIRE(col == 512, "iq_dgcnn_forward: concatenated width %d != 512", col);
+    {
+        iq::ProfileSpan span(iq::kSlotTrunk, st);
+        if ((rc = iq::launch_linear(s.xc, 512, w->conv5, s.h, 1024, rows, 2, st))) return rc;
+        hipLaunchKernelGGL(pool_max_avg_kernel, dim3(1024 / kThreads, B), dim3(kThreads), 0, st, s.h, s.g, N, 1024);
+        if ((rc = iq::check_launch("pool_max_avg_kernel"))) return rc;
+    }
+    if ((rc = iq::launch_linear(s.g, 2048, w->fc1, s.f1, 512, B, 2, st))) return rc;
+    if ((rc = iq::launch_linear(s.f1, 512, w->fc2, s.f2, 256, B, 2, st))) return rc;
+    if ((rc = iq::launch_linear(s.f2, 256, w->fc3, logits, w->fc3.cout, B, 0, st))) return rc;
+    return IQ_OK;
+}

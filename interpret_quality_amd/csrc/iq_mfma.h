@@ -80,6 +80,7 @@ __device__ __forceinline__ void mfma_ntile(const float* abase, const float* wcur
 
 namespace iq {
 // Batched dense layer out = act(A W^T + b) on packed weights (iq_pointnet.hip).
+// relu: 0 = none, 1 = ReLU, 2 = LeakyReLU(0.2).
 int launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,
                   hipStream_t st);
 // Farthest point sampling (iq_geom.hip); n_unique may be null.

@@ -541,7 +541,8 @@ __global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __rest
                 const int row = m0 + i * 32 + c_row(r, lane);
                 if (row < M) {
                     float v = acc[i][j][r] + b;
-                    if (relu) v = fmaxf(v, 0.f);
+                    if (relu == 1) v = fmaxf(v, 0.f);
+                    else if (relu == 2) v = v > 0.f ? v : 0.2f * v;  // LeakyReLU(0.2), models/dgcnn.py:66-80
                     out[(size_t)row * ldo + col] = v;
                 }
             }

@@ -1,0 +1,150 @@
+"""DGCNN and GCNN classifiers on the HIP path.
+
+Host-side mirror of models/dgcnn.py:51-194 (DGCNN_cls: dynamic feature-space kNN graph per layer;
+GCNN_cls: one fixed xyz graph): same constructor argument, same ``state_dict`` keys (70 tensors, the
+BatchNorms appear twice as ``bnK.*`` and ``convK.1.*``), same call ``model(x: (B,3,N)) -> logits``.
+kNN, the EdgeConv GEMMs, the neighbour max, conv5, pooling and the head run in libiq_hip.so
+(csrc/iq_dgcnn.hip); the torch modules only hold parameters.  ``gcnn_adv`` is GCNN_cls with another
+checkpoint (tools/final_util.py:243-244).
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .pointnet import BN_EPS, _np
+
+CONVS = [(6, 64), (128, 64), (128, 128), (256, 256)]  # models/dgcnn.py:66-77
+
+
+def _bn_affine(sd, bn):
+    s = _np(sd[bn + ".weight"]) / np.sqrt(_np(sd[bn + ".running_var"]) + BN_EPS)
+    t = _np(sd[bn + ".bias"]) - _np(sd[bn + ".running_mean"]) * s
+    return s, t
+
+
+class PackedWeightsD:
+    def __init__(self, sd, device, k):
+        lib = _lib.load()
+        self._keep = []
+        self.struct = _lib.DgcnnWeights()
+
+        def dense(w, b):
+            cout, cin = w.shape
+            w32 = np.ascontiguousarray(w, dtype=np.float32)
+            out = np.empty(lib.iq_packed_floats(cout, cin), dtype=np.float32)
+            _lib.check(lib.iq_pack_weight(w32.ctypes.data, out.ctypes.data, cout, cin), "iq_pack_weight")
+            bp = np.zeros(lib.iq_padded_cout(cout), dtype=np.float32)
+            bp[:cout] = b
+            wt = torch.from_numpy(out).to(device)
+            bt = torch.from_numpy(bp).to(device)
+            self._keep += [wt, bt]
+            return _lib.DenseLayer(wt.data_ptr(), bt.data_ptr(), cin, cout)
+
+        for j, (cin2, cout) in enumerate(CONVS, start=1):
+            c = cin2 // 2
+            w = _np(sd["conv%d.0.weight" % j]).reshape(cout, cin2)
+            s, t = _bn_affine(sd, "bn%d" % j)
+            wa, wb = w[:, :c], w[:, c:]                       # [x_j - x_i ; x_i]  (models/dgcnn.py:45)
+            cpad = 8 if c == 3 else c
+            pq = np.zeros((2 * cout, cpad))
+            pq[:cout, :c] = wa * s[:, None]                   # P = (s.W_a) x
+            pq[cout:, :c] = (wb - wa) * s[:, None]            # Q = (s.(W_b - W_a)) x + t
+            self.struct.pq[j - 1] = dense(pq, np.concatenate([np.zeros(cout), t]))
+        s, t = _bn_affine(sd, "bn5")
+        self.struct.conv5 = dense(_np(sd["conv5.0.weight"]).reshape(1024, 512) * s[:, None], t)
+        s, t = _bn_affine(sd, "bn6")
+        self.struct.fc1 = dense(_np(sd["linear1.weight"]) * s[:, None], t)      # linear1 has no bias (:79)
+        s, t = _bn_affine(sd, "bn7")
+        self.struct.fc2 = dense(_np(sd["linear2.weight"]) * s[:, None], _np(sd["linear2.bias"]) * s + t)
+        self.struct.fc3 = dense(_np(sd["linear3.weight"]), _np(sd["linear3.bias"]))
+        self.struct.k = k
+        self.num_classes = int(sd["linear3.weight"].shape[0])
+
+
+class DgcnnEngine:
+    def __init__(self, state_dict, device, k, fixed_graph):
+        if torch.device(device).type != "cuda":
+            raise _lib.IqError("DgcnnEngine needs a GPU device (no CPU fallback)")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.fixed_graph = int(fixed_graph)
+        self.weights = PackedWeightsD(state_dict, self.device, k)
+        self._ws = None
+
+    def forward_points(self, xyz):
+        if not xyz.is_cuda or xyz.dtype != torch.float32 or not xyz.is_contiguous():
+            raise _lib.IqError("xyz must be a contiguous float32 GPU tensor (B,N,3)")
+        b, n, _ = xyz.shape
+        need = self.lib.iq_dgcnn_workspace_bytes(b, n)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        logits = torch.empty((b, self.weights.num_classes), dtype=torch.float32, device=self.device)
+        rc = self.lib.iq_dgcnn_forward(ctypes.byref(self.weights.struct), ctypes.c_void_p(xyz.data_ptr()),
+                                       ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(self._ws.data_ptr()),
+                                       self._ws.numel(), b, n, self.fixed_graph,
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "iq_dgcnn_forward")
+        return logits
+
+
+class _GraphCnn(nn.Module):
+    fixed_graph = False
+    max_clouds_per_call = 1024  # bounds the workspace (8.2 MB per cloud)
+
+    def __init__(self, args=None):
+        super().__init__()
+        self.args = args
+        self.k = getattr(args, "k", 20)
+        self.output_channels = 40 if getattr(args, "dataset", "modelnet10") == "modelnet40" else 10
+        self.bn1, self.bn2, self.bn3, self.bn4 = nn.BatchNorm2d(64), nn.BatchNorm2d(64), nn.BatchNorm2d(128), nn.BatchNorm2d(256)
+        self.bn5 = nn.BatchNorm1d(1024)
+        for j, (cin, cout) in enumerate(CONVS, start=1):
+            setattr(self, "conv%d" % j, nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, bias=False),
+                                                     getattr(self, "bn%d" % j), nn.LeakyReLU(negative_slope=0.2)))
+        self.conv5 = nn.Sequential(nn.Conv1d(512, 1024, kernel_size=1, bias=False), self.bn5, nn.LeakyReLU(negative_slope=0.2))
+        self.linear1 = nn.Linear(2048, 512, bias=False)
+        self.bn6 = nn.BatchNorm1d(512)
+        self.linear2 = nn.Linear(512, 256)
+        self.bn7 = nn.BatchNorm1d(256)
+        self.linear3 = nn.Linear(256, self.output_channels)
+        self._engine = None
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def engine(self):
+        if self.training:
+            raise _lib.IqError("the HIP DGCNN path implements eval mode only")
+        if self._engine is None:
+            self._engine = DgcnnEngine(self.state_dict(), self.linear3.weight.device, self.k, self.fixed_graph)
+        return self._engine
+
+    def forward_points(self, xyz):
+        """(B,N,3) channel-last clouds -> logits."""
+        eng = self.engine()
+        step = self.max_clouds_per_call
+        if xyz.shape[0] <= step:
+            return eng.forward_points(xyz)
+        return torch.cat([eng.forward_points(xyz[i:i + step].contiguous()) for i in range(0, xyz.shape[0], step)], dim=0)
+
+    def forward(self, x):
+        """x (B,3,N) as in the reference -> logits (B,10)."""
+        return self.forward_points(x.permute(0, 2, 1).contiguous())
+
+
+class DGCNN_cls(_GraphCnn):
+    """models/dgcnn.py:51-120."""
+    fixed_graph = False
+
+
+class GCNN_cls(_GraphCnn):
+    """models/dgcnn.py:123-194."""
+    fixed_graph = True

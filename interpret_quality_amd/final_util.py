@@ -130,6 +130,10 @@ def load_model(args):
     elif args.model == "pointnet2":
         from .pointnet2 import PointNet2ClsMsg
         model, synth_sd = PointNet2ClsMsg(args).to(args.device), synth.pointnet2_state_dict
+    elif args.model in ("dgcnn", "gcnn", "gcnn_adv"):
+        from .dgcnn import DGCNN_cls, GCNN_cls
+        model = (DGCNN_cls if args.model == "dgcnn" else GCNN_cls)(args).to(args.device)
+        synth_sd = synth.dgcnn_state_dict
     else:
         raise IqError("model %r is not on the HIP path yet (see DESIGN.md 'next')" % args.model)
     if getattr(args, "synthetic", False) and not os.path.exists(args.model_path):

@@ -151,3 +151,13 @@ def ball_query(xyz, new_xyz, radius, nsample):
     _lib.check(lib.iq_ball_query(_dev(xyz, torch.float32, "xyz"), _dev(new_xyz, torch.float32, "new_xyz"),
                                  ctypes.c_float(radius), nsample, _p(out), b, n, s, _stream()), "iq_ball_query")
     return out
+
+
+def knn(x, k=20):
+    """x (B,N,C) row-major f32, C in {3,64,128} -> (B,N,k) i32 neighbour sets (models/dgcnn.py:12-18)."""
+    lib = _lib.load()
+    b, n, c = x.shape
+    out = torch.empty((b, n, k), dtype=torch.int32, device=x.device)
+    tmp = torch.empty((b * n * 76 + 4096,), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.iq_knn(_dev(x, torch.float32, "x"), _p(out), _p(tmp), tmp.numel(), b, n, c, k, _stream()), "iq_knn")
+    return out

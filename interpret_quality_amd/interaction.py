@@ -67,10 +67,11 @@ def compute_order_interaction_logits(model, data_disturb, region_id, region_pair
                 bs = 4 * args.interaction_batch_size
                 keep = hip_ops.masks_to_tensor(keep_np, dev)
                 chunks = []
+                points_api = hasattr(model, "forward_points")  # consumes (B,N,3) directly: no transpose
                 for i in range(0, keep.numel(), bs):
                     x = hip_ops.mask_coalitions(data_disturb[0].contiguous(), rid, keep[i:i + bs].contiguous(),
-                                                center.reshape(3).contiguous(), channel_first=True)
-                    chunks.append(model(x))
+                                                center.reshape(3).contiguous(), channel_first=not points_api)
+                    chunks.append(model.forward_points(x) if points_api else model(x))
                 logits = torch.cat(chunks, dim=0)
             logits = logits.reshape(hi - lo, 4 * num_context, -1)
         else:

@@ -58,6 +58,13 @@ def main():
                 args.model = name
                 logits = ref_inter.compute_order_interaction_logits(models[name], data, region_id, pairs, ctx, args)
                 out["%s_%s_logits" % (tag, name)] = logits.numpy()
+                if name == "dgcnn":
+                    # the reference in float64 on the same inputs: how far its own float32 result is from
+                    # exact arithmetic tells which clouds sit on a kNN near-tie (dynamic graphs flip there)
+                    m64 = ref_dg.DGCNN_cls(a).double()
+                    m64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()})
+                    l64 = ref_inter.compute_order_interaction_logits(m64.eval(), data.double(), region_id, pairs, ctx, args)
+                    out["%s_dgcnn_logits_fp64" % tag] = l64.numpy()
                 out["%s_%s_interaction" % (tag, name)] = ref_cal.compute_order_interaction(logits, lbl, args)
         # op level on a half-masked cloud and on a raw cloud
         center = torch.mean(data, dim=1).squeeze()

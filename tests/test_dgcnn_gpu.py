@@ -1,0 +1,154 @@
+"""GPU parity: DGCNN / GCNN (kNN, EdgeConv, full models, interaction path) against golden vectors from
+the reference.  kNN is index-valued with arbitrary tie order among exact duplicates, so neighbour SETS
+are compared modulo distance ties."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from interpret_quality_amd import hip_ops, interaction, synth
+from interpret_quality_amd.dgcnn import DGCNN_cls, GCNN_cls
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import ref_cpu
+    return ref_cpu
+
+
+@pytest.fixture(scope="module")
+def clouds():
+    g = load_golden("dgcnn.npz")
+    pts, _ = synth.make_cloud(0)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    center = torch.mean(data, dim=1).squeeze()
+    half = data.clone()
+    half[0, g["region_id"] >= 16, :] = center
+    return torch.cat([data, half], dim=0)  # (2,1024,3): raw + half-masked
+
+
+def make(cls):
+    m = cls(argparse.Namespace(dataset="modelnet10", k=20))
+    m.load_state_dict(synth.to_torch(synth.dgcnn_state_dict(0)))
+    return m.to(dev()).eval()
+
+
+def knn_set_mismatches(got, want, x_cf):
+    """rows whose neighbour sets differ must differ only by candidates at (numerically) tied distance"""
+    inner = torch.matmul(x_cf.transpose(2, 1), x_cf) * -2
+    xx = torch.sum(x_cf ** 2, dim=1, keepdim=True)
+    dist = (-xx - inner - xx.transpose(2, 1)).numpy()
+    bad = 0
+    for b in range(got.shape[0]):
+        for i in range(got.shape[1]):
+            sg, sw = set(got[b, i].tolist()), set(want[b, i].tolist())
+            assert len(sg) == 20, "duplicate neighbour in row (%d,%d)" % (b, i)
+            if sg != sw:
+                dg = np.sort(dist[b, i, list(sg - sw)])
+                dw = np.sort(dist[b, i, list(sw - sg)])
+                scale = max(1.0, float(np.abs(dist[b, i]).max()))
+                assert np.allclose(dg, dw, rtol=0, atol=2e-6 * scale), (b, i, dg, dw)
+                bad += 1
+    return bad
+
+
+def test_knn_xyz_and_feature_space(clouds, oracle):
+    g = load_golden("dgcnn.npz")
+    got = hip_ops.knn(clouds.to(dev()).contiguous(), 20).cpu().numpy()
+    x_cf = clouds.permute(0, 2, 1).contiguous()
+    nbad = knn_set_mismatches(got, g["knn_xyz"].astype(np.int32), x_cf)
+    # feature space (C = 64): layer-1 output of the oracle as input
+    sd = synth.to_torch(synth.dgcnn_state_dict(0))
+    with torch.no_grad():
+        _, aux = oracle.dgcnn_forward(sd, x_cf, 20, False, return_aux=True)
+    x1 = aux["x1"]                                           # (2,64,1024)
+    got64 = hip_ops.knn(x1.permute(0, 2, 1).contiguous().to(dev()), 20).cpu().numpy()
+    nbad += knn_set_mismatches(got64, g["knn_feat64"].astype(np.int32), x1)
+    # knn_set_mismatches already proved every difference is a tie; the half-masked cloud has 512 identical
+    # rows (plus their neighbours) whose ties resolve arbitrarily, the raw cloud must match exactly
+    assert nbad <= 2 * 640
+    assert knn_set_mismatches(got[:1], g["knn_xyz"][:1].astype(np.int32), x_cf[:1]) == 0
+    assert knn_set_mismatches(got64[:1], g["knn_feat64"][:1].astype(np.int32), x1[:1]) == 0
+
+
+@pytest.mark.parametrize("cls,name", [(DGCNN_cls, "dgcnn"), (GCNN_cls, "gcnn")])
+def test_forward_matches_reference(clouds, cls, name):
+    g = load_golden("dgcnn.npz")
+    model = make(cls)
+    logits = model(clouds.permute(0, 2, 1).contiguous().to(dev()))
+    assert rel_err(logits.cpu().numpy(), g["raw_logits_" + name]) < RTOL
+
+
+def knn_min_margin(p, c, g, tag):
+    """Smallest relative gap between the 20th and 21st nearest candidates (exact ties excluded) over all
+    rows and the three feature-space graphs of interaction cloud (pair p, row c), from the CPU oracle."""
+    from oracle import ref_cpu as O
+    pts, _ = synth.make_cloud(0)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    center = torch.mean(data, dim=1).squeeze()
+    ri, rj = g["pairs"][p]
+    masked = O.interaction_masked_batch(data.permute(0, 2, 1), center, g["region_id"], ri, rj, g[tag + "_contexts"][p])
+    x = masked[c:c + 1].contiguous()
+    with torch.no_grad():
+        _, aux = O.dgcnn_forward(synth.to_torch(synth.dgcnn_state_dict(0)), x, 20, False, return_aux=True)
+        best = 1.0
+        for t in (aux["x1"], aux["x2"], aux["x3"]):
+            inner = torch.matmul(t.transpose(2, 1), t) * -2
+            xx = torch.sum(t ** 2, dim=1, keepdim=True)
+            d = (-xx - inner - xx.transpose(2, 1))[0]
+            top = d.topk(40, dim=-1)[0]
+            gap = (top[:, 19:20] - top[:, 20:])                     # 20th minus later candidates
+            gap = torch.where(gap > 0, gap, torch.full_like(gap, float("inf"))).min(dim=1)[0]
+            best = min(best, float((gap / xx.max()).min()))
+    return best
+
+
+@pytest.mark.parametrize("cls,name", [(DGCNN_cls, "dgcnn"), (GCNN_cls, "gcnn")])
+def test_interaction_path_matches_reference(cls, name):
+    g = load_golden("dgcnn.npz")
+    model = make(cls)
+    pts, label = synth.make_cloud(0)
+    data = torch.from_numpy(pts).unsqueeze(0).to(dev())
+    lbl = torch.tensor([label], device=dev())
+    args = argparse.Namespace(model=name, softmax_type="modified", num_regions=32, interaction_batch_size=2)
+    for ratio in g["ratios"]:
+        tag = "ratio%d" % int(ratio * 100)
+        logits = interaction.compute_order_interaction_logits(model, data, g["region_id"], g["pairs"], g[tag + "_contexts"], args)
+        want = g["%s_%s_logits" % (tag, name)]
+        assert logits.shape == want.shape
+        got = logits.cpu().numpy()
+        cond = np.zeros(1)
+        if name == "gcnn":
+            assert rel_err(got, want) < RTOL
+        else:
+            # DGCNN rebuilds its graph in feature space at every layer: a cloud that sits on a kNN near-tie
+            # flips a neighbour under ANY rounding change (the reference's own float32 result is then far
+            # from its float64 result).  Bar: 1e-4 relative, or 10x the reference's own float32
+            # conditioning for such clouds (SURVEY.md §7 "index-valued kernels").
+            scale = np.abs(want).max()
+            cond = np.abs(want - g[tag + "_dgcnn_logits_fp64"]).max(axis=-1) / scale      # (P, 4C)
+            err = np.abs(got - want).max(axis=-1) / scale
+            assert np.median(err) < 1e-5
+            for p, c in zip(*np.nonzero(err >= np.maximum(RTOL, 10 * cond))):
+                # must be explained by a kNN near-tie in some layer of THIS cloud (gap between the 20th and
+                # the 21st candidate below float32 resolution of the expanded-form distance), and stay small
+                assert err[p, c] < 1e-3
+                assert knn_min_margin(p, c, g, tag) < 2e-6, "cloud (%d,%d): error %.2e without a near-tie" % (p, c, err[p, c])
+        inter = interaction.compute_order_interaction(logits, lbl, args)
+        vmax = np.abs(hip_ops.reward(torch.from_numpy(want).reshape(-1, 10).to(dev()), label).cpu().numpy()).max()
+        tol = RTOL if name == "gcnn" else max(RTOL, 40 * float(cond.max()))
+        assert np.abs(inter - g["%s_%s_interaction" % (tag, name)]).max() < tol * vmax

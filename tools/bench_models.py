@@ -23,6 +23,9 @@ ap.add_argument("--perms", type=int, default=100)
 ap.add_argument("--batch", type=int, default=20, help="permutations per forward batch (config.py knob)")
 ap.add_argument("--regions", type=int, default=32)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--mode", default="shapley", choices=["shapley", "interaction"])
+ap.add_argument("--pairs", type=int, default=30)
+ap.add_argument("--contexts", type=int, default=100)
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -31,6 +34,10 @@ if a.model == "pointnet2":
     from interpret_quality_amd.pointnet2 import PointNet2ClsMsg
     model = PointNet2ClsMsg(None)
     model.load_state_dict(synth.to_torch(synth.pointnet2_state_dict(0)))
+elif a.model in ("dgcnn", "gcnn"):
+    from interpret_quality_amd.dgcnn import DGCNN_cls, GCNN_cls
+    model = (DGCNN_cls if a.model == "dgcnn" else GCNN_cls)(argparse.Namespace(dataset="modelnet10", k=20))
+    model.load_state_dict(synth.to_torch(synth.dgcnn_state_dict(0)))
 else:
     raise SystemExit("unknown model")
 model = model.to(dev).eval()
@@ -42,6 +49,25 @@ region_id = hip_ops.region_assign(data[0].contiguous(), hip_ops.fps(data, R)[0].
 orders = synth.make_orders(S, R, seed=1)
 args = argparse.Namespace(model=a.model, softmax_type="modified", num_points=1024, num_regions=R, num_samples=S,
                           shapley_batch_size=a.batch, verbose=False)
+if a.mode == "interaction":
+    # BASELINE configs[3] shape: pairs x contexts x 4 masked clouds (ratio 0.5 -> m = 15 of the 30 other regions)
+    from interpret_quality_amd import interaction
+    rng = np.random.default_rng(0)
+    all_pairs = np.array([[i, j] for i in range(R) for j in range(R) if j > i])
+    pairs = all_pairs[rng.choice(len(all_pairs), size=a.pairs, replace=False)]
+    ctx = np.stack([np.stack([rng.choice([r for r in range(R) if r not in pr], 15, replace=False) for _ in range(a.contexts)])
+                    for pr in pairs])
+    args.interaction_batch_size = a.batch
+    import contextlib, io
+
+    def run():
+        with contextlib.redirect_stdout(io.StringIO()):
+            return interaction.compute_order_interaction_logits(model, data, region_id, pairs, ctx, args)
+    n_per_step = a.pairs * a.contexts * 4
+else:
+    def run():
+        return final_common.shap_sampling_all_regions_batch(model, data, lbl, region_id, orders, args)
+    n_per_step = S * (R + 1)
 
 
 def read(slot):
@@ -50,17 +76,17 @@ def read(slot):
     return ms.value
 
 
-final_common.shap_sampling_all_regions_batch(model, data, lbl, region_id, orders, args)
+run()
 torch.cuda.synchronize()
 lib.iq_profile_enable(1)
 t0 = time.perf_counter()
 for _ in range(a.steps):
-    phi, logits = final_common.shap_sampling_all_regions_batch(model, data, lbl, region_id, orders, args)
+    phi, logits = run()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 lib.iq_profile_enable(0)
-n = S * (R + 1) * a.steps
+n = n_per_step * a.steps
 sa1, sa2, sa3, call = read(0), read(1), read(2), read(3)
-print("%s: %d coalitions in %.3f s = %.0f coalitions/s | per step: sa1 groups %.1f ms, sa2 groups %.1f ms, sa3 %.1f ms, "
+print("%s: %d coalitions in %.3f s = %.0f coalitions/s | per step: slot0 (sa1 | kNN) %.1f ms, slot1 (sa2 | EdgeConv) %.1f ms, slot2 (sa3 | conv5+pool) %.1f ms, "
       "whole forward calls %.1f ms of %.1f ms" % (a.model, n, dt, n / dt, sa1 / a.steps, sa2 / a.steps, sa3 / a.steps,
                                                    call / a.steps, dt / a.steps * 1e3))
