@@ -29,10 +29,21 @@ __global__ void pad_xyz_kernel(const float* __restrict__ xyz, float* __restrict_
 }
 
 // ---- xx[i] = sum_c x[i][c]^2 in channel order (torch.sum(x**2, dim=1)) ------------------------------
-__global__ void rownorm_kernel(const float* __restrict__ x, int ldx, int C, float* __restrict__ xx, int rows) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+// 64 rows per workgroup, staged through LDS so the global reads are coalesced; each row is still summed
+// sequentially over its channels by one lane.
+__global__ __launch_bounds__(64) void rownorm_kernel(const float* __restrict__ x, int ldx, int C, float* __restrict__ xx,
+                                                     int rows) {
+    __shared__ float tile[64 * 129];
+    const int r0 = blockIdx.x * 64;
+    const int ld = C + 1;
+    for (int e = threadIdx.x; e < 64 * C; e += 64) {
+        const int r = e / C, c = e - r * C;
+        tile[r * ld + c] = (r0 + r < rows) ? x[(size_t)(r0 + r) * ldx + c] : 0.f;
+    }
+    __syncthreads();
+    const int r = r0 + threadIdx.x;
     if (r >= rows) return;
-    const float* p = x + (size_t)r * ldx;
+    const float* p = tile + threadIdx.x * ld;
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += p[c] * p[c];
     xx[r] = s;
@@ -103,12 +114,27 @@ __global__ __launch_bounds__(kThreads, 2) void knn_kernel(const float* __restric
         const float* abase = keys[buf] + fl * LD + 4 * fh;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) acc = mfma4(lds_frag<LD>(abase, 0, kb), qf[kb], acc);
+        float d[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int jl = c_row(r, lane);
-            const float inner = -2.f * acc[r];                // -2 * matmul
-            const float d = ((-kxx[buf][jl]) - inner) - xxq;  // -xx - inner - xx^T   (models/dgcnn.py:15)
-            top.offer(d, t * 32 + jl);
+            const float inner = -2.f * acc[r];                              // -2 * matmul
+            d[r] = ((-kxx[buf][c_row(r, lane)]) - inner) - xxq;             // -xx - inner - xx^T (models/dgcnn.py:15)
+        }
+        // Insert only what beats the lane's current 20th best, best candidate first; the wave leaves the
+        // loop as soon as no lane has a candidate left (late tiles: 1-3 rounds instead of 16).
+        for (;;) {
+            float best = top.minv;
+            int br = -1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (d[r] > best) { best = d[r]; br = r; }
+            if (!__any(br >= 0)) break;
+            if (br >= 0) {
+                top.offer(best, t * 32 + c_row_i(br) + 4 * fh);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (r == br) d[r] = -INFINITY;
+            }
         }
         __syncthreads();
     }
@@ -244,7 +270,7 @@ extern "C" int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes,
         hipLaunchKernelGGL(pad_xyz_kernel, dim3((r + 255) / 256), dim3(256), 0, st, x, x0, (int)r);
         src = x0; ld = 8; cpad = 8;
     }
-    hipLaunchKernelGGL(rownorm_kernel, dim3((r + 255) / 256), dim3(256), 0, st, src, ld, C, xx, (int)r);
+    hipLaunchKernelGGL(rownorm_kernel, dim3((r + 63) / 64), dim3(64), 0, st, src, ld, C, xx, (int)r);
     int rc = launch_knn(src, ld, cpad, xx, i16, B, N, st);
     if (rc) return rc;
     hipLaunchKernelGGL(widen_idx_kernel, dim3((r * kK + 255) / 256), dim3(256), 0, st, i16, idx, r * kK);
@@ -275,7 +301,7 @@ extern "C" int iq_dgcnn_forward(const iq_dgcnn_weights* w, const float* xyz, flo
         IQ_REQUIRE(w->pq[l].cin == cin, "iq_dgcnn_forward: layer %d expects %d inputs, got %d", l, cin, w->pq[l].cin);
         if (l == 0 || !fixed_graph) {
             iq::ProfileSpan span(iq::kSlotPrepool, st);
-            hipLaunchKernelGGL(rownorm_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, src, ld, creal, s.xx, rows);
+            hipLaunchKernelGGL(rownorm_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, src, ld, creal, s.xx, rows);
             if ((rc = launch_knn(src, ld, cin, s.xx, s.idx, B, N, st))) return rc;
         }
         {

@@ -81,7 +81,7 @@ torch.cuda.synchronize()
 lib.iq_profile_enable(1)
 t0 = time.perf_counter()
 for _ in range(a.steps):
-    phi, logits = run()
+    run()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 lib.iq_profile_enable(0)
