@@ -1,0 +1,206 @@
+"""Stage 1 of scripts/exp_interaction.sh - host-side mirror of final_gen_pair.py: which region pairs
+and which contexts the interaction stages evaluate, and which pose is "adversarial".
+
+Everything random here is HOST NumPy on the global RNG, called in the reference's order, so for the
+same seed the artefacts (region_pair_list.npy, ratio*_context_list.npy) are the reference's.  The
+only device work is two dense forwards: all poses of a cloud in one batch (check_adv_success,
+final_gen_pair.py:221-286) and the prediction at a chosen pose (gen_pred_label, :74-88).
+"""
+import argparse
+import itertools
+import os
+
+import numpy as np
+import torch
+from scipy.special import comb
+
+from . import final_common
+from .final_util import (BALL_QUERY_COEF, cal_rank, get_folder_name_list, load_model, mkdir)
+from .interaction import DEFAULT_RATIOS
+from .pose_sweep import rotate_xyz, translate_pc
+from .shapley_stage import data_loader, finish_args
+
+
+def square_distance_np(x):
+    """tools/final_util.py:122-132."""
+    xx = np.sum(x ** 2, axis=1, keepdims=True)
+    return xx + xx.T - 2 * np.matmul(x, x.T)
+
+
+def ball_query(x, r):
+    """tools/final_util.py:150-160: boolean neighbour matrix of the region centres."""
+    return square_distance_np(x) < r ** 2
+
+
+def gen_context(region_pair_list, save_path, args):
+    """final_gen_pair.py:18-43.  For every ratio: m = int((R-2)*ratio) context regions per sample; at
+    most num_save_context_max sampled contexts per pair, all C(R-2, m) of them when there are fewer."""
+    for ratio in args.ratio:
+        m = int((args.num_regions - 2) * ratio)
+        per_pair = []
+        for region_i, region_j in region_pair_list:
+            rest = [r for r in range(args.num_regions) if r != region_i and r != region_j]
+            if comb(len(rest), m) > args.num_save_context_max:
+                per_pair.append([np.random.choice(rest, m, replace=False) for _ in range(args.num_save_context_max)])
+            else:
+                per_pair.append(list(itertools.combinations(rest, m)))
+        context_list = np.array(per_pair)  # (num_pairs, num_context, m)
+        print(context_list.shape)
+        np.save(save_path + "ratio%d_context_list.npy" % int(ratio * 100), context_list)
+
+
+def gen_pair_random(args):
+    """final_gen_pair.py:288-300: num_pairs_random distinct unordered pairs (i < j)."""
+    all_pairs = np.array([[i, j] for i in range(args.num_regions) for j in range(args.num_regions) if j > i])
+    return all_pairs[np.random.choice(all_pairs.shape[0], size=args.num_pairs_random, replace=False)]
+
+
+def gen_pair_single_region(region, neighbor_idx, args):
+    """final_gen_pair.py:127-142: (region, neighbour) for every ball-query neighbour except itself."""
+    neighbors = np.arange(args.num_regions)[neighbor_idx[region]]
+    return np.array([[region, n] for n in neighbors if n != region])
+
+
+def _interaction_folder(args, name):
+    return args.exp_folder + "%s/" % name + "interaction_seed%d/" % args.seed
+
+
+def save_pair_random(args, folder_name_list):
+    """final_gen_pair.py:302-320."""
+    print("gen pair random...")
+    for name in folder_name_list:
+        folder = _interaction_folder(args, name)
+        mkdir(folder + "normal/")
+        mkdir(folder + "%s_adv/" % args.mode)
+        np.save(folder + "region_pair_list.npy", gen_pair_random(args))
+
+
+def _dense_logits(model, clouds_cf, args):
+    out = model(clouds_cf)
+    return out[0] if args.model == "pointnet" else out
+
+
+def check_adv_success(args, disturb_fn, folder_name_list):
+    """final_gen_pair.py:221-286: one dense forward over all poses of each cloud; saves the pose with the
+    lowest reward on the true class (max attacking utility)."""
+    model = load_model(args)
+    with torch.no_grad():
+        for pc_idx, (data, lbl) in enumerate(data_loader(args)):
+            name = folder_name_list[pc_idx]
+            data, lbl = data.to(args.device), lbl.to(args.device)
+            base_folder = args.exp_folder + "%s/" % name
+            mode_folder = base_folder + "%s_all/" % args.mode
+            params = np.load(mode_folder + ("trans_vector.npy" if args.mode == "trans" else "angle_tuple.npy"))
+            poses = torch.cat([disturb_fn(data, torch.from_numpy(params[i]).to(args.device)) for i in range(params.shape[0])], dim=0)
+            logits = _dense_logits(model, poses.permute(0, 2, 1).contiguous(), args)
+            pred = torch.argmax(logits, dim=1)
+            print("%d poses are misclassified" % int((pred != lbl[0].item()).sum()))
+            v = final_common.get_reward(logits, lbl, args)
+            pose_idx = torch.argmin(v).item()
+            folder = _interaction_folder(args, name) + "%s_adv/" % args.mode
+            np.save(folder + "pose_idx.npy", pose_idx)
+            np.save(folder + "transform_params.npy", params[pose_idx])
+            print("Pose idx with max attacking utility: %d" % pose_idx)
+
+
+def save_pair_single_region(args, folder_name_list):
+    """final_gen_pair.py:145-218: per region, the poses of its largest / smallest Shapley value and the
+    pairs (region, neighbour) inside a ball of BALL_QUERY_COEF x cloud diameter around the region centre."""
+    print("gen pair single region...")
+    assert args.mode == "trans" or args.mode == "rotate"
+    for pc_idx, (data, _) in enumerate(data_loader(args)):
+        name = folder_name_list[pc_idx]
+        pts = data.cpu().numpy().squeeze()
+        base_folder = args.exp_folder + "%s/" % name
+        mode_folder = base_folder + "%s_all/" % args.mode
+        single = _interaction_folder(args, name) + "%s_adv_single_region/" % args.mode
+        mkdir(single)
+        region_id = np.load(base_folder + "region_id.npy")
+        phi = np.load(mode_folder + "region_shapley_value.npy")                 # (num_poses, R)
+        params = np.load(mode_folder + ("trans_vector.npy" if args.mode == "trans" else "angle_tuple.npy"))
+        max_pose, min_pose = np.argmax(phi, axis=0), np.argmin(phi, axis=0)
+        range_rank = args.num_regions - cal_rank(np.max(phi, axis=0) - np.min(phi, axis=0))  # 1 = largest range
+        diameter = np.sqrt(np.maximum(square_distance_np(pts), 0)).max()
+        centers = np.stack([pts[region_id == r].mean(axis=0) for r in range(args.num_regions)])
+        neighbor_idx = ball_query(centers, r=BALL_QUERY_COEF * diameter)
+        for region in range(args.num_regions):
+            folder = single + "range_rank%02d_region%02d/" % (range_rank[region], region)
+            for sub in ("normal/", "max_pose/", "min_pose/"):
+                mkdir(folder + sub)
+            np.save(folder + "max_pose/transform_params.npy", params[max_pose[region]])
+            np.save(folder + "max_pose/pose_idx.npy", max_pose[region])
+            np.save(folder + "min_pose/transform_params.npy", params[min_pose[region]])
+            np.save(folder + "min_pose/pose_idx.npy", min_pose[region])
+            pairs = gen_pair_single_region(region, neighbor_idx, args)
+            print(pairs.shape)
+            if len(pairs) == 0:
+                print("NO NEIGHBORS!!!")
+            np.save(folder + "region_pair_list.npy", pairs)
+
+
+def _region_folders(single):
+    if not os.path.isdir(single):
+        return []
+    return [single + d + "/" for d in sorted(os.listdir(single)) if os.path.isdir(single + d)]
+
+
+def save_context(args, folder_name_list):
+    """final_gen_pair.py:44-70."""
+    print("gen context start...")
+    for name in folder_name_list:
+        folder = _interaction_folder(args, name)
+        gen_context(np.load(folder + "region_pair_list.npy"), folder, args)
+        for region_folder in _region_folders(folder + "%s_adv_single_region/" % args.mode):
+            gen_context(np.load(region_folder + "region_pair_list.npy"), region_folder, args)
+
+
+def gen_pred_label(model, data, lbl, disturb_fn, save_path, args):
+    """final_gen_pair.py:74-88."""
+    params = torch.from_numpy(np.load(save_path + "transform_params.npy").astype(np.float32)).to(data.device)
+    logits = _dense_logits(model, disturb_fn(data, params).permute(0, 2, 1).contiguous(), args)
+    pred = torch.argmax(logits, dim=1)
+    with open(save_path + "pred_labels.txt", "w") as f:
+        f.write("lbl: %d\npred_lbl: %d\n" % (lbl[0].item(), pred[0].item()))
+    np.save(save_path + "pred_labels.npy", np.array([lbl[0].item(), pred[0].item()]))
+
+
+def save_pred_label(args, disturb_fn, folder_name_list):
+    """final_gen_pair.py:90-123."""
+    print("saving pred labels...")
+    model = load_model(args)
+    with torch.no_grad():
+        for pc_idx, (data, lbl) in enumerate(data_loader(args)):
+            data, lbl = data.to(args.device), lbl.to(args.device)
+            folder = _interaction_folder(args, folder_name_list[pc_idx])
+            gen_pred_label(model, data, lbl, disturb_fn, folder + "%s_adv/" % args.mode, args)
+            for region_folder in _region_folders(folder + "%s_adv_single_region/" % args.mode):
+                gen_pred_label(model, data, lbl, disturb_fn, region_folder + "max_pose/", args)
+                gen_pred_label(model, data, lbl, disturb_fn, region_folder + "min_pose/", args)
+
+
+def main(argv=None):
+    """final_gen_pair.py:323-374, same flags and stage order."""
+    p = argparse.ArgumentParser(description="Point Cloud Recognition")
+    p.add_argument("--model", type=str, default="pointnet", metavar="N",
+                   choices=["pointnet", "pointnet2", "pointconv", "dgcnn", "gcnn", "gcnn_adv"])
+    p.add_argument("--test_batch_size", type=int, default=1, metavar="batch_size", help="Size of batch)")
+    p.add_argument("--dataset", type=str, default="shapenet", metavar="N", choices=["modelnet10", "shapenet"])
+    p.add_argument("--no_cuda", type=bool, default=False, help="enables CUDA training")
+    p.add_argument("--seed", type=int, default=1, metavar="S", help="random seed (default: 1)")
+    p.add_argument("--device_id", type=int, default=0)
+    p.add_argument("--mode", default="rotate", type=str)
+    p.add_argument("--ratio", default=DEFAULT_RATIOS, type=int)
+    p.add_argument("--num_pairs_random", default=300, type=int)
+    p.add_argument("--num_save_context_max", default=100, type=int)
+    p.add_argument("--softmax_type", default="modified", type=str, choices=["normal", "modified"])
+    p.add_argument("--synthetic", action="store_true")
+    p.add_argument("--num_clouds", type=int, default=30)
+    args = p.parse_args(argv)
+    finish_args(args)
+    names = get_folder_name_list(args)
+    disturb_fn = translate_pc if args.mode == "trans" else rotate_xyz
+    save_pair_random(args, names)
+    check_adv_success(args, disturb_fn, names)
+    save_pair_single_region(args, names)
+    save_context(args, names)
+    save_pred_label(args, disturb_fn, names)

@@ -193,3 +193,35 @@ def test_pose_sweep_and_interaction_scripts(tmp_path, monkeypatch, oracle):
             want = oracle.compute_order_interaction(lg.cpu(), torch.tensor([lab]))
             assert got.shape == want.shape == (3, lg.shape[1] // 4)
             np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+
+
+def test_exp_interaction_full_pipeline_incl_gen_pair(tmp_path, monkeypatch):
+    """exp_shapley.sh (stage 1 + rotate sweep) then the complete exp_interaction.sh, synthetic cloud."""
+    from interpret_quality_amd import gen_pair
+    monkeypatch.chdir(tmp_path)
+    common = ["--model", "pointnet", "--dataset", "modelnet10", "--synthetic", "--num_clouds", "1"]
+    shapley_stage.main(common + ["--num_samples_save", "100"])
+    pose_sweep.main_rotate(common)
+    root = "checkpoints/exp_MODEL_pointnet_DATA_modelnet10_POINTNUM_1024_REGIONNUM_32_shapley_test/synthetic_00/"
+    assert np.load(root + "rotate_all/region_shapley_value.npy").shape == (216, 32)
+    gen_pair.main(common + ["--num_pairs_random", "4", "--num_save_context_max", "3"])
+    inter = root + "interaction_seed1/"
+    assert np.load(inter + "region_pair_list.npy").shape == (4, 2)
+    assert np.load(inter + "ratio50_context_list.npy").shape == (4, 3, 15)
+    assert np.load(inter + "ratio0_context_list.npy").shape == (4, 1, 0)
+    lab = np.load(inter + "rotate_adv/pred_labels.npy")
+    assert lab.shape == (2,) and lab[0] == 0
+    pose_idx = int(np.load(inter + "rotate_adv/pose_idx.npy"))
+    np.testing.assert_array_equal(np.load(inter + "rotate_adv/transform_params.npy"),
+                                  np.load(root + "rotate_all/angle_tuple.npy")[pose_idx])
+    singles = sorted(os.listdir(inter + "rotate_adv_single_region"))
+    assert len(singles) == 32 and singles[0].startswith("range_rank01_region")
+    interaction.main_logits(common)
+    interaction.main_cal(common)
+    for sub in ("normal/", "rotate_adv/", "rotate_adv_single_region/" + singles[0] + "/normal/"):
+        lg = torch.load(inter + sub + "ratio50_all_logits.pt")
+        it = np.load(inter + sub + "ratio50_pred_interaction.npy")
+        if lg.shape[0] == 0:   # a region without ball-query neighbours ("NO NEIGHBORS!!!"): empty, not a crash
+            assert it.shape[0] == 0
+        else:
+            assert lg.shape[1] == 12 and it.shape == (lg.shape[0], 3)

@@ -57,6 +57,28 @@ def test_pose_grids_and_perturbations_match_reference():
     np.testing.assert_array_equal(out[0, :4].numpy(), g["rotate_out_first4"])
 
 
+def test_gen_pair_and_context_reproduce_the_reference_rng_stream():
+    """final_gen_pair.py pair / context sampling: same NumPy calls in the same order as the reference."""
+    from interpret_quality_amd import gen_pair
+    g = load_golden("pointnet_interaction_R32.npz")
+    ratios = [float(r) for r in g["ratios"]]
+    args = argparse.Namespace(num_regions=32, num_pairs_random=len(g["pairs"]), num_save_context_max=6, ratio=ratios)
+    final_util.set_random(1)
+    pairs = gen_pair.gen_pair_random(args)
+    assert np.array_equal(pairs, g["pairs"])
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        gen_pair.gen_context(pairs, td + "/", args)
+        for ratio in ratios:
+            tag = "ratio%d" % int(ratio * 100)
+            ctx = np.load(td + "/%s_context_list.npy" % tag)
+            assert ctx.shape == g[tag + "_contexts"].shape and np.array_equal(ctx, g[tag + "_contexts"])
+    nb = np.zeros((32, 32), dtype=bool)
+    nb[3, [1, 3, 9]] = True
+    assert gen_pair.gen_pair_single_region(3, nb, args).tolist() == [[3, 1], [3, 9]]
+    assert gen_pair.gen_pair_single_region(5, nb, args).shape[0] == 0
+
+
 def test_shard_range_partitions():
     assert iqdist.shard_counts(300, 8) == [38, 38, 38, 38, 37, 37, 37, 37]  # SURVEY §8e
     assert iqdist.shard_counts(100, 8) == [13, 13, 13, 13, 12, 12, 12, 12]
