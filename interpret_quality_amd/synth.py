@@ -166,3 +166,51 @@ def dgcnn_state_dict(seed=0):
     _linear(sd, "linear2", 256, 512, seed, False, g)
     _linear(sd, "linear3", NUM_CLASSES, 256, seed, False, 1.0)
     return sd
+
+
+# --------------------------------------------------------------------------------------------
+# PointConv (models/pointconv.py:394-424): 226 tensors
+# --------------------------------------------------------------------------------------------
+PC_SA = [dict(npoint=512, nsample=32, in_channel=3, mlp=[64, 64, 128], bandwidth=0.1),
+         dict(npoint=128, nsample=64, in_channel=128 + 3, mlp=[128, 128, 256], bandwidth=0.2),
+         dict(npoint=1, nsample=None, in_channel=256 + 3, mlp=[256, 512, 1024], bandwidth=0.4)]
+
+
+PC_LINEAR_SCALE = (0.0244, 0.00617, 0.00377)
+
+
+def _bn_pos(sd, name, c, seed):
+    """BatchNorm with a positive shift, for the tiny scalar nets (keeps ReLU outputs alive)."""
+    _bn(sd, name, c, seed)
+    sd[name + ".bias"] = (np.abs(sd[name + ".bias"]) + 0.3).astype(np.float32)
+
+
+def pointconv_state_dict(seed=0):
+    """Reference-keyed PointConvDensityClsSsg state dict as numpy arrays."""
+    sd = {}
+    g = np.sqrt(2.0)
+    for k, cfg in enumerate(PC_SA, start=1):
+        p = "sa%d" % k
+        last = cfg["in_channel"]
+        for j, c in enumerate(cfg["mlp"]):
+            _conv2d(sd, "%s.mlp_convs.%d" % (p, j), c, last, seed, g * (3.0 if (k == 1 and j == 0) else 1.0))
+            _bn(sd, "%s.mlp_bns.%d" % (p, j), c, seed)
+            last = c
+        for net, dims in (("weightnet", [3, 8, 8, 16]), ("densitynet", [1, 16, 8, 1])):
+            for j in range(3):
+                name = "%s.%s.mlp_convs.%d" % (p, net, j)
+                _conv2d(sd, name, dims[j + 1], dims[j], seed, g * (3.0 if (net == "weightnet" and j == 0) else 1.0))
+                if net == "densitynet" or j > 0:  # non-negative weights on non-negative inputs: the scalar nets stay alive
+                    sd[name + ".weight"] = np.abs(sd[name + ".weight"])
+                _bn_pos(sd, "%s.%s.mlp_bns.%d" % (p, net, j), dims[j + 1], seed)
+        # the weighted sum over the K members is not normalised: keep the following linear layer's output O(1)
+        _linear(sd, p + ".linear", cfg["mlp"][-1], 16 * cfg["mlp"][-1], seed, False, g / (cfg["nsample"] or 128))
+        for f in ("weight", "bias"):  # empirical: brings the stage output to O(1) for the synthetic clouds
+            sd["%s.linear.%s" % (p, f)] = (sd["%s.linear.%s" % (p, f)] * PC_LINEAR_SCALE[k - 1]).astype(np.float32)
+        _bn(sd, p + ".bn_linear", cfg["mlp"][-1], seed)
+    _linear(sd, "fc1", 512, 1024, seed, False, g)
+    _bn(sd, "bn1", 512, seed)
+    _linear(sd, "fc2", 256, 512, seed, False, g)
+    _bn(sd, "bn2", 256, seed)
+    _linear(sd, "fc3", NUM_CLASSES, 256, seed, False, 1.0)
+    return sd

@@ -477,3 +477,85 @@ class DgcnnOracle:
     def __call__(self, x):
         with torch.no_grad():
             return dgcnn_forward(self.sd, x, self.k, self.fixed_graph)
+
+
+# --------------------------------------------------------------------------------------------
+# PointConv (models/pointconv.py)
+# --------------------------------------------------------------------------------------------
+
+def knn_point(nsample, xyz, new_xyz):
+    """models/pointconv.py:103-114 - the nsample smallest expanded-form distances, unsorted."""
+    return torch.topk(square_distance(new_xyz, xyz), nsample, dim=-1, largest=False, sorted=False)[1]
+
+
+def compute_density(xyz, bandwidth):
+    """models/pointconv.py:199-209 - Gaussian KDE over all points of the cloud."""
+    d = square_distance(xyz, xyz)
+    return (torch.exp(-d / (2.0 * bandwidth * bandwidth)) / (2.5 * bandwidth)).mean(dim=-1)
+
+
+def _scalar_net(x, sd, prefix):
+    """DensityNet / WeightNet (models/pointconv.py:212-265): three 1x1 conv + BN + ReLU layers (the sigmoid branch
+    of DensityNet is unreachable: `i == len(self.mlp_convs)` is never true, :228-231)."""
+    for j in range(3):
+        x = _conv2d_bn_relu(x, sd, "%s.mlp_convs.%d" % (prefix, j), "%s.mlp_bns.%d" % (prefix, j))
+    return x
+
+
+def pointconv_sa(sd, name, npoint, nsample, bandwidth, group_all, xyz_cf, points_cf, return_aux=False):
+    """models/pointconv.py:324-391 - PointConvDensitySetAbstraction.forward."""
+    xyz = xyz_cf.permute(0, 2, 1)
+    points = points_cf.permute(0, 2, 1) if points_cf is not None else None
+    b, n, _ = xyz.shape
+    inv_density = 1.0 / compute_density(xyz, bandwidth)
+    aux = {}
+    if group_all:
+        new_xyz = xyz.mean(dim=1, keepdim=True)
+        g_xyz = xyz.reshape(b, 1, n, 3) - new_xyz.reshape(b, 1, 1, 3)
+        new_points = torch.cat([g_xyz, points.reshape(b, 1, n, -1)], dim=-1) if points is not None else g_xyz
+        g_density = inv_density.reshape(b, 1, n, 1)
+        s = 1
+    else:
+        fps = farthest_point_sample(xyz, npoint)
+        new_xyz = index_points(xyz, fps)
+        idx = knn_point(nsample, xyz, new_xyz)
+        aux = {"fps": fps, "knn": idx}
+        g_xyz = index_points(xyz, idx) - new_xyz.reshape(b, npoint, 1, 3)
+        new_points = torch.cat([g_xyz, index_points(points, idx)], dim=-1) if points is not None else g_xyz  # xyz FIRST
+        g_density = index_points(inv_density.reshape(b, n, 1), idx)
+        s = npoint
+    h = new_points.permute(0, 3, 2, 1)  # (B, C, K, S)
+    for j in range(3):
+        h = _conv2d_bn_relu(h, sd, "%s.mlp_convs.%d" % (name, j), "%s.mlp_bns.%d" % (name, j))
+    scale = g_density / g_density.max(dim=2, keepdim=True)[0]
+    h = h * _scalar_net(scale.permute(0, 3, 2, 1), sd, name + ".densitynet")
+    w = _scalar_net(g_xyz.permute(0, 3, 2, 1), sd, name + ".weightnet")
+    out = torch.matmul(h.permute(0, 3, 1, 2), w.permute(0, 3, 2, 1)).reshape(b, s, -1)
+    out = F.linear(out, sd[name + ".linear.weight"], sd[name + ".linear.bias"])
+    out = F.relu(_bn(out.permute(0, 2, 1), sd, name + ".bn_linear"))
+    res = (new_xyz.permute(0, 2, 1), out)
+    return res + (aux,) if return_aux else res
+
+
+def pointconv_forward(sd, xyz_cf, return_aux=False):
+    """models/pointconv.py:414-424 - eval-mode PointConvDensityClsSsg.  (B,3,N) -> logits (B,10)."""
+    b = xyz_cf.shape[0]
+    r1 = pointconv_sa(sd, "sa1", 512, 32, 0.1, False, xyz_cf, None, return_aux)
+    r2 = pointconv_sa(sd, "sa2", 128, 64, 0.2, False, r1[0], r1[1], return_aux)
+    r3 = pointconv_sa(sd, "sa3", 1, None, 0.4, True, r2[0], r2[1], return_aux)
+    x = r3[1].reshape(b, 1024)
+    x = F.relu(_bn(_fc(x, sd, "fc1"), sd, "bn1"))
+    x = F.relu(_bn(_fc(x, sd, "fc2"), sd, "bn2"))
+    logits = _fc(x, sd, "fc3")
+    if return_aux:
+        return logits, {"sa1": r1[2], "sa2": r2[2], "l1_points": r1[1], "l2_points": r2[1], "l1_xyz": r1[0]}
+    return logits
+
+
+class PointConvOracle:
+    def __init__(self, state_dict):
+        self.sd = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))) for k, v in state_dict.items()}
+
+    def __call__(self, x):
+        with torch.no_grad():
+            return pointconv_forward(self.sd, x)

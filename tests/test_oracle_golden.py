@@ -169,3 +169,29 @@ def test_dgcnn_oracle_matches_reference():
                 np.testing.assert_allclose(lg.numpy(), g["%s_%s_logits" % (tag, name)], rtol=1e-5, atol=1e-5)
                 inter = O.compute_order_interaction(torch.from_numpy(g["%s_%s_logits" % (tag, name)]), lbl)
                 np.testing.assert_array_equal(inter, g["%s_%s_interaction" % (tag, name)])
+
+
+def test_pointconv_oracle_matches_reference():
+    g = load_golden("pointconv.npz")
+    sd = synth.to_torch(synth.pointconv_state_dict(0))
+    pts, label = synth.make_cloud(0)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    lbl = torch.tensor([label])
+    center = torch.mean(data, dim=1).squeeze()
+    masked = O.shapley_masked_batch(data, center, g["orders"], g["region_id"])
+    x = masked.permute(0, 2, 1).contiguous()
+    sel = list(g["sel"])
+    with torch.no_grad():
+        xyz = x[sel].permute(0, 2, 1)
+        np.testing.assert_allclose(O.compute_density(xyz, 0.1).numpy(), g["density_sa1"], rtol=1e-6)
+        logits, aux = O.pointconv_forward(sd, x[sel], return_aux=True)
+        got, want = aux["sa1"]["knn"].numpy(), g["knn_sa1"]
+        for b in range(got.shape[0]):   # unsorted top-k: compare as sets
+            assert all(set(got[b, s].tolist()) == set(want[b, s].tolist()) for s in range(got.shape[1]))
+        np.testing.assert_allclose(aux["l1_points"][:, :8, :].numpy(), g["l1_points_first8"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(aux["l2_points"][:, :8, :].numpy(), g["l2_points_first8"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(logits.numpy(), g["logits"][sel], rtol=1e-5, atol=1e-5)
+    phi, lg = O.shap_sampling_all_regions_batch(lambda t: (O.pointconv_forward(sd, t),), data, lbl, g["region_id"], g["orders"],
+                                                2, 2, 8)
+    np.testing.assert_allclose(lg.numpy(), g["shap_logits"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(phi, g["phi"], rtol=1e-5, atol=1e-6)
