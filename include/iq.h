@@ -231,6 +231,37 @@ int iq_dgcnn_forward(const iq_dgcnn_weights* w /*host struct of device pointers*
                      float* logits, void* workspace, size_t workspace_bytes, int B, int N,
                      int fixed_graph, iq_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * PointConv with density (models/pointconv.py:103-424)
+ * ------------------------------------------------------------------------------------------- */
+
+/* One PointConvDensitySetAbstraction (BN folded).  Layer 1 of the shared MLP is split:
+ * relu(w1x . (x_p - c) + U_p) with U = u(features) (bias inside; sa1 has no features: bias in w1x[3]).
+ * densitynet: rows [w | b] of 1->16->8->1 (32 + 136 + 9 floats); weightnet: 3->8->8->16 (32 + 72 + 144). */
+typedef struct iq_pointconv_sa {
+    const float* w1x;         /* [C1][4] = (wx0, wx1, wx2, bias) */
+    iq_dense_layer u;         /* features -> C1 (unused for sa1) */
+    iq_dense_layer l2, l3;
+    const float* densitynet;
+    const float* weightnet;
+    iq_dense_layer linear;    /* 16*C3 -> C3, + bn_linear, ReLU */
+    float bandwidth;
+    int32_t nsample;          /* 32, 64, 0 = group all */
+} iq_pointconv_sa;
+
+typedef struct iq_pointconv_weights {
+    iq_pointconv_sa sa[3];
+    iq_dense_layer fc1, fc2, fc3;
+} iq_pointconv_weights;
+
+size_t iq_pointconv_workspace_bytes(int B, int N);
+
+/* Eval-mode PointConvDensityClsSsg.forward (models/pointconv.py:414-424) on B materialised clouds.
+ * xyz (B,N,3) channel-last -> logits (B,10). */
+int iq_pointconv_forward(const iq_pointconv_weights* w /*host struct of device pointers*/, const float* xyz,
+                         float* logits, void* workspace, size_t workspace_bytes, int B, int N,
+                         iq_stream_t stream);
+
 /* Optional HIP-event profiler (bench.py's roofline leg).  While enabled, iq_pointnet_coalitions
  * brackets its chain-kernel launches with hipEvents recorded on the launch stream.
  * iq_profile_read(slot) synchronises on the recorded events of that slot, returns their summed

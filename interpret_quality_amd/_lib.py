@@ -46,6 +46,16 @@ class PointNet2Weights(ctypes.Structure):
                 ("fc1", DenseLayer), ("fc2", DenseLayer), ("fc3", DenseLayer)]
 
 
+class PointConvSa(ctypes.Structure):
+    _fields_ = [("w1x", ctypes.c_void_p), ("u", DenseLayer), ("l2", DenseLayer), ("l3", DenseLayer),
+                ("densitynet", ctypes.c_void_p), ("weightnet", ctypes.c_void_p), ("linear", DenseLayer),
+                ("bandwidth", ctypes.c_float), ("nsample", ctypes.c_int32)]
+
+
+class PointConvWeights(ctypes.Structure):
+    _fields_ = [("sa", PointConvSa * 3), ("fc1", DenseLayer), ("fc2", DenseLayer), ("fc3", DenseLayer)]
+
+
 class DgcnnWeights(ctypes.Structure):
     _fields_ = [("pq", DenseLayer * 4), ("conv5", DenseLayer), ("fc1", DenseLayer), ("fc2", DenseLayer),
                 ("fc3", DenseLayer), ("k", ctypes.c_int32)]
@@ -81,6 +91,8 @@ SIGNATURES = {
     "iq_knn": (_I, [_P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
     "iq_dgcnn_workspace_bytes": (_SZ, [_I, _I]),
     "iq_dgcnn_forward": (_I, [ctypes.POINTER(DgcnnWeights), _P, _P, _P, _SZ, _I, _I, _I, _P]),
+    "iq_pointconv_workspace_bytes": (_SZ, [_I, _I]),
+    "iq_pointconv_forward": (_I, [ctypes.POINTER(PointConvWeights), _P, _P, _P, _SZ, _I, _I, _P]),
     "iq_profile_enable": (_I, [_I]),
     "iq_set_tuning": (_I, [_I, _I]),
     "iq_debug_chain_occupancy": (_I, []),

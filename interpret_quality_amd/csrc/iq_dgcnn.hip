@@ -13,6 +13,7 @@
 #include "iq_common.h"
 #include "iq_mfma.h"
 #include "iq_profile.h"
+#include "iq_topk.h"
 
 namespace {
 
@@ -50,29 +51,6 @@ __global__ __launch_bounds__(64) void rownorm_kernel(const float* __restrict__ x
 }
 
 // ---- kNN ------------------------------------------------------------------------------------------
-struct TopK {
-    float v[kK];
-    int i[kK];
-    float minv;
-    int minp;
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int q = 0; q < kK; ++q) { v[q] = -INFINITY; i[q] = 0; }
-        minv = -INFINITY; minp = 0;
-    }
-    __device__ __forceinline__ void offer(float val, int idx) {
-        if (val > minv) {
-#pragma unroll
-            for (int q = 0; q < kK; ++q)
-                if (q == minp) { v[q] = val; i[q] = idx; }
-            minv = v[0]; minp = 0;
-#pragma unroll
-            for (int q = 1; q < kK; ++q)
-                if (v[q] < minv) { minv = v[q]; minp = q; }
-        }
-    }
-};
-
 template <int C>
 __global__ __launch_bounds__(kThreads, 2) void knn_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ xx,
                                                           int16_t* __restrict__ idx, int N) {
@@ -102,7 +80,7 @@ __global__ __launch_bounds__(kThreads, 2) void knn_kernel(const float* __restric
         if (tid < 32) kxx[buf][tid] = xxb[tile * 32 + tid];
     };
 
-    TopK top;
+    TopK<kK> top;
     top.init();
     const int ntiles = N / 32;
     stage(0, 0);
@@ -120,31 +98,10 @@ __global__ __launch_bounds__(kThreads, 2) void knn_kernel(const float* __restric
             const float inner = -2.f * acc[r];                              // -2 * matmul
             d[r] = ((-kxx[buf][c_row(r, lane)]) - inner) - xxq;             // -xx - inner - xx^T (models/dgcnn.py:15)
         }
-        // Insert only what beats the lane's current 20th best, best candidate first; the wave leaves the
-        // loop as soon as no lane has a candidate left (late tiles: 1-3 rounds instead of 16).
-        for (;;) {
-            float best = top.minv;
-            int br = -1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (d[r] > best) { best = d[r]; br = r; }
-            if (!__any(br >= 0)) break;
-            if (br >= 0) {
-                top.offer(best, t * 32 + c_row_i(br) + 4 * fh);
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (r == br) d[r] = -INFINITY;
-            }
-        }
+        top.offer_tile(d, t * 32, fh);
         __syncthreads();
     }
-    // merge the two half-waves (each saw half of the keys of every tile)
-    float pv[kK];
-    int pi[kK];
-#pragma unroll
-    for (int q = 0; q < kK; ++q) { pv[q] = __shfl_xor(top.v[q], 32); pi[q] = __shfl_xor(top.i[q], 32); }
-#pragma unroll
-    for (int q = 0; q < kK; ++q) top.offer(pv[q], pi[q]);
+    top.merge_halves();  // each half-wave saw half of the keys of every tile
     if (fh == 0) {
         int16_t* o = idx + ((size_t)b * N + q0 + fl) * kK;
 #pragma unroll

@@ -1,0 +1,528 @@
+// PointConv (density) forward (models/pointconv.py:103-424) on materialised (masked) clouds.
+//
+// Per set abstraction:  Gaussian KDE density -> FPS -> K nearest (expanded-form distance, index set) ->
+// shared MLP on [x_p - c ; f_p] -> x DensityNet(inverse density / group max) -> contraction with
+// WeightNet(x_p - c) over the K members: out[c][w] = sum_k h[k][c] s_k wt[k][w] -> Linear(16 C -> C)+BN+ReLU.
+// Members are SUMMED here, so (unlike the max-pooled families) duplicates count with their multiplicity
+// and nothing is skipped.  Layer 1 of sa2 / sa3 uses the exact linear split
+// W.[x_p - c ; f_p] = W_x (x_p - c) + (W_f f_p + b); the per-point part is one batched GEMM.
+// Grouped kernel: 64-row chunks -> LDS act1 -> MFMA C1->C2 -> LDS act2 -> MFMA C2->C3 -> the contraction runs
+// on the accumulator tiles in registers (16 rows x 16 weights per lane and tile), so the (C3 x K) member
+// features never leave the CU.
+#include "iq_common.h"
+#include "iq_mfma.h"
+#include "iq_profile.h"
+#include "iq_topk.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMC = 64;
+
+__global__ void pc_gather_xyz_kernel(const float* __restrict__ xyz, int ldx, const int32_t* __restrict__ idx,
+                                     float* __restrict__ out, int N, int S, int total) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int b = t / S;
+    const float* src = xyz + ((size_t)b * N + idx[t]) * ldx;
+    out[t * 3] = src[0]; out[t * 3 + 1] = src[1]; out[t * 3 + 2] = src[2];
+}
+
+__global__ void pc_compact_xyz_kernel(const float* __restrict__ xyz, int ldx, float* __restrict__ out, int total) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const float* src = xyz + (size_t)t * ldx;
+    out[t * 3] = src[0]; out[t * 3 + 1] = src[1]; out[t * 3 + 2] = src[2];
+}
+
+// ---- inverse Gaussian KDE density (models/pointconv.py:199-209, :352) --------------------------------
+// inv[i] = 1 / mean_j( exp(-d_ij / (2 bw^2)) / (2.5 bw) ),  d = -2 x_i.x_j + |x_i|^2 + |x_j|^2
+__global__ __launch_bounds__(kThreads) void pc_density_kernel(const float* __restrict__ xyz, float bw,
+                                                              float* __restrict__ inv_density, int N) {
+    extern __shared__ float pts[];  // N x 4
+    const int b = blockIdx.y;
+    const float* src = xyz + (size_t)b * N * 3;
+    for (int p = threadIdx.x; p < N; p += kThreads) {
+        const float x = src[p * 3], y = src[p * 3 + 1], z = src[p * 3 + 2];
+        pts[p * 4] = x; pts[p * 4 + 1] = y; pts[p * 4 + 2] = z; pts[p * 4 + 3] = (x * x + y * y) + z * z;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= N) return;
+    const f32x4 q = *reinterpret_cast<const f32x4*>(pts + i * 4);
+    const float c0 = 2.0f * bw * bw, c1 = 2.5f * bw;
+    float s = 0.f;
+    for (int j = 0; j < N; ++j) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(pts + j * 4);
+        const float dot = fmaf(q[2], v[2], fmaf(q[1], v[1], q[0] * v[0]));
+        const float d = (-2.f * dot + q[3]) + v[3];
+        s += expf(-d / c0) / c1;
+    }
+    inv_density[(size_t)b * N + i] = 1.0f / (s / (float)N);
+}
+
+// ---- K nearest points (models/pointconv.py:103-114): queries on the lanes, keys on the accumulator rows ----
+template <int K>
+__global__ __launch_bounds__(kThreads, 1) void pc_knn_kernel(const float* __restrict__ keys8 /*(B,N,8)*/,
+                                                             const float* __restrict__ q8 /*(B,S,8)*/,
+                                                             int16_t* __restrict__ idx /*(B,S,K)*/, int N, int S) {
+    constexpr int LD = 12;
+    __shared__ __attribute__((aligned(16))) float tile[2][32 * LD];
+    __shared__ float kxx[2][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const float* kb = keys8 + (size_t)b * N * 8;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int fl = lane & 31, fh = lane >> 5;
+    const int qrow = min(q0 + fl, S - 1);
+    const float* qp = q8 + ((size_t)b * S + qrow) * 8;
+    const f32x4 qf = *reinterpret_cast<const f32x4*>(qp + 4 * fh);
+    const float xxq = (qp[0] * qp[0] + qp[1] * qp[1]) + qp[2] * qp[2];
+
+    auto stage = [&](int t, int buf) {
+        if (tid < 64) {
+            const int row = tid >> 1, half = tid & 1;
+            *reinterpret_cast<f32x4*>(&tile[buf][row * LD + half * 4]) =
+                *reinterpret_cast<const f32x4*>(kb + (size_t)(t * 32 + row) * 8 + half * 4);
+        }
+        if (tid >= 64 && tid < 96) {
+            const float* p = kb + (size_t)(t * 32 + tid - 64) * 8;
+            kxx[buf][tid - 64] = (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2];
+        }
+    };
+    TopK<K> top;
+    top.init();
+    const int ntiles = N / 32;
+    stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+        f32x16 acc = {0};
+        acc = mfma4(lds_frag<LD>(tile[buf] + fl * LD + 4 * fh, 0, 0), qf, acc);
+        float d[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)  // -(((-2 q.p) + |q|^2) + |p|^2): largest = nearest
+            d[r] = -(((-2.f * acc[r]) + xxq) + kxx[buf][c_row(r, lane)]);
+        top.offer_tile(d, t * 32, fh);
+        __syncthreads();
+    }
+    top.merge_halves();
+    if (fh == 0 && q0 + fl < S) {
+        int16_t* o = idx + ((size_t)b * S + q0 + fl) * K;
+#pragma unroll
+        for (int q = 0; q < K; ++q) o[q] = (int16_t)top.i[q];
+    }
+}
+
+// ---- the two tiny per-member nets (models/pointconv.py:212-265), BN folded: [w | b] rows ---------------------
+struct TinyNets {
+    const float* dn;  // densitynet: l0 16x(1+1), l1 8x(16+1), l2 1x(8+1)  = 32 + 136 + 9 floats
+    const float* wn;  // weightnet : l0 8x(3+1),  l1 8x(8+1),  l2 16x(8+1) = 32 + 72 + 144 floats
+};
+
+__device__ __forceinline__ float density_net(const float* __restrict__ p, float rho) {
+    float h0[16], h1[8];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) h0[o] = fmaxf(fmaf(p[o * 2], rho, p[o * 2 + 1]), 0.f);
+    p += 32;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        float a = p[o * 17 + 16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a = fmaf(p[o * 17 + i], h0[i], a);
+        h1[o] = fmaxf(a, 0.f);
+    }
+    p += 136;
+    float a = p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a = fmaf(p[i], h1[i], a);
+    return fmaxf(a, 0.f);
+}
+
+__device__ __forceinline__ void weight_net(const float* __restrict__ p, float dx, float dy, float dz, float (&out)[16]) {
+    float h0[8], h1[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) h0[o] = fmaxf(fmaf(p[o * 4 + 2], dz, fmaf(p[o * 4 + 1], dy, fmaf(p[o * 4], dx, p[o * 4 + 3]))), 0.f);
+    p += 32;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        float a = p[o * 9 + 8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a = fmaf(p[o * 9 + i], h0[i], a);
+        h1[o] = fmaxf(a, 0.f);
+    }
+    p += 72;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+        float a = p[o * 9 + 8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a = fmaf(p[o * 9 + i], h1[i], a);
+        out[o] = fmaxf(a, 0.f);
+    }
+}
+
+// ---- grouped MLP + density scale + WeightNet contraction ------------------------------------------------------
+struct PcGroupArgs {
+    const float* xyz;          // (B,N,3) member coordinates
+    const float* new_xyz;      // (B,S,3) centroids
+    const int16_t* idx;        // (B,S,K)
+    const float* inv_density;  // (B,N)
+    const float* U;            // (B,N,ldu) per-point part of layer 1 (bias included) or null
+    int ldu;
+    const float* w1x;          // [C1][4] = (wx0, wx1, wx2, bias)
+    const float* w2; const float* b2;
+    const float* w3; const float* b3;
+    TinyNets nets;
+    float* out;                // (B,S,C3*16): [c][w]
+    int N, S, K;
+};
+
+template <int C1, int C2, int C3>
+__global__ __launch_bounds__(kThreads, 2) void pc_group_kernel(PcGroupArgs a) {
+    constexpr int LD1 = C1 + 4, LD2 = C2 + 4;
+    constexpr int KB1 = C1 / 8, KB2 = C2 / 8, NT2 = C2 / 32, NT3 = C3 / 32;
+    static_assert(NT3 >= 4, "C3 >= 128");
+    constexpr int NR = kMC * C1 / kThreads;
+    __shared__ __attribute__((aligned(16))) float act1[kMC * LD1];
+    __shared__ __attribute__((aligned(16))) float act2[kMC * LD2];
+    __shared__ __attribute__((aligned(16))) float rel[kMC * 4];   // dx,dy,dz, member index (bits)
+    __shared__ __attribute__((aligned(16))) float sw[kMC * 16];   // density scale x WeightNet output per member
+    __shared__ float rho[kMC];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int K = a.K;                       // 32 (two groups per chunk) or 64 (one group per chunk)
+    const int gpc = kMC / K;                 // groups per chunk
+    const int g_first = blockIdx.x * gpc;    // one chunk per workgroup
+    if (g_first >= a.S) return;
+    const int fl = lane & 31, fh = lane >> 5;
+    const float* a1base = act1 + fl * LD1 + 4 * fh;
+    const float* a2base = act2 + fl * LD2 + 4 * fh;
+    float* c2base = act2 + (4 * fh) * LD2 + fl;
+
+    // ---- stage 0a: members, relative coordinates, inverse densities ------------------------------------
+    if (tid < kMC) {
+        const int g = min(g_first + tid / K, a.S - 1), k = tid % K;
+        const int p = a.idx[((size_t)b * a.S + g) * K + k];
+        const float* x = a.xyz + ((size_t)b * a.N + p) * 3;
+        const float* c = a.new_xyz + ((size_t)b * a.S + g) * 3;
+        f32x4 v;
+        v[0] = x[0] - c[0]; v[1] = x[1] - c[1]; v[2] = x[2] - c[2];
+        v[3] = __int_as_float(p);
+        *reinterpret_cast<f32x4*>(rel + tid * 4) = v;
+        rho[tid] = a.inv_density[(size_t)b * a.N + p];
+    }
+    __syncthreads();
+    // ---- stage 0b: DensityNet(rho / group max) x WeightNet(dx) -> sw; layer 1 -> act1 ----------------------
+    if (tid < kMC) {
+        const int g0 = (tid / K) * K;
+        float mx = rho[g0];
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, rho[g0 + k]);
+        const float s = density_net(a.nets.dn, rho[tid] / mx);
+        float wt[16];
+        weight_net(a.nets.wn, rel[tid * 4], rel[tid * 4 + 1], rel[tid * 4 + 2], wt);
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4)
+            *reinterpret_cast<f32x4*>(sw + tid * 16 + w4 * 4) =
+                (f32x4){s * wt[w4 * 4], s * wt[w4 * 4 + 1], s * wt[w4 * 4 + 2], s * wt[w4 * 4 + 3]};
+    }
+    {
+        const int chn = tid % C1, rsub = tid / C1;
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.w1x + chn * 4);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = rsub + i * (kThreads / C1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rel + r * 4);
+            float h = fmaf(w1[2], v[2], fmaf(w1[1], v[1], w1[0] * v[0])) + w1[3];
+            if (a.U) h += a.U[((size_t)b * a.N + __float_as_int(v[3])) * a.ldu + chn];
+            act1[r * LD1 + chn] = fmaxf(h, 0.f);
+        }
+    }
+    WRing ring2, ring3;
+    if (NT2 >= 4) wring_prime(ring2, a.w2 + (size_t)wave * KB1 * 256, lane);
+    __syncthreads();
+    // ---- layer 2 -------------------------------------------------------------------------------------------------
+    if (NT2 >= 4) {
+#pragma unroll
+        for (int q = 0; q < NT2 / 4; ++q) {
+            const int nt = q * 4 + wave;
+            f32x16 acc0 = {0}, acc1 = {0};
+            const float* wq = a.w2 + (size_t)nt * KB1 * 256;
+            const float* wn = a.w2 + (size_t)(q + 1 < NT2 / 4 ? nt + 4 : nt) * KB1 * 256;
+            mfma_ntile<LD1, KB1, 2>(a1base, wq, wn, lane, ring2, acc0, acc1);
+            const float bias = a.b2[nt * 32 + fl];
+            float* dst = c2base + nt * 32;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                dst[c_row_i(i) * LD2] = fmaxf(acc0[i] + bias, 0.f);
+                dst[(32 + c_row_i(i)) * LD2] = fmaxf(acc1[i] + bias, 0.f);
+            }
+        }
+    } else {
+        for (int t = wave; t < 2 * NT2; t += 4) {
+            const int mt = t / NT2, nt = t - mt * NT2;
+            f32x16 acc = {0};
+            const float* wq = a.w2 + (size_t)nt * KB1 * 256;
+#pragma unroll 4
+            for (int kb = 0; kb < KB1; ++kb)
+                acc = mfma4(lds_frag<LD1>(a1base + mt * 32 * LD1, 0, kb), glb_b(wq + kb * 256, lane), acc);
+            const float bias = a.b2[nt * 32 + fl];
+            float* dst = c2base + mt * 32 * LD2 + nt * 32;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[c_row_i(i) * LD2] = fmaxf(acc[i] + bias, 0.f);
+        }
+    }
+    wring_prime(ring3, a.w3 + (size_t)wave * KB2 * 256, lane);
+    __syncthreads();
+    // ---- layer 3 + contraction over the members -------------------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < NT3 / 4; ++q) {
+        const int nt = q * 4 + wave;
+        f32x16 acc0 = {0}, acc1 = {0};
+        const float* wq = a.w3 + (size_t)nt * KB2 * 256;
+        const float* wn = a.w3 + (size_t)(q + 1 < NT3 / 4 ? nt + 4 : nt) * KB2 * 256;
+        mfma_ntile<LD2, KB2, 2>(a2base, wq, wn, lane, ring3, acc0, acc1);
+        const float bias = a.b3[nt * 32 + fl];
+        float o0[16], o1[16];   // per m-tile: sum over its 16 rows (this half-wave) of h[row][c] * sw[row][w]
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { o0[w] = 0.f; o1[w] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float h0 = fmaxf(acc0[r] + bias, 0.f), h1 = fmaxf(acc1[r] + bias, 0.f);
+            const float* s0 = sw + (c_row_i(r) + 4 * fh) * 16;
+            const float* s1 = s0 + 32 * 16;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(s0 + w4 * 4);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(s1 + w4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0[w4 * 4 + e] = fmaf(h0, x0[e], o0[w4 * 4 + e]);
+                    o1[w4 * 4 + e] = fmaf(h1, x1[e], o1[w4 * 4 + e]);
+                }
+            }
+        }
+        const int c = nt * 32 + fl;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            o0[w] += __shfl_xor(o0[w], 32);
+            o1[w] += __shfl_xor(o1[w], 32);
+        }
+        if (K == 64) {          // one group: both m-tiles
+            if (fh == 0) {
+                float* dst = a.out + ((size_t)b * a.S + g_first) * (C3 * 16) + c * 16;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4)
+                    *reinterpret_cast<f32x4*>(dst + w4 * 4) = (f32x4){o0[w4 * 4] + o1[w4 * 4], o0[w4 * 4 + 1] + o1[w4 * 4 + 1],
+                                                                      o0[w4 * 4 + 2] + o1[w4 * 4 + 2], o0[w4 * 4 + 3] + o1[w4 * 4 + 3]};
+            }
+        } else {                // K == 32: m-tile 0 = group g_first, m-tile 1 = g_first + 1; half-waves split the stores
+            const int g = g_first + fh;
+            if (g < a.S) {
+                float* dst = a.out + ((size_t)b * a.S + g) * (C3 * 16) + c * 16;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4)
+                    *reinterpret_cast<f32x4*>(dst + w4 * 4) = fh == 0
+                        ? (f32x4){o0[w4 * 4], o0[w4 * 4 + 1], o0[w4 * 4 + 2], o0[w4 * 4 + 3]}
+                        : (f32x4){o1[w4 * 4], o1[w4 * 4 + 1], o1[w4 * 4 + 2], o1[w4 * 4 + 3]};
+            }
+        }
+    }
+}
+
+// ---- sa3 (group all, models/pointconv.py:147-167) helpers ----------------------------------------------------------
+// mean centre, relative coordinates, density scale and WeightNet for the S points of each cloud; layer 1.
+__global__ __launch_bounds__(128) void pc_all_prepare_kernel(const float* __restrict__ xyz /*(B,S,3)*/,
+                                                             const float* __restrict__ inv_density, TinyNets nets,
+                                                             const float* __restrict__ w1x /*[C1][4]*/,
+                                                             const float* __restrict__ U /*(B,S,C1)*/, int C1,
+                                                             float* __restrict__ h1 /*(B,S,C1)*/,
+                                                             float* __restrict__ sw /*(B,S,16)*/, int S) {
+    __shared__ float red[128 * 4];
+    __shared__ float rels[128 * 3];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* p = xyz + ((size_t)b * S + t) * 3;
+    const float x = t < S ? p[0] : 0.f, y = t < S ? p[1] : 0.f, z = t < S ? p[2] : 0.f;
+    const float rho = t < S ? inv_density[(size_t)b * S + t] : -INFINITY;
+    red[t * 4] = x; red[t * 4 + 1] = y; red[t * 4 + 2] = z; red[t * 4 + 3] = rho;
+    __syncthreads();
+    float mx = 0.f, my = 0.f, mz = 0.f, mr = -INFINITY;
+    for (int i = 0; i < S; ++i) { mx += red[i * 4]; my += red[i * 4 + 1]; mz += red[i * 4 + 2]; mr = fmaxf(mr, red[i * 4 + 3]); }
+    mx /= (float)S; my /= (float)S; mz /= (float)S;   // xyz.mean(dim=1)
+    const float dx = x - mx, dy = y - my, dz = z - mz;
+    if (t < S) {
+        const float s = density_net(nets.dn, rho / mr);
+        float wt[16];
+        weight_net(nets.wn, dx, dy, dz, wt);
+        float* o = sw + ((size_t)b * S + t) * 16;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) o[w] = s * wt[w];
+        rels[t * 3] = dx; rels[t * 3 + 1] = dy; rels[t * 3 + 2] = dz;
+    }
+    __syncthreads();
+    for (int e = t; e < S * C1; e += 128) {
+        const int r = e / C1, c = e - r * C1;
+        const f32x4 w = *reinterpret_cast<const f32x4*>(w1x + c * 4);
+        const float h = fmaf(w[2], rels[r * 3 + 2], fmaf(w[1], rels[r * 3 + 1], w[0] * rels[r * 3])) + w[3] + U[((size_t)b * S + r) * C1 + c];
+        h1[((size_t)b * S + r) * C1 + c] = fmaxf(h, 0.f);
+    }
+}
+
+// out[b][c*16 + w] = sum_k h[b][k][c] * sw[b][k][w]
+__global__ __launch_bounds__(kThreads) void pc_all_contract_kernel(const float* __restrict__ h, const float* __restrict__ sw,
+                                                                   float* __restrict__ out, int S, int C) {
+    __shared__ __attribute__((aligned(16))) float s[128 * 16];
+    const int b = blockIdx.y;
+    for (int e = threadIdx.x; e < S * 16; e += kThreads) s[e] = sw[(size_t)b * S * 16 + e];
+    __syncthreads();
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    float o[16];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) o[w] = 0.f;
+    for (int k = 0; k < S; ++k) {
+        const float hv = h[((size_t)b * S + k) * C + c];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) o[w] = fmaf(hv, s[k * 16 + w], o[w]);
+    }
+    float* dst = out + ((size_t)b * C + c) * 16;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) dst[w] = o[w];
+}
+
+__global__ void pc_pad8_kernel(const float* __restrict__ xyz, float* __restrict__ out, int total) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    reinterpret_cast<f32x4*>(out)[t * 2] = (f32x4){xyz[t * 3], xyz[t * 3 + 1], xyz[t * 3 + 2], 0.f};
+    reinterpret_cast<f32x4*>(out)[t * 2 + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+struct WsC {
+    float *inv1, *inv2, *inv3;
+    int32_t *fps1, *fps2;
+    float *nx1, *nx2;          // (B,512,3), (B,128,3)
+    float *k8, *q8;            // padded keys / queries for the kNN MFMA
+    int16_t *idx1, *idx2;      // (B,512,32), (B,128,64)
+    float *g1, *l1;            // (B,512,2048), (B,512,128)
+    float *u2, *g2, *l2;       // (B,512,128), (B,128,4096), (B,128,256)
+    float *u3, *h1, *h2, *h3, *sw3, *g3, *l3;
+    float *f1, *f2;
+    size_t bytes;
+};
+
+WsC carve_c(void* base, int B, int N) {
+    WsC s{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = iq::align_up(off + bytes, 256);
+        return reinterpret_cast<char*>(base) + o;
+    };
+    const size_t b = (size_t)B;
+    s.inv1 = (float*)take(b * N * 4); s.inv2 = (float*)take(b * 512 * 4); s.inv3 = (float*)take(b * 128 * 4);
+    s.fps1 = (int32_t*)take(b * 512 * 4); s.fps2 = (int32_t*)take(b * 128 * 4);
+    s.nx1 = (float*)take(b * 512 * 3 * 4); s.nx2 = (float*)take(b * 128 * 3 * 4);
+    s.k8 = (float*)take(b * N * 8 * 4); s.q8 = (float*)take(b * 512 * 8 * 4);
+    s.idx1 = (int16_t*)take(b * 512 * 32 * 2); s.idx2 = (int16_t*)take(b * 128 * 64 * 2);
+    s.g1 = (float*)take(b * 512 * 2048 * 4); s.l1 = (float*)take(b * 512 * 128 * 4);
+    s.u2 = (float*)take(b * 512 * 128 * 4); s.g2 = (float*)take(b * 128 * 4096 * 4); s.l2 = (float*)take(b * 128 * 256 * 4);
+    s.u3 = (float*)take(b * 128 * 256 * 4); s.h1 = (float*)take(b * 128 * 256 * 4); s.h2 = (float*)take(b * 128 * 512 * 4);
+    s.h3 = (float*)take(b * 128 * 1024 * 4); s.sw3 = (float*)take(b * 128 * 16 * 4); s.g3 = (float*)take(b * 16384 * 4);
+    s.l3 = (float*)take(b * 1024 * 4); s.f1 = (float*)take(b * 512 * 4); s.f2 = (float*)take(b * 256 * 4);
+    s.bytes = off;
+    return s;
+}
+
+template <int K>
+int launch_pc_knn(const float* keys, int nkeys, const float* queries, int S, WsC& s, int16_t* idx, int B, hipStream_t st) {
+    hipLaunchKernelGGL(pc_pad8_kernel, dim3((B * nkeys + 255) / 256), dim3(256), 0, st, keys, s.k8, B * nkeys);
+    hipLaunchKernelGGL(pc_pad8_kernel, dim3((B * S + 255) / 256), dim3(256), 0, st, queries, s.q8, B * S);
+    hipLaunchKernelGGL(pc_knn_kernel<K>, dim3((S + 127) / 128, B), dim3(kThreads), 0, st, s.k8, s.q8, idx, nkeys, S);
+    return iq::check_launch("pc_knn_kernel");
+}
+
+int launch_pc_group(const iq_pointconv_sa& sa, PcGroupArgs a, int B, hipStream_t st) {
+    a.w1x = sa.w1x;
+    a.w2 = sa.l2.w; a.b2 = sa.l2.b; a.w3 = sa.l3.w; a.b3 = sa.l3.b;
+    a.nets.dn = sa.densitynet; a.nets.wn = sa.weightnet;
+    const int gpc = kMC / a.K;
+    dim3 grid((a.S + gpc - 1) / gpc, B);
+    const int c1 = sa.l2.cin, c2 = sa.l2.cout, c3 = sa.l3.cout;
+    if (c1 == 64 && c2 == 64 && c3 == 128) hipLaunchKernelGGL((pc_group_kernel<64, 64, 128>), grid, dim3(kThreads), 0, st, a);
+    else if (c1 == 128 && c2 == 128 && c3 == 256) hipLaunchKernelGGL((pc_group_kernel<128, 128, 256>), grid, dim3(kThreads), 0, st, a);
+    else return iq::fail(IQ_EUNSUPPORTED, "pointconv stage %d-%d-%d has no kernel instantiation", c1, c2, c3);
+    return iq::check_launch("pc_group_kernel");
+}
+
+}  // namespace
+
+extern "C" size_t iq_pointconv_workspace_bytes(int B, int N) {
+    if (B < 0 || N < 0) return 0;
+    return carve_c(nullptr, B, N).bytes;
+}
+
+extern "C" int iq_pointconv_forward(const iq_pointconv_weights* w, const float* xyz, float* logits, void* workspace,
+                                    size_t workspace_bytes, int B, int N, iq_stream_t stream) {
+    IQ_REQUIRE(w && xyz && logits, "iq_pointconv_forward: null pointer");
+    IQ_REQUIRE(B >= 0 && N >= 512 && N % 32 == 0 && N <= 4096, "iq_pointconv_forward: N=%d", N);
+    IQ_REQUIRE(w->sa[0].nsample == 32 && w->sa[1].nsample == 64, "iq_pointconv_forward: nsample must be 32 / 64");
+    if (B == 0) return IQ_OK;
+    const size_t need = carve_c(nullptr, B, N).bytes;
+    if (!workspace || workspace_bytes < need)
+        return iq::fail(IQ_EWORKSPACE, "iq_pointconv_forward: workspace %zu < %zu bytes", workspace_bytes, need);
+    WsC s = carve_c(workspace, B, N);
+    hipStream_t st = iq::as_stream(stream);
+    int rc;
+    iq::ProfileSpan call_span(iq::kSlotCall, st);
+    constexpr int S1 = 512, S2 = 128;
+
+    // ---- sa1: 1024 -> 512 points, K = 32, 3 -> 64 -> 64 -> 128 ---------------------------------------------------
+    {
+        iq::ProfileSpan span(iq::kSlotPrepool, st);
+        hipLaunchKernelGGL(pc_density_kernel, dim3((N + kThreads - 1) / kThreads, B), dim3(kThreads), (size_t)N * 16, st, xyz,
+                           w->sa[0].bandwidth, s.inv1, N);
+        if ((rc = iq::launch_fps(xyz, s.fps1, nullptr, B, N, S1, st))) return rc;
+        hipLaunchKernelGGL(pc_gather_xyz_kernel, dim3((B * S1 + 255) / 256), dim3(256), 0, st, xyz, 3, s.fps1, s.nx1, N, S1, B * S1);
+        if ((rc = launch_pc_knn<32>(xyz, N, s.nx1, S1, s, s.idx1, B, st))) return rc;
+        PcGroupArgs a{};
+        a.xyz = xyz; a.new_xyz = s.nx1; a.idx = s.idx1; a.inv_density = s.inv1; a.U = nullptr; a.ldu = 0;
+        a.out = s.g1; a.N = N; a.S = S1; a.K = 32;
+        if ((rc = launch_pc_group(w->sa[0], a, B, st))) return rc;
+        if ((rc = iq::launch_linear(s.g1, 2048, w->sa[0].linear, s.l1, 128, B * S1, 1, st))) return rc;
+    }
+    // ---- sa2: 512 -> 128 points, K = 64, 131 -> 128 -> 128 -> 256 --------------------------------------------------
+    {
+        iq::ProfileSpan span(iq::kSlotFstn, st);
+        hipLaunchKernelGGL(pc_density_kernel, dim3((S1 + kThreads - 1) / kThreads, B), dim3(kThreads), (size_t)S1 * 16, st, s.nx1,
+                           w->sa[1].bandwidth, s.inv2, S1);
+        if ((rc = iq::launch_fps(s.nx1, s.fps2, nullptr, B, S1, S2, st))) return rc;
+        hipLaunchKernelGGL(pc_gather_xyz_kernel, dim3((B * S2 + 255) / 256), dim3(256), 0, st, s.nx1, 3, s.fps2, s.nx2, S1, S2, B * S2);
+        if ((rc = launch_pc_knn<64>(s.nx1, S1, s.nx2, S2, s, s.idx2, B, st))) return rc;
+        if ((rc = iq::launch_linear(s.l1, 128, w->sa[1].u, s.u2, 128, B * S1, 0, st))) return rc;
+        PcGroupArgs a{};
+        a.xyz = s.nx1; a.new_xyz = s.nx2; a.idx = s.idx2; a.inv_density = s.inv2; a.U = s.u2; a.ldu = 128;
+        a.out = s.g2; a.N = S1; a.S = S2; a.K = 64;
+        if ((rc = launch_pc_group(w->sa[1], a, B, st))) return rc;
+        if ((rc = iq::launch_linear(s.g2, 4096, w->sa[1].linear, s.l2, 256, B * S2, 1, st))) return rc;
+    }
+    // ---- sa3: group all 128 points, 259 -> 256 -> 512 -> 1024 ------------------------------------------------------
+    {
+        iq::ProfileSpan span(iq::kSlotTrunk, st);
+        hipLaunchKernelGGL(pc_density_kernel, dim3(1, B), dim3(kThreads), (size_t)S2 * 16, st, s.nx2, w->sa[2].bandwidth, s.inv3, S2);
+        if ((rc = iq::launch_linear(s.l2, 256, w->sa[2].u, s.u3, 256, B * S2, 0, st))) return rc;
+        TinyNets nets{w->sa[2].densitynet, w->sa[2].weightnet};
+        hipLaunchKernelGGL(pc_all_prepare_kernel, dim3(B), dim3(128), 0, st, s.nx2, s.inv3, nets, w->sa[2].w1x, s.u3, 256, s.h1,
+                           s.sw3, S2);
+        if ((rc = iq::check_launch("pc_all_prepare_kernel"))) return rc;
+        if ((rc = iq::launch_linear(s.h1, 256, w->sa[2].l2, s.h2, 512, B * S2, 1, st))) return rc;
+        if ((rc = iq::launch_linear(s.h2, 512, w->sa[2].l3, s.h3, 1024, B * S2, 1, st))) return rc;
+        hipLaunchKernelGGL(pc_all_contract_kernel, dim3(1024 / kThreads, B), dim3(kThreads), 0, st, s.h3, s.sw3, s.g3, S2, 1024);
+        if ((rc = iq::check_launch("pc_all_contract_kernel"))) return rc;
+        if ((rc = iq::launch_linear(s.g3, 16384, w->sa[2].linear, s.l3, 1024, B, 1, st))) return rc;
+    }
+    if ((rc = iq::launch_linear(s.l3, 1024, w->fc1, s.f1, 512, B, 1, st))) return rc;
+    if ((rc = iq::launch_linear(s.f1, 512, w->fc2, s.f2, 256, B, 1, st))) return rc;
+    if ((rc = iq::launch_linear(s.f2, 256, w->fc3, logits, w->fc3.cout, B, 0, st))) return rc;
+    return IQ_OK;
+}

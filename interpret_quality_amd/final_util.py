@@ -134,8 +134,11 @@ def load_model(args):
         from .dgcnn import DGCNN_cls, GCNN_cls
         model = (DGCNN_cls if args.model == "dgcnn" else GCNN_cls)(args).to(args.device)
         synth_sd = synth.dgcnn_state_dict
+    elif args.model == "pointconv":
+        from .pointconv import PointConvDensityClsSsg
+        model, synth_sd = PointConvDensityClsSsg(args).to(args.device), synth.pointconv_state_dict
     else:
-        raise IqError("model %r is not on the HIP path yet (see DESIGN.md 'next')" % args.model)
+        raise IqError("model %r is unknown" % args.model)
     if getattr(args, "synthetic", False) and not os.path.exists(args.model_path):
         state_dict = synth.to_torch(synth_sd(0))
     else:

@@ -1,0 +1,159 @@
+"""PointConv (density) classifier on the HIP path.
+
+Host-side mirror of models/pointconv.py:394-424 (PointConvDensityClsSsg): same constructor argument,
+same ``state_dict`` keys (226 tensors), same call ``model(xyz: (B,3,N)) -> logits (B,10)``.  Density,
+FPS, kNN grouping, the shared MLPs, DensityNet / WeightNet and the weighted aggregation run in
+libiq_hip.so (csrc/iq_pointconv.hip); the torch modules only hold parameters.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .pointnet2 import fold_conv_bn
+
+SA = [dict(npoint=512, nsample=32, in_channel=3, mlp=[64, 64, 128], bandwidth=0.1),          # models/pointconv.py:403
+      dict(npoint=128, nsample=64, in_channel=128 + 3, mlp=[128, 128, 256], bandwidth=0.2),  # :404
+      dict(npoint=1, nsample=None, in_channel=256 + 3, mlp=[256, 512, 1024], bandwidth=0.4)]  # :405
+
+
+class PackedWeightsC:
+    def __init__(self, sd, device):
+        lib = _lib.load()
+        self._keep = []
+        self.struct = _lib.PointConvWeights()
+
+        def dev(arr):
+            t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device)
+            self._keep.append(t)
+            return t
+
+        def dense(w, b):
+            cout, cin = w.shape
+            w32 = np.ascontiguousarray(w, dtype=np.float32)
+            out = np.empty(lib.iq_packed_floats(cout, cin), dtype=np.float32)
+            _lib.check(lib.iq_pack_weight(w32.ctypes.data, out.ctypes.data, cout, cin), "iq_pack_weight")
+            bp = np.zeros(lib.iq_padded_cout(cout), dtype=np.float32)
+            bp[:cout] = b
+            wt, bt = dev(out), dev(bp)
+            return _lib.DenseLayer(wt.data_ptr(), bt.data_ptr(), cin, cout)
+
+        def tiny(prefix):
+            rows = []
+            for j in range(3):
+                w, b = fold_conv_bn(sd, "%s.mlp_convs.%d" % (prefix, j), "%s.mlp_bns.%d" % (prefix, j))
+                rows.append(np.concatenate([w, b[:, None]], axis=1).reshape(-1))
+            return dev(np.concatenate(rows)).data_ptr()
+
+        for k, cfg in enumerate(SA):
+            p = "sa%d" % (k + 1)
+            dst = self.struct.sa[k]
+            w0, b0 = fold_conv_bn(sd, p + ".mlp_convs.0", p + ".mlp_bns.0")
+            feat = cfg["in_channel"] - 3                               # input = [x_p - c (3) ; features]  (:133-135)
+            bias = b0 if feat == 0 else np.zeros_like(b0)
+            dst.w1x = dev(np.concatenate([w0[:, :3], bias[:, None]], axis=1)).data_ptr()
+            if feat:
+                dst.u = dense(w0[:, 3:], b0)
+            dst.l2 = dense(*fold_conv_bn(sd, p + ".mlp_convs.1", p + ".mlp_bns.1"))
+            dst.l3 = dense(*fold_conv_bn(sd, p + ".mlp_convs.2", p + ".mlp_bns.2"))
+            dst.densitynet = tiny(p + ".densitynet")
+            dst.weightnet = tiny(p + ".weightnet")
+            dst.linear = dense(*fold_conv_bn(sd, p + ".linear", p + ".bn_linear"))
+            dst.bandwidth = cfg["bandwidth"]
+            dst.nsample = cfg["nsample"] or 0
+        self.struct.fc1 = dense(*fold_conv_bn(sd, "fc1", "bn1"))
+        self.struct.fc2 = dense(*fold_conv_bn(sd, "fc2", "bn2"))
+        self.struct.fc3 = dense(*fold_conv_bn(sd, "fc3", None))
+        self.num_classes = int(sd["fc3.weight"].shape[0])
+
+
+class PointConvEngine:
+    def __init__(self, state_dict, device):
+        if torch.device(device).type != "cuda":
+            raise _lib.IqError("PointConvEngine needs a GPU device (no CPU fallback)")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.weights = PackedWeightsC(state_dict, self.device)
+        self._ws = None
+
+    def forward_points(self, xyz):
+        if not xyz.is_cuda or xyz.dtype != torch.float32 or not xyz.is_contiguous():
+            raise _lib.IqError("xyz must be a contiguous float32 GPU tensor (B,N,3)")
+        b, n, _ = xyz.shape
+        need = self.lib.iq_pointconv_workspace_bytes(b, n)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        logits = torch.empty((b, self.weights.num_classes), dtype=torch.float32, device=self.device)
+        rc = self.lib.iq_pointconv_forward(ctypes.byref(self.weights.struct), ctypes.c_void_p(xyz.data_ptr()),
+                                           ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(self._ws.data_ptr()),
+                                           self._ws.numel(), b, n, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "iq_pointconv_forward")
+        return logits
+
+
+def _tiny_holder(dims):
+    m = nn.Module()
+    m.mlp_convs, m.mlp_bns = nn.ModuleList(), nn.ModuleList()
+    for j in range(3):
+        m.mlp_convs.append(nn.Conv2d(dims[j], dims[j + 1], 1))
+        m.mlp_bns.append(nn.BatchNorm2d(dims[j + 1]))
+    return m
+
+
+def _sa_holder(cfg):
+    m = nn.Module()
+    m.mlp_convs, m.mlp_bns = nn.ModuleList(), nn.ModuleList()
+    last = cfg["in_channel"]
+    for c in cfg["mlp"]:
+        m.mlp_convs.append(nn.Conv2d(last, c, 1))
+        m.mlp_bns.append(nn.BatchNorm2d(c))
+        last = c
+    m.weightnet = _tiny_holder([3, 8, 8, 16])
+    m.linear = nn.Linear(16 * last, last)
+    m.bn_linear = nn.BatchNorm1d(last)
+    m.densitynet = _tiny_holder([1, 16, 8, 1])
+    return m
+
+
+class PointConvDensityClsSsg(nn.Module):
+    """Parameter container with the reference's state-dict layout; forward runs on the HIP path."""
+
+    max_clouds_per_call = 1024  # bounds the workspace (9.4 MB per cloud)
+
+    def __init__(self, args=None):
+        super().__init__()
+        self.args = args
+        self.output_channels = 40 if getattr(args, "dataset", "modelnet10") == "modelnet40" else 10
+        self.sa1, self.sa2, self.sa3 = _sa_holder(SA[0]), _sa_holder(SA[1]), _sa_holder(SA[2])
+        self.fc1, self.bn1 = nn.Linear(1024, 512), nn.BatchNorm1d(512)
+        self.fc2, self.bn2 = nn.Linear(512, 256), nn.BatchNorm1d(256)
+        self.fc3 = nn.Linear(256, self.output_channels)
+        self._engine = None
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def engine(self):
+        if self.training:
+            raise _lib.IqError("the HIP PointConv path implements eval mode only")
+        if self._engine is None:
+            self._engine = PointConvEngine(self.state_dict(), self.fc3.weight.device)
+        return self._engine
+
+    def forward_points(self, xyz):
+        eng = self.engine()
+        step = self.max_clouds_per_call
+        if xyz.shape[0] <= step:
+            return eng.forward_points(xyz)
+        return torch.cat([eng.forward_points(xyz[i:i + step].contiguous()) for i in range(0, xyz.shape[0], step)], dim=0)
+
+    def forward(self, xyz):
+        """xyz (B,3,N) as in the reference -> logits (B,10)."""
+        return self.forward_points(xyz.permute(0, 2, 1).contiguous())

@@ -1,0 +1,66 @@
+"""GPU parity: PointConv (density, kNN grouping, weighted aggregation, full model) against golden vectors
+from the reference."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from interpret_quality_amd import final_common, synth
+from interpret_quality_amd.pointconv import PointConvDensityClsSsg
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def model():
+    m = PointConvDensityClsSsg(None)
+    m.load_state_dict(synth.to_torch(synth.pointconv_state_dict(0)))
+    return m.to(dev()).eval()
+
+
+def masked_clouds():
+    from oracle import ref_cpu as O
+    g = load_golden("pointconv.npz")
+    pts, _ = synth.make_cloud(0)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    center = torch.mean(data, dim=1).squeeze()
+    return O.shapley_masked_batch(data, center, g["orders"], g["region_id"])  # (18,1024,3)
+
+
+def test_pointconv_forward_matches_reference(model):
+    g = load_golden("pointconv.npz")
+    logits = model(masked_clouds().permute(0, 2, 1).contiguous().to(dev()))
+    err = np.abs(logits.cpu().numpy() - g["logits"]).max(axis=1) / np.abs(g["logits"]).max()
+    assert err.max() < RTOL, err
+
+
+def test_pointconv_shapley_matches_reference(model):
+    g = load_golden("pointconv.npz")
+    pts, label = synth.make_cloud(0)
+    data = torch.from_numpy(pts).unsqueeze(0).to(dev())
+    lbl = torch.tensor([label], device=dev())
+    args = argparse.Namespace(model="pointconv", softmax_type="modified", num_points=1024, num_regions=8, num_samples=2,
+                              shapley_batch_size=2, verbose=False)
+    phi, logits = final_common.shap_sampling_all_regions_batch(model, data, lbl, g["region_id"], g["orders"], args)
+    assert rel_err(logits.cpu().numpy(), g["shap_logits"]) < RTOL
+    assert np.abs(phi - g["phi"]).max() < RTOL * np.abs(g["phi"]).max()
+
+
+def test_pointconv_raw_clouds_vs_oracle(model):
+    from oracle import ref_cpu as O
+    x = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in (3, 4)]).permute(0, 2, 1).contiguous()
+    want = O.PointConvOracle(synth.to_torch(synth.pointconv_state_dict(0)))(x)
+    got = model(x.to(dev()))
+    assert rel_err(got.cpu().numpy(), want.numpy()) < RTOL

@@ -38,6 +38,10 @@ elif a.model in ("dgcnn", "gcnn"):
     from interpret_quality_amd.dgcnn import DGCNN_cls, GCNN_cls
     model = (DGCNN_cls if a.model == "dgcnn" else GCNN_cls)(argparse.Namespace(dataset="modelnet10", k=20))
     model.load_state_dict(synth.to_torch(synth.dgcnn_state_dict(0)))
+elif a.model == "pointconv":
+    from interpret_quality_amd.pointconv import PointConvDensityClsSsg
+    model = PointConvDensityClsSsg(None)
+    model.load_state_dict(synth.to_torch(synth.pointconv_state_dict(0)))
 else:
     raise SystemExit("unknown model")
 model = model.to(dev).eval()
