@@ -88,11 +88,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # IQ_BENCH_REHEARSAL=1: rehearse the N > 1 code path on a one-GPU box (all ranks on cuda:0, gloo
+    # collectives).  Never set by the driver; the numbers of a rehearsal mean nothing.
+    rehearsal = os.environ.get("IQ_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)  # nccl = RCCL on ROCm
 
     from interpret_quality_amd import _lib, final_common, hip_ops, synth
     from interpret_quality_amd.pointnet import PointNetCls
