@@ -676,8 +676,8 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
                                       float* logits, float* trans_feat_packed, void* workspace,
                                       size_t workspace_bytes, int B, int nclouds, int N, int R,
                                       int channel_first, iq_stream_t stream) {
-    IQ_REQUIRE(w && clouds && region_id && logits, "iq_pointnet_coalitions: null pointer");
     IQ_REQUIRE(B >= 0 && nclouds >= 1, "iq_pointnet_coalitions: B=%d nclouds=%d", B, nclouds);
+    IQ_REQUIRE(w && clouds && region_id && (logits || B == 0), "iq_pointnet_coalitions: null pointer");
     IQ_REQUIRE(N >= 1 && N <= kMaxN, "iq_pointnet_coalitions: N=%d not in [1,%d]", N, kMaxN);
     IQ_REQUIRE(R >= 1 && R <= IQ_MAX_REGIONS, "iq_pointnet_coalitions: R=%d not in [1,%d]", R, IQ_MAX_REGIONS);
     IQ_REQUIRE(cloud_of || nclouds == 1 || nclouds == B, "iq_pointnet_coalitions: cloud_of required when 1 < nclouds != B");

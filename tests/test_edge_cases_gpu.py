@@ -1,0 +1,166 @@
+"""GPU: edge cases of the hot path - empty / full / single-region coalitions, empty regions, the maximum
+region count, smaller clouds, empty batches, and the error behaviour of the C ABI."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from interpret_quality_amd import _lib, hip_ops, synth
+from interpret_quality_amd.pointnet import PointNetCls
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(pointnet_sd):
+    m = PointNetCls(None)
+    m.load_state_dict(pointnet_sd)
+    return m.to(dev()).eval()
+
+
+@pytest.fixture(scope="module")
+def oracle_model(pointnet_sd):
+    from oracle import ref_cpu
+    return ref_cpu.PointNetOracle(pointnet_sd)
+
+
+def masked_by_keep(pts, region_id, keep, center):
+    out = np.repeat(pts[None], len(keep), axis=0).copy()
+    for b, k in enumerate(keep):
+        drop = ((np.uint64(k) >> np.asarray(region_id).astype(np.uint64)) & np.uint64(1)) == 0
+        out[b, drop] = center
+    return out
+
+
+def check_against_oracle(model, oracle_model, pts, region_id, num_regions, keep):
+    d = dev()
+    data = torch.from_numpy(pts).unsqueeze(0)
+    center = torch.mean(data, dim=1)
+    got = model.coalition_logits(data.to(d), center.to(d), hip_ops.as_i32(region_id, d).reshape(1, -1),
+                                 hip_ops.masks_to_tensor(keep, d), None, num_regions=num_regions).cpu().numpy()
+    x = torch.from_numpy(masked_by_keep(pts, region_id, keep, center[0].numpy())).permute(0, 2, 1).contiguous()
+    want = oracle_model(x)[0].numpy()
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-4
+
+
+def test_extreme_coalitions_and_max_region_count(model, oracle_model):
+    pts, _ = synth.make_cloud(5)
+    rng = np.random.default_rng(0)
+    region_id = rng.integers(0, 64, size=1024)            # R = 64: the ABI maximum (uint64 masks)
+    keep = [0, (1 << 64) - 1, 1, 1 << 63, (1 << 64) - 2, 0x5555555555555555, 1 << 17]
+    check_against_oracle(model, oracle_model, pts, region_id, 64, keep)
+
+
+def test_empty_regions_and_single_region(model, oracle_model):
+    pts, _ = synth.make_cloud(6)
+    region_id = np.zeros(1024, dtype=np.int64)
+    region_id[:100] = 5                                   # regions 1-4, 6, 7 are empty
+    # keeping only empty regions masks everything; dropping only empty regions masks nothing (no centre row)
+    check_against_oracle(model, oracle_model, pts, region_id, 8, [0, 0b11011110, 0b00100001, 0b1, 0b100000, 0xff])
+    check_against_oracle(model, oracle_model, pts, np.zeros(1024, dtype=np.int64), 1, [0, 1])   # R = 1
+
+
+def test_smaller_cloud_and_batch_of_one(model, oracle_model):
+    pts, _ = synth.make_cloud(7, num_points=512)          # N = 512 (< the 1024 of the reference)
+    rng = np.random.default_rng(1)
+    check_against_oracle(model, oracle_model, pts, rng.integers(0, 32, size=512), 32, [0x0f0f0f0f])
+
+
+def test_empty_batches_everywhere(model):
+    d = dev()
+    cloud = torch.zeros((1, 1024, 3), device=d)
+    rid = torch.zeros((1, 1024), dtype=torch.int32, device=d)
+    out = model.coalition_logits(cloud, torch.zeros((1, 3), device=d), rid, torch.zeros((0,), dtype=torch.int64, device=d),
+                                 None, num_regions=32)
+    assert tuple(out.shape) == (0, 10)
+    assert hip_ops.reward(torch.zeros((0, 10), device=d), 0).shape == (0,)
+    phi, rows, _ = hip_ops.shapley_accum(torch.zeros((0,), device=d), torch.zeros((0, 32), dtype=torch.int32, device=d))
+    assert phi.shape == (32,) and float(phi.abs().sum()) == 0.0 and rows.shape == (0, 32)
+    assert hip_ops.interaction_reduce(torch.zeros((0,), device=d)).shape == (0,)
+    assert hip_ops.mask_interaction(cloud[0], rid[0], torch.zeros((0, 2), dtype=torch.int32, device=d),
+                                    torch.zeros((0,), dtype=torch.int64, device=d), torch.zeros(3, device=d), 32).shape == (0, 3, 1024)
+
+
+def test_abi_error_reporting(model):
+    lib = _lib.load()
+    d = dev()
+    # unsupported sizes -> negative code + message, nothing is launched
+    cloud = torch.zeros((1022, 3), device=d)
+    with pytest.raises(_lib.IqError, match="multiple of 4"):
+        hip_ops.mask_shapley(cloud, torch.zeros(1022, dtype=torch.int32, device=d), torch.zeros((1, 8), dtype=torch.int32, device=d),
+                             torch.zeros(3, device=d))
+    with pytest.raises(_lib.IqError, match="label"):
+        hip_ops.reward(torch.zeros((4, 10), device=d), 10)
+    # workspace too small -> IQ_EWORKSPACE
+    eng = model.engine()
+    clouds = torch.zeros((1, 1024, 3), device=d)
+    rid = torch.zeros((1, 1024), dtype=torch.int32, device=d)
+    keep = torch.zeros((4,), dtype=torch.int64, device=d)
+    logits = torch.empty((4, 10), device=d)
+    tiny = torch.empty(1024, dtype=torch.uint8, device=d)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.iq_pointnet_coalitions(ctypes.byref(eng.weights.struct), p(clouds), p(torch.zeros((1, 3), device=d)), p(rid),
+                                    p(keep), None, p(logits), None, p(tiny), tiny.numel(), 4, 1, 1024, 32, 0, None)
+    assert rc == -3 and b"workspace" in lib.iq_last_error()
+    # N beyond the fused kernel's row-list capacity
+    rc = lib.iq_pointnet_coalitions(ctypes.byref(eng.weights.struct), p(clouds), None, p(rid), None, None, p(logits), None,
+                                    p(tiny), tiny.numel(), 1, 1, 2048, 1, 0, None)
+    assert rc == -1 and b"N=2048" in lib.iq_last_error()
+    # wrong dtype / device at the Python boundary
+    with pytest.raises(_lib.IqError):
+        hip_ops.fps(torch.zeros((1, 64, 3), dtype=torch.float64, device=d), 8)
+    with pytest.raises(_lib.IqError):
+        model.coalition_logits(clouds.cpu(), None, rid, None, None, num_regions=1)
+
+
+def test_fps_more_samples_than_distinct_points():
+    d = dev()
+    x = torch.zeros((2, 64, 3), device=d)
+    x[0, 10, 0] = 1.0
+    x[0, 20, 1] = 2.0
+    got = hip_ops.fps(x, 8).cpu().numpy()
+    assert got[0].tolist() == [0, 20, 10, 0, 0, 0, 0, 0]      # farthest first, then index 0 forever
+    assert got[1].tolist() == [0] * 8
+
+
+def _degenerate_clouds():
+    """(4,1024,3): everything masked (one distinct location), one region of 32 kept, all but one kept, raw."""
+    from oracle import ref_cpu as O
+    pts, _ = synth.make_cloud(8)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    rid = O.cal_region_id(data, O.farthest_point_sample(data, 32)[0])
+    center = torch.mean(data, dim=1)[0].numpy()
+    keep = [0, 1 << 3, ((1 << 32) - 1) ^ (1 << 9), (1 << 32) - 1]
+    return torch.from_numpy(masked_by_keep(pts, np.asarray(rid), keep, center)).permute(0, 2, 1).contiguous()
+
+
+@pytest.mark.parametrize("name", ["pointnet2", "dgcnn", "gcnn", "pointconv"])
+def test_degenerate_clouds_other_models(name):
+    import argparse
+    from oracle import ref_cpu as O
+    from interpret_quality_amd.dgcnn import DGCNN_cls, GCNN_cls
+    from interpret_quality_amd.pointconv import PointConvDensityClsSsg
+    from interpret_quality_amd.pointnet2 import PointNet2ClsMsg
+    ns = argparse.Namespace(dataset="modelnet10", k=20)
+    cls, sd, orc = {
+        "pointnet2": (PointNet2ClsMsg, synth.pointnet2_state_dict, O.PointNet2Oracle),
+        "dgcnn": (DGCNN_cls, synth.dgcnn_state_dict, lambda s: O.DgcnnOracle(s, k=20, fixed_graph=False)),
+        "gcnn": (GCNN_cls, synth.dgcnn_state_dict, lambda s: O.DgcnnOracle(s, k=20, fixed_graph=True)),
+        "pointconv": (PointConvDensityClsSsg, synth.pointconv_state_dict, O.PointConvOracle),
+    }[name]
+    sd = synth.to_torch(sd(0))
+    m = cls(ns if "cnn" in name else None)
+    m.load_state_dict(sd)
+    m = m.to(dev()).eval()
+    x = _degenerate_clouds()
+    got = m(x.to(dev()))
+    got = (got[0] if isinstance(got, tuple) else got).cpu().numpy()
+    want = orc(sd)(x)
+    want = (want[0] if isinstance(want, tuple) else want).numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-4
