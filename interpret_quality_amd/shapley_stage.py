@@ -41,11 +41,12 @@ def save_fps(args, loader=None):
 
 
 def data_loader(args):
-    """The reference's 30-cloud loaders need the datasets (final_data_shapley.py:47-179), which are
-    not available offline; ``--synthetic`` substitutes the seeded synthetic clouds."""
+    """The 30-cloud loaders of final_data_shapley.py (data_shapley.py here) when the dataset trees exist;
+    ``--synthetic`` (additive flag) substitutes the seeded synthetic clouds when they do not."""
     if getattr(args, "synthetic", False):
         return synthetic_loader(args)
-    raise FileNotFoundError("dataset loaders are out of scope of this build (SURVEY.md §2 row 9); run with --synthetic")
+    from .data_shapley import shapley_test_loader
+    return shapley_test_loader(args)
 
 
 def cal_region_id(data, fps_index, result_path, save=True):

@@ -214,3 +214,62 @@ def pointconv_state_dict(seed=0):
     _bn(sd, "bn2", 256, seed)
     _linear(sd, "fc3", NUM_CLASSES, 256, seed, False, 1.0)
     return sd
+
+
+# ------------------------------------------------------------------------------------------------
+# a miniature dataset tree in the reference's on-disk formats (final_data_shapley.py), for loader tests
+# ------------------------------------------------------------------------------------------------
+DATASET_TREE = {
+    "modelnet10": [("bathtub", "bathtub_0003", 1100), ("chair", "chair_0007", 2048)],
+    "shapenet": [("02773838", "aaaa0001", 2607), ("03797390", "bbbb0002", 1024), ("04099429", "cccc0003", 2890)],
+}
+
+
+def raw_scan(seed, n):
+    """An un-normalised, off-centre 'scan': anisotropic blob + a denser lump (so FPS has something to do)."""
+    rng = np.random.default_rng(7000 + seed)
+    body = rng.normal(size=(n - n // 4, 3)) * np.array([0.31, 0.12, 0.22])
+    lump = rng.normal(size=(n // 4, 3)) * 0.03 + np.array([0.2, -0.05, 0.1])
+    return (np.concatenate([body, lump]) + np.array([0.4, -0.2, 0.1])).astype(np.float64)
+
+
+def write_dataset_tree(root):
+    """Creates <root>/data/modelnet10_numpy, <root>/data/shapenetcore_partanno_segmentation_benchmark_v0 and
+    <root>/misc with the tiny lists above; returns the raw arrays keyed by sample name."""
+    import json
+    import os
+    raw = {}
+    mn = os.path.join(root, "data", "modelnet10_numpy")
+    os.makedirs(mn, exist_ok=True)
+    names = ["bathtub", "bed", "chair", "desk", "dresser", "monitor", "night_stand", "sofa", "table", "toilet"]
+    with open(os.path.join(mn, "modelnet10_shape_names.txt"), "w") as f:
+        f.write("\n".join(names) + "\n")
+    os.makedirs(os.path.join(root, "misc"), exist_ok=True)
+    with open(os.path.join(root, "misc", "modelnet10_train_final30.txt"), "w") as f:
+        for i, (folder, name, n) in enumerate(DATASET_TREE["modelnet10"]):
+            os.makedirs(os.path.join(mn, folder), exist_ok=True)
+            arr = np.concatenate([raw_scan(i, n), np.ones((n, 3))], axis=1).astype(np.float32)  # xyz + normals
+            np.save(os.path.join(mn, folder, name + ".npy"), arr)
+            raw[name] = arr
+            f.write(name + "\n")
+    sn = os.path.join(root, "data", "shapenetcore_partanno_segmentation_benchmark_v0")
+    os.makedirs(sn, exist_ok=True)
+    cats = {"Airplane": "02691156", "Bag": "02773838", "Cap": "02954340", "Car": "02958343", "Chair": "03001627",
+            "Earphone": "03261776", "Guitar": "03467517", "Knife": "03624134", "Lamp": "03636649", "Laptop": "03642806",
+            "Motorbike": "03790512", "Mug": "03797390", "Pistol": "03948459", "Rocket": "04099429",
+            "Skateboard": "04225987", "Table": "04379243"}
+    with open(os.path.join(sn, "synsetoffset2category.txt"), "w") as f:
+        for k, v in cats.items():
+            f.write("%s\t%s\n" % (k, v))
+    files = []
+    for i, (cat, uuid, n) in enumerate(DATASET_TREE["shapenet"]):
+        os.makedirs(os.path.join(sn, cat, "points"), exist_ok=True)
+        os.makedirs(os.path.join(sn, cat, "points_label"), exist_ok=True)
+        arr = raw_scan(10 + i, n)
+        np.savetxt(os.path.join(sn, cat, "points", uuid + ".pts"), arr, fmt="%.5f")
+        np.savetxt(os.path.join(sn, cat, "points_label", uuid + ".seg"), np.ones(n, dtype=np.int64), fmt="%d")
+        raw[uuid] = arr
+        files.append("shape_data/%s/%s" % (cat, uuid))
+    with open(os.path.join(root, "misc", "shapenet_train_selected.json"), "w") as f:
+        json.dump(files, f)
+    return raw

@@ -56,6 +56,22 @@ def farthest_point_sample(xyz, npoint):
     return out
 
 
+def farthest_point_sample_np(point, npoint):
+    """final_data_shapley.py:71-92 - the NumPy sampler of the ShapeNet loader: start at index 0, squared
+    distances in the dtype of the points (fp32 there), running minimum kept in fp64, first-index argmax."""
+    xyz = np.asarray(point)[:, :3]
+    out = np.zeros((npoint,), dtype=np.int64)
+    mind = np.full((xyz.shape[0],), 1e10)
+    cur = 0
+    for i in range(npoint):
+        out[i] = cur
+        d = ((xyz - xyz[cur]) ** 2).sum(-1)
+        closer = d < mind
+        mind[closer] = d[closer]
+        cur = int(np.argmax(mind))
+    return out
+
+
 def cal_region_id(data, fps_index):
     """final_shapley_value.py:20-35 - nearest FPS centre per point.  data (1,N,3) tensor,
     fps_index (R,) -> (N,) int64 ndarray."""

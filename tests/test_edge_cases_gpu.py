@@ -164,3 +164,29 @@ def test_degenerate_clouds_other_models(name):
     want = (want[0] if isinstance(want, tuple) else want).numpy()
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() / np.abs(want).max() < 1e-4
+
+
+def test_shapenet_loader_downsamples_on_the_hip_path(tmp_path, monkeypatch):
+    """final_data_shapley.py:95-179: loadtxt -> centre -> scale -> FPS(1024) -> gather, items bit-identical to the
+    reference's (its NumPy sampler is iq_fps here), plus the raw sampler on a 2607-point scan."""
+    import argparse
+    from conftest import load_golden
+    from interpret_quality_amd import data_shapley, final_util
+    g = load_golden("loaders.npz")
+    raw = synth.raw_scan(10, 2607).astype(np.float32)
+    assert np.array_equal(data_shapley.farthest_point_sample_np(raw, 64), g["fps_np_2607_to_64"])
+    synth.write_dataset_tree(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    args = argparse.Namespace(dataset="shapenet", num_points=1024, device=dev())
+    ds = data_shapley.ShapeNetDataset_Shapley_test(args, split="train", npoints=1024,
+                                                   class_choice=final_util.SHAPENET_CLASS, classification=True)
+    assert len(ds) == int(g["shapenet_len"])
+    for i in range(len(ds)):
+        pts, cls = ds[i]
+        assert pts.dtype == torch.float32 and cls.dtype == torch.int64 and cls.dim() == 0
+        assert np.array_equal(pts.numpy(), g["shapenet_%d_points" % i])
+        assert int(cls) == int(g["shapenet_%d_label" % i])
+    batches = list(data_shapley.shapley_test_loader(args))
+    assert len(batches) == 3 and tuple(batches[0][0].shape) == (1, 1024, 3) and tuple(batches[0][1].shape) == (1,)
+    with pytest.raises(_lib.IqError, match="exceeds"):
+        data_shapley.farthest_point_sample_np(np.zeros((9000, 3), dtype=np.float32), 8)

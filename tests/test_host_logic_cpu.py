@@ -142,3 +142,26 @@ def test_gloo_world2_sharded_shapley_matches_single_process(tmp_path):
     # rows are independent in eval mode, so sharding cannot change them (allow last-bit batch effects)
     np.testing.assert_allclose(got["v"].numpy(), v.reshape(s, num_regions + 1).numpy(), rtol=1e-5, atol=1e-5)
     assert got["empty"].shape == (1, 2) and float(got["empty"][0, 0]) == 0.0
+
+
+def test_modelnet_loader_and_sample_names_match_reference(tmp_path, monkeypatch):
+    """final_data_shapley.py:10-69, tools/final_util.py:265-283 on the miniature dataset tree."""
+    import argparse
+    from conftest import load_golden
+    from interpret_quality_amd import data_shapley, final_util, synth
+    g = load_golden("loaders.npz")
+    synth.write_dataset_tree(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    args = argparse.Namespace(dataset="modelnet10", num_points=1024)
+    ds = data_shapley.ModelNet_Loader_Shapley_test(args, partition="train", num_points=1024)
+    assert len(ds) == 2
+    for i in range(2):
+        pts, cls = ds[i]
+        assert pts.dtype == np.float32 and np.array_equal(pts, g["modelnet_%d_points" % i])
+        assert cls == int(g["modelnet_%d_label" % i])
+    assert final_util.get_folder_name_list(args) == list(g["modelnet_names"])
+    assert final_util.get_folder_name_list(argparse.Namespace(dataset="shapenet")) == list(g["shapenet_names"])
+    data, lbl = next(iter(data_shapley.shapley_test_loader(args)))
+    assert tuple(data.shape) == (1, 1024, 3) and data.dtype == torch.float32 and tuple(lbl.shape) == (1,) and lbl.dtype == torch.long
+    with pytest.raises(Exception, match="mode"):
+        data_shapley.ModelNet_Loader_Shapley_test(args, partition="test", num_points=1024)

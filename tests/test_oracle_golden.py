@@ -195,3 +195,10 @@ def test_pointconv_oracle_matches_reference():
                                                 2, 2, 8)
     np.testing.assert_allclose(lg.numpy(), g["shap_logits"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(phi, g["phi"], rtol=1e-5, atol=1e-6)
+
+
+def test_numpy_fps_of_the_shapenet_loader_matches_reference():
+    from interpret_quality_amd import synth
+    g = load_golden("loaders.npz")
+    raw = synth.raw_scan(10, 2607).astype(np.float32)
+    assert np.array_equal(O.farthest_point_sample_np(raw, 64), g["fps_np_2607_to_64"])
