@@ -108,6 +108,39 @@ int iq_region_assign(const float* cloud /*N,3*/, const int32_t* fps_idx /*R*/,
  * ties -> lowest index.  xyz (B,N,3) -> idx (B,S). */
 int iq_fps(const float* xyz, int32_t* idx, int B, int N, int S, iq_stream_t stream);
 
+/* final_smoothness_center_enum_all.py:183-242 (update_region) for every region and every epoch of
+ * test_all_region's loop (:303-335) in one launch: gradient ascent (objective +1) / descent (-1) on the
+ * linearity (mode 0) / planarity (1) / scattering (2) of each region's points, under the reference's
+ * variance bounds (:66-82), distance bound (:102-118) and stop conditions (:163-180).  The constants are
+ * the reference's module-level STEP .. MAX_ITERATION (:13-19).  Regions only move their own points, so
+ * epoch e of region r does not depend on other regions.  Outputs:
+ *   data_out   (epochs,N,3)  the cloud after epoch e (data_list, :326)
+ *   smooth_out (epochs,R)    smoothness of region r recorded in epoch e (smoothness_list, :325)
+ *   var_out    (epochs,R,3)  last variances on o1,o2,o3 (the "var1: .." log line, :239)
+ *   orig_out   (R,4)         original variances on o1,o2,o3 and original smoothness (:256-261)
+ *   stop_epoch (R)           epoch in which the region stopped updating (indicator False), `epochs` if it
+ *                            never did, -1 for a region of fewer than two points (left untouched;
+ *                            the reference cannot process such a region)
+ * The caller evaluates epochs 0 .. min(epochs, max_r stop_epoch + 1) - 1, as the break at :333-334 does.
+ * `origin` (optional) restarts the enumeration from an already deformed `cloud`: orientations, variance
+ * bounds, the distance bound and the first target are taken from `origin` (NULL: from `cloud`). */
+typedef struct iq_smoothness_params {
+    double step;           /* STEP = 1e-3 */
+    double enum_step;      /* ENUM_STEP = 0.05 */
+    double var_threshold;  /* VAR_THRESHOLD = 0.003 */
+    double dist_threshold; /* DIST_THRESHOLD = 0.03 */
+    double stop_ratio;     /* STOP_RATIO = 0.5 */
+    int32_t epochs;        /* EPOCH = 50 */
+    int32_t max_iteration; /* MAX_ITERATION = 100 */
+    int32_t project_to_bound; /* 0 = as the reference behaves: points beyond dist_threshold are counted (stop
+                                 condition) but stay where they are, because its write-back at :117 assigns to a
+                                 temporary view; 1 = project them back onto the sphere as :110-117 intends */
+    int32_t reserved;
+} iq_smoothness_params;
+int iq_smoothness_enum(const float* cloud /*N,3*/, const float* origin /*N,3 or NULL*/, const int32_t* region_id /*N*/, int N, int R, int mode,
+                       int objective, const iq_smoothness_params* prm, float* data_out, float* smooth_out,
+                       float* var_out, float* orig_out, int32_t* stop_epoch, iq_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * PointNet (models/pointnet.py:11-115) - fused fp32-MFMA forward over coalitions
  * ------------------------------------------------------------------------------------------- */

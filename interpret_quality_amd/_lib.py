@@ -61,6 +61,12 @@ class DgcnnWeights(ctypes.Structure):
                 ("fc3", DenseLayer), ("k", ctypes.c_int32)]
 
 
+class SmoothnessParams(ctypes.Structure):
+    _fields_ = [("step", ctypes.c_double), ("enum_step", ctypes.c_double), ("var_threshold", ctypes.c_double),
+                ("dist_threshold", ctypes.c_double), ("stop_ratio", ctypes.c_double), ("epochs", ctypes.c_int32),
+                ("max_iteration", ctypes.c_int32), ("project_to_bound", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 _I = ctypes.c_int
 _P = ctypes.c_void_p
 _SZ = ctypes.c_size_t
@@ -77,6 +83,7 @@ SIGNATURES = {
     "iq_interaction_reduce": (_I, [_P, _P, _I, _P]),
     "iq_region_assign": (_I, [_P, _P, _P, _I, _I, _P]),
     "iq_fps": (_I, [_P, _P, _I, _I, _I, _P]),
+    "iq_smoothness_enum": (_I, [_P, _P, _P, _I, _I, _I, _I, ctypes.POINTER(SmoothnessParams), _P, _P, _P, _P, _P, _P]),
     "iq_packed_floats": (_SZ, [_I, _I]),
     "iq_padded_cout": (_I, [_I]),
     "iq_pack_weight": (_I, [_P, _P, _I, _I]),

@@ -17,7 +17,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "iq.h")
 ARCH = "gfx950"
 # Index-valued kernels (FPS, ball query, region assignment) need individually rounded operations:
 # hipcc's default -ffp-contract=fast fuses a*b+c into fma even through the __f*_rn intrinsics.
-NO_CONTRACT = ("iq_geom.hip", "iq_pointnet2.hip", "iq_dgcnn.hip", "iq_pointconv.hip")
+NO_CONTRACT = ("iq_geom.hip", "iq_pointnet2.hip", "iq_dgcnn.hip", "iq_pointconv.hip", "iq_smooth.hip")
 
 
 def sources():

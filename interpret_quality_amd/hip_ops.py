@@ -161,3 +161,30 @@ def knn(x, k=20):
     tmp = torch.empty((b * n * 76 + 4096,), dtype=torch.uint8, device=x.device)
     _lib.check(lib.iq_knn(_dev(x, torch.float32, "x"), _p(out), _p(tmp), tmp.numel(), b, n, c, k, _stream()), "iq_knn")
     return out
+
+
+SMOOTHNESS_MODES = ("linearity", "planarity", "scattering")
+
+
+def smoothness_enum(cloud, region_id, num_regions, mode, objective, step=1e-3, enum_step=0.05, var_threshold=0.003,
+                    dist_threshold=0.03, stop_ratio=0.5, epochs=50, max_iteration=100, origin=None, project_to_bound=False):
+    """final_smoothness_center_enum_all.py:183-242,303-335 for all regions and epochs in one launch.
+    cloud (N,3) f32, region_id (N,) i32 -> dict(data (E,N,3) f32, smoothness (E,R) f32, var (E,R,3) f32,
+    orig (R,4) f32, stop_epoch (R,) i32); see include/iq.h.  ``origin`` (N,3): restart from a deformed ``cloud``."""
+    lib = _lib.load()
+    n, r, e = cloud.shape[0], int(num_regions), int(epochs)
+    dev = cloud.device
+    out = {"data": torch.empty((e, n, 3), dtype=torch.float32, device=dev),
+           "smoothness": torch.empty((e, r), dtype=torch.float32, device=dev),
+           "var": torch.empty((e, r, 3), dtype=torch.float32, device=dev),
+           "orig": torch.empty((r, 4), dtype=torch.float32, device=dev),
+           "stop_epoch": torch.empty((r,), dtype=torch.int32, device=dev)}
+    prm = _lib.SmoothnessParams(step, enum_step, var_threshold, dist_threshold, stop_ratio, e, int(max_iteration), int(bool(project_to_bound)), 0)
+    if mode not in SMOOTHNESS_MODES or objective not in ("inc", "dec"):
+        raise _lib.IqError("smoothness_enum: mode %r / objective %r" % (mode, objective))
+    org = _dev(origin, torch.float32, "origin") if origin is not None else ctypes.c_void_p(0)
+    _lib.check(lib.iq_smoothness_enum(_dev(cloud, torch.float32, "cloud"), org, _dev(region_id, torch.int32, "region_id"), n, r,
+                                      SMOOTHNESS_MODES.index(mode), 1 if objective == "inc" else -1, ctypes.byref(prm),
+                                      _p(out["data"]), _p(out["smoothness"]), _p(out["var"]), _p(out["orig"]),
+                                      _p(out["stop_epoch"]), _stream()), "iq_smoothness_enum")
+    return out

