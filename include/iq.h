@@ -242,7 +242,7 @@ int iq_pointnet2_forward(const iq_pointnet2_weights* w /*host struct of device p
 
 /* models/dgcnn.py:12-18 (knn): the k = 20 largest of -|x_i|^2 - (-2 x_i.x_j) - |x_j|^2 per row, self
  * included, as an (unordered) index set.  x (B,N,C) row-major with C in {3, 64, 128}; idx (B,N,20)
- * int32; tmp = scratch of at least B*N*76 + 1024 bytes. */
+ * int32; tmp = scratch of at least B*N*80 + 16*B + 4096 bytes. */
 int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes, int B, int N, int C, int k,
            iq_stream_t stream);
 
@@ -263,6 +263,18 @@ size_t iq_dgcnn_workspace_bytes(int B, int N);
 int iq_dgcnn_forward(const iq_dgcnn_weights* w /*host struct of device pointers*/, const float* xyz,
                      float* logits, void* workspace, size_t workspace_bytes, int B, int N,
                      int fixed_graph, iq_stream_t stream);
+
+/* The same network on B coalitions WITHOUT materialising the masked clouds (the argument convention of
+ * iq_pointnet_coalitions: clouds (nclouds,N,3), centers (nclouds,3), region_id (nclouds,N), keep (B) region
+ * bit masks, cloud_of (B) or NULL when nclouds is 1 or B).  Replaces the masking + forward of
+ * tools/final_common.py:88-91 and final_point_binary_interaction_logits.py:45-60 for DGCNN / GCNN.  A masked
+ * cloud is its kept points plus M copies of the centre that behave identically in every layer, so each
+ * coalition runs on kept + min(M,20) rows (exact: neighbourhood max and max-pool are set operations, the
+ * mean pool weights the centre by M).  Same workspace as iq_dgcnn_forward(B, N). */
+int iq_dgcnn_coalitions(const iq_dgcnn_weights* w, const float* clouds, const float* centers,
+                        const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of, float* logits,
+                        void* workspace, size_t workspace_bytes, int B, int nclouds, int N, int fixed_graph,
+                        iq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PointConv with density (models/pointconv.py:103-424)

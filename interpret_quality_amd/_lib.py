@@ -98,6 +98,7 @@ SIGNATURES = {
     "iq_knn": (_I, [_P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
     "iq_dgcnn_workspace_bytes": (_SZ, [_I, _I]),
     "iq_dgcnn_forward": (_I, [ctypes.POINTER(DgcnnWeights), _P, _P, _P, _SZ, _I, _I, _I, _P]),
+    "iq_dgcnn_coalitions": (_I, [ctypes.POINTER(DgcnnWeights), _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
     "iq_pointconv_workspace_bytes": (_SZ, [_I, _I]),
     "iq_pointconv_forward": (_I, [ctypes.POINTER(PointConvWeights), _P, _P, _P, _SZ, _I, _I, _P]),
     "iq_profile_enable": (_I, [_I]),

@@ -10,6 +10,14 @@
 // products on the fp32 MFMA.  Keys run along the accumulator registers and queries along the lanes,
 // so every lane keeps the running top-20 of its query in registers; ties between exact duplicates
 // (masked points) are harmless because duplicates carry identical features.
+//
+// Ragged batches.  A masked cloud holds its kept points plus M copies of the centre, and every copy sees the same
+// neighbourhoods and produces the same features in every layer.  iq_dgcnn_coalitions therefore never materialises the
+// N rows: cloud b becomes D_b = kept + min(M, 20) rows (20 copies are all a top-20 can ever select), padded to a
+// multiple of 32 with dead rows whose |x|^2 is +inf so that no query selects them.  Max-pooling and the neighbourhood
+// max are set operations, so they are unchanged; the mean pool weights the centre by M.  Exact, and the kNN work drops
+// with the square of the kept fraction.  All kernels below run on the ragged layout (row offsets per cloud); the dense
+// forward is the special case D_b = N.
 #include "iq_common.h"
 #include "iq_mfma.h"
 #include "iq_profile.h"
@@ -29,13 +37,110 @@ __global__ void pad_xyz_kernel(const float* __restrict__ xyz, float* __restrict_
     reinterpret_cast<f32x4*>(out)[t * 2 + 1] = z;
 }
 
+// ---- ragged layout ---------------------------------------------------------------------------------------------
+struct Ragged {
+    const int32_t* roff;       // (B+1) first row of cloud b; roff[B] = total rows (all multiples of 32)
+    const int32_t* nkept;      // (B) kept points = rows [0, nkept)
+    const int32_t* ncopy;      // (B) centre copies = rows [nkept, nkept + ncopy)
+    const int32_t* row_cloud;  // (rows) cloud of a row
+};
+
+// dense forward: D_b = N
+__global__ void dg_dense_layout_kernel(int32_t* __restrict__ roff, int32_t* __restrict__ nkept, int32_t* __restrict__ ncopy,
+                                       int32_t* __restrict__ row_cloud, int B, int N) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < B * N) row_cloud[t] = t / N;
+    if (t <= B) roff[t] = t * N;
+    if (t < B) { nkept[t] = N; ncopy[t] = 0; }
+}
+
+// coalitions: kept points of coalition b = points whose region bit is set in keep[b]
+__global__ __launch_bounds__(64) void dg_count_kernel(const int32_t* __restrict__ region_id, const uint64_t* __restrict__ keep,
+                                                      const int32_t* __restrict__ cloud_of, int32_t* __restrict__ nkept,
+                                                      int32_t* __restrict__ ncopy, int32_t* __restrict__ dpad, int N, int nclouds) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int c = cloud_of ? cloud_of[b] : (nclouds == 1 ? 0 : b);
+    const uint64_t k = keep[b];
+    const int32_t* rid = region_id + (size_t)c * N;
+    int n = 0;
+    for (int i = lane; i < N; i += 64) n += (int)((k >> rid[i]) & 1ull);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
+    if (lane == 0) {
+        const int copies = min(N - n, kK);
+        nkept[b] = n;
+        ncopy[b] = copies;
+        dpad[b] = (n + copies + 31) & ~31;
+    }
+}
+
+// exclusive scan of dpad -> roff (single workgroup; B is at most a few thousand per call)
+__global__ __launch_bounds__(1024) void dg_scan_kernel(const int32_t* __restrict__ dpad, int32_t* __restrict__ roff, int B) {
+    __shared__ int32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (B + 1023) / 1024;
+    const int lo = t * per, hi = min(lo + per, B);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += dpad[i];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int i = lo; i < hi; ++i) { roff[i] = run; run += dpad[i]; }
+    if (t == 1023) roff[B] = part[1023];
+}
+
+// rows of coalition b: kept points in index order, then the centre copies, then dead rows; (.,8) padded xyz
+__global__ __launch_bounds__(64) void dg_compact_kernel(const float* __restrict__ clouds, const float* __restrict__ centers,
+                                                        const int32_t* __restrict__ region_id, const uint64_t* __restrict__ keep,
+                                                        const int32_t* __restrict__ cloud_of, const int32_t* __restrict__ roff,
+                                                        const int32_t* __restrict__ nkept, const int32_t* __restrict__ ncopy,
+                                                        float* __restrict__ x0, int32_t* __restrict__ row_cloud, int N,
+                                                        int nclouds) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int c = cloud_of ? cloud_of[b] : (nclouds == 1 ? 0 : b);
+    const uint64_t k = keep[b];
+    const int32_t* rid = region_id + (size_t)c * N;
+    const float* xyz = clouds + (size_t)c * N * 3;
+    const int base = roff[b], end = roff[b + 1];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    int pos = 0;
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        const int i = i0 + lane;
+        const bool kept = i < N && ((k >> rid[i]) & 1ull);
+        const unsigned long long m = __ballot(kept);
+        if (kept) {
+            const int row = base + pos + __popcll(m & ((1ull << lane) - 1ull));
+            const f32x4 a = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2], 0.f};
+            reinterpret_cast<f32x4*>(x0)[(size_t)row * 2] = a;
+            reinterpret_cast<f32x4*>(x0)[(size_t)row * 2 + 1] = z;
+        }
+        pos += __popcll(m);
+    }
+    const int live = nkept[b] + ncopy[b];
+    const f32x4 ctr = {centers[c * 3], centers[c * 3 + 1], centers[c * 3 + 2], 0.f};
+    for (int row = base + nkept[b] + lane; row < end; row += 64) {
+        reinterpret_cast<f32x4*>(x0)[(size_t)row * 2] = (row < base + live) ? ctr : z;
+        reinterpret_cast<f32x4*>(x0)[(size_t)row * 2 + 1] = z;
+    }
+    for (int row = base + lane; row < end; row += 64) row_cloud[row] = b;
+}
+
 // ---- xx[i] = sum_c x[i][c]^2 in channel order (torch.sum(x**2, dim=1)) ------------------------------
 // 64 rows per workgroup, staged through LDS so the global reads are coalesced; each row is still summed
 // sequentially over its channels by one lane.
+// Dead (padding) rows get +inf: as keys they then score -inf and are never selected.
 __global__ __launch_bounds__(64) void rownorm_kernel(const float* __restrict__ x, int ldx, int C, float* __restrict__ xx,
-                                                     int rows) {
+                                                     Ragged rg, int B) {
     __shared__ float tile[64 * 129];
+    const int rows = rg.roff[B];
     const int r0 = blockIdx.x * 64;
+    if (r0 >= rows) return;
     const int ld = C + 1;
     for (int e = threadIdx.x; e < 64 * C; e += 64) {
         const int r = e / C, c = e - r * C;
@@ -47,21 +152,27 @@ __global__ __launch_bounds__(64) void rownorm_kernel(const float* __restrict__ x
     const float* p = tile + threadIdx.x * ld;
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += p[c] * p[c];
-    xx[r] = s;
+    const int b = rg.row_cloud[r];
+    xx[r] = (r - rg.roff[b] < rg.nkept[b] + rg.ncopy[b]) ? s : INFINITY;
 }
 
 // ---- kNN ------------------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(kThreads, 2) void knn_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ xx,
-                                                          int16_t* __restrict__ idx, int N) {
+                                                          int16_t* __restrict__ idx, Ragged rg) {
     constexpr int LD = C + 4, KB = C / 8;
     __shared__ __attribute__((aligned(16))) float keys[2][32 * LD];
     __shared__ float kxx[2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
-    const float* xb = x + (size_t)b * N * ldx;
-    const float* xxb = xx + (size_t)b * N;
-    const int q0 = blockIdx.x * 128 + wave * 32;  // this wave's 32 queries
+    const int base = rg.roff[b];
+    const int N = rg.roff[b + 1] - base;          // padded rows of this cloud (multiple of 32)
+    if ((int)blockIdx.x * 128 >= N) return;
+    const float* xb = x + (size_t)base * ldx;
+    const float* xxb = xx + base;
+    const int q0w = blockIdx.x * 128 + wave * 32;  // this wave's 32 queries
+    const bool wave_live = q0w < N;
+    const int q0 = wave_live ? q0w : 0;            // idle waves of the last block shadow block 0's queries (no write)
     const int fl = lane & 31, fh = lane >> 5;
 
     // B operand: queries, stationary in registers
@@ -102,8 +213,8 @@ __global__ __launch_bounds__(kThreads, 2) void knn_kernel(const float* __restric
         __syncthreads();
     }
     top.merge_halves();  // each half-wave saw half of the keys of every tile
-    if (fh == 0) {
-        int16_t* o = idx + ((size_t)b * N + q0 + fl) * kK;
+    if (fh == 0 && wave_live) {
+        int16_t* o = idx + ((size_t)base + q0 + fl) * kK;
 #pragma unroll
         for (int q = 0; q < kK; ++q) o[q] = (int16_t)top.i[q];
     }
@@ -112,18 +223,18 @@ __global__ __launch_bounds__(kThreads, 2) void knn_kernel(const float* __restric
 // ---- out[i][c] = LeakyReLU(max_j P[idx[i][j]][c] + Q[i][c]) ------------------------------------------
 __global__ __launch_bounds__(kThreads) void gather_max_kernel(const float* __restrict__ pq, int Co,
                                                               const int16_t* __restrict__ idx, float* __restrict__ out,
-                                                              int ldo, int N, int total_pts) {
+                                                              int ldo, Ragged rg, int B) {
     const int per = Co / 4;                               // float4 lanes per point
     const int t = blockIdx.x * kThreads + threadIdx.x;
     const int pt = t / per, c4 = t - pt * per;
-    if (pt >= total_pts) return;
-    const int b = pt / N;
+    if (pt >= rg.roff[B]) return;
+    const int base = rg.roff[rg.row_cloud[pt]];
     const int16_t* nb = idx + (size_t)pt * kK;
     const f32x4* P = reinterpret_cast<const f32x4*>(pq);
     f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll 4
     for (int j = 0; j < kK; ++j) {
-        const f32x4 v = P[((size_t)b * N + nb[j]) * (2 * per) + c4];
+        const f32x4 v = P[((size_t)base + nb[j]) * (2 * per) + c4];
         m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
     }
     const f32x4 q = P[(size_t)pt * (2 * per) + per + c4];
@@ -136,28 +247,36 @@ __global__ __launch_bounds__(kThreads) void gather_max_kernel(const float* __res
     *reinterpret_cast<f32x4*>(out + (size_t)pt * ldo + c4 * 4) = o;
 }
 
-// ---- global max and mean pooling over the N rows of (B,N,C) -> (B,2C) ---------------------------------
+// ---- global max and mean pooling over the N points of each cloud: (rows,C) -> (B,2C) --------------------------------
+// Kept rows count once, the centre (all copies identical) counts with its multiplicity M = N - kept.
 __global__ __launch_bounds__(kThreads) void pool_max_avg_kernel(const float* __restrict__ h, float* __restrict__ out,
-                                                                int N, int C) {
+                                                                Ragged rg, int N, int C) {
     const int b = blockIdx.y;
     const int c = blockIdx.x * kThreads + threadIdx.x;
     if (c >= C) return;
-    const float* p = h + (size_t)b * N * C + c;
+    const int nk = rg.nkept[b];
+    const float* p = h + (size_t)rg.roff[b] * C + c;
     float m = -INFINITY, s = 0.f;
-    for (int i = 0; i < N; ++i) {
+    for (int i = 0; i < nk; ++i) {
         const float v = p[(size_t)i * C];
         m = fmaxf(m, v);
         s += v;
+    }
+    if (rg.ncopy[b] > 0) {
+        const float v = p[(size_t)nk * C];
+        m = fmaxf(m, v);
+        s += (float)(N - nk) * v;
     }
     out[(size_t)b * 2 * C + c] = m;
     out[(size_t)b * 2 * C + C + c] = s / (float)N;
 }
 
-int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, int B, int N, hipStream_t st) {
-    dim3 grid(N / 128, B);
-    if (C == 8) hipLaunchKernelGGL(knn_kernel<8>, grid, dim3(kThreads), 0, st, x, ldx, xx, idx, N);
-    else if (C == 64) hipLaunchKernelGGL(knn_kernel<64>, grid, dim3(kThreads), 0, st, x, ldx, xx, idx, N);
-    else if (C == 128) hipLaunchKernelGGL(knn_kernel<128>, grid, dim3(kThreads), 0, st, x, ldx, xx, idx, N);
+int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, int B, int N, const Ragged& rg,
+               hipStream_t st) {
+    dim3 grid((N + 127) / 128, B);
+    if (C == 8) hipLaunchKernelGGL(knn_kernel<8>, grid, dim3(kThreads), 0, st, x, ldx, xx, idx, rg);
+    else if (C == 64) hipLaunchKernelGGL(knn_kernel<64>, grid, dim3(kThreads), 0, st, x, ldx, xx, idx, rg);
+    else if (C == 128) hipLaunchKernelGGL(knn_kernel<128>, grid, dim3(kThreads), 0, st, x, ldx, xx, idx, rg);
     else return iq::fail(IQ_EUNSUPPORTED, "knn: C=%d has no kernel instantiation (8, 64, 128)", C);
     return iq::check_launch("knn_kernel");
 }
@@ -170,6 +289,7 @@ struct WsD {
     int16_t* idx;   // (B,N,20)
     float* h;       // (B,N,1024)
     float *g, *f1, *f2;
+    int32_t *roff, *nkept, *ncopy, *dpad, *row_cloud;  // ragged layout
     size_t bytes;
 };
 
@@ -191,6 +311,11 @@ WsD carve_d(void* base, int B, int N) {
     s.g = (float*)take((size_t)B * 2048 * 4);
     s.f1 = (float*)take((size_t)B * 512 * 4);
     s.f2 = (float*)take((size_t)B * 256 * 4);
+    s.roff = (int32_t*)take((size_t)(B + 1) * 4);
+    s.nkept = (int32_t*)take((size_t)B * 4);
+    s.ncopy = (int32_t*)take((size_t)B * 4);
+    s.dpad = (int32_t*)take((size_t)B * 4);
+    s.row_cloud = (int32_t*)take(r * 4);
     s.bytes = off;
     return s;
 }
@@ -207,37 +332,89 @@ extern "C" size_t iq_dgcnn_workspace_bytes(int B, int N) {
     return carve_d(nullptr, B, N).bytes;
 }
 
-// Op-level kNN for tests: x (B,N,C) row-major, C in {3, 64, 128}; idx (B,N,20) int32; tmp >= B*N*(8*4+4+40) bytes.
+// Op-level kNN for tests: x (B,N,C) row-major, C in {3, 64, 128}; idx (B,N,20) int32; tmp >= B*N*80 + 16*B + 4096 bytes.
 extern "C" int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes, int B, int N, int C, int k,
                       iq_stream_t stream) {
     IQ_REQUIRE(x && idx && tmp, "iq_knn: null pointer");
     IQ_REQUIRE(k == kK, "iq_knn: k=%d (only k=20, tools/final_util.py:19)", k);
-    IQ_REQUIRE(B >= 1 && N >= 128 && N % 128 == 0 && N <= 32767, "iq_knn: N=%d must be a multiple of 128", N);
+    IQ_REQUIRE(B >= 1 && N >= 32 && N % 32 == 0 && N <= 32767, "iq_knn: N=%d must be a multiple of 32", N);
     IQ_REQUIRE(C == 3 || C == 64 || C == 128, "iq_knn: C=%d unsupported", C);
     const size_t r = (size_t)B * N;
-    IQ_REQUIRE(tmp_bytes >= r * (8 * 4 + 4 + kK * 2) + 1024, "iq_knn: tmp too small");
+    IQ_REQUIRE(tmp_bytes >= r * 80 + (size_t)B * 16 + 4096, "iq_knn: tmp too small");
     hipStream_t st = iq::as_stream(stream);
     char* p = reinterpret_cast<char*>(tmp);
-    float* x0 = reinterpret_cast<float*>(p);
-    float* xx = reinterpret_cast<float*>(p + iq::align_up(r * 8 * 4, 256));
-    int16_t* i16 = reinterpret_cast<int16_t*>(p + iq::align_up(r * 8 * 4, 256) + iq::align_up(r * 4, 256));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* q = p + off; off = iq::align_up(off + bytes, 256); return q; };
+    float* x0 = reinterpret_cast<float*>(take(r * 8 * 4));
+    float* xx = reinterpret_cast<float*>(take(r * 4));
+    int16_t* i16 = reinterpret_cast<int16_t*>(take(r * kK * 2));
+    int32_t* row_cloud = reinterpret_cast<int32_t*>(take(r * 4));
+    int32_t* roff = reinterpret_cast<int32_t*>(take((size_t)(B + 1) * 4));
+    int32_t* nkept = reinterpret_cast<int32_t*>(take((size_t)B * 4));
+    int32_t* ncopy = reinterpret_cast<int32_t*>(take((size_t)B * 4));
+    hipLaunchKernelGGL(dg_dense_layout_kernel, dim3((r + 256) / 256), dim3(256), 0, st, roff, nkept, ncopy, row_cloud, B, N);
+    const Ragged rg{roff, nkept, ncopy, row_cloud};
     const float* src = x;
     int ld = C, cpad = C;
     if (C == 3) {
         hipLaunchKernelGGL(pad_xyz_kernel, dim3((r + 255) / 256), dim3(256), 0, st, x, x0, (int)r);
         src = x0; ld = 8; cpad = 8;
     }
-    hipLaunchKernelGGL(rownorm_kernel, dim3((r + 63) / 64), dim3(64), 0, st, src, ld, C, xx, (int)r);
-    int rc = launch_knn(src, ld, cpad, xx, i16, B, N, st);
+    hipLaunchKernelGGL(rownorm_kernel, dim3((r + 63) / 64), dim3(64), 0, st, src, ld, C, xx, rg, B);
+    int rc = launch_knn(src, ld, cpad, xx, i16, B, N, rg, st);
     if (rc) return rc;
     hipLaunchKernelGGL(widen_idx_kernel, dim3((r * kK + 255) / 256), dim3(256), 0, st, i16, idx, r * kK);
     return iq::check_launch("iq_knn");
 }
 
+namespace {
+
+// The network on the ragged rows described by s.roff / s.nkept / s.ncopy / s.row_cloud; s.x0 holds the padded xyz rows.
+// `rows` = upper bound of the row count (grid sizes); the live count is roff[B], on the device.
+int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, int N, int rows, int fixed_graph,
+                hipStream_t st) {
+    const Ragged rg{s.roff, s.nkept, s.ncopy, s.row_cloud};
+    const int32_t* live = s.roff + B;
+    int rc;
+    const float* src = s.x0;
+    int ld = 8, cin = 8, creal = 3, col = 0;
+    for (int l = 0; l < 4; ++l) {
+        const int co = w->pq[l].cout / 2;
+        IQ_REQUIRE(w->pq[l].cin == cin, "iq_dgcnn: layer %d expects %d inputs, got %d", l, cin, w->pq[l].cin);
+        if (l == 0 || !fixed_graph) {
+            iq::ProfileSpan span(iq::kSlotPrepool, st);
+            hipLaunchKernelGGL(rownorm_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, src, ld, creal, s.xx, rg, B);
+            if ((rc = launch_knn(src, ld, cin, s.xx, s.idx, B, N, rg, st))) return rc;
+        }
+        {
+            iq::ProfileSpan span(iq::kSlotFstn, st);
+            if ((rc = iq::launch_linear(src, ld, w->pq[l], s.pq, 2 * co, rows, 0, st, live))) return rc;
+            const long long nthreads = (long long)rows * (co / 4);
+            hipLaunchKernelGGL(gather_max_kernel, dim3((unsigned)((nthreads + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                               s.pq, co, s.idx, s.xc + col, 512, rg, B);
+            if ((rc = iq::check_launch("gather_max_kernel"))) return rc;
+        }
+        src = s.xc + col; ld = 512; cin = co; creal = co; col += co;
+    }
+    IQ_REQUIRE(col == 512, "iq_dgcnn: concatenated width %d != 512", col);
+    {
+        iq::ProfileSpan span(iq::kSlotTrunk, st);
+        if ((rc = iq::launch_linear(s.xc, 512, w->conv5, s.h, 1024, rows, 2, st, live))) return rc;
+        hipLaunchKernelGGL(pool_max_avg_kernel, dim3(1024 / kThreads, B), dim3(kThreads), 0, st, s.h, s.g, rg, N, 1024);
+        if ((rc = iq::check_launch("pool_max_avg_kernel"))) return rc;
+    }
+    if ((rc = iq::launch_linear(s.g, 2048, w->fc1, s.f1, 512, B, 2, st))) return rc;
+    if ((rc = iq::launch_linear(s.f1, 512, w->fc2, s.f2, 256, B, 2, st))) return rc;
+    if ((rc = iq::launch_linear(s.f2, 256, w->fc3, logits, w->fc3.cout, B, 0, st))) return rc;
+    return IQ_OK;
+}
+
+}  // namespace
+
 extern "C" int iq_dgcnn_forward(const iq_dgcnn_weights* w, const float* xyz, float* logits, void* workspace,
                                 size_t workspace_bytes, int B, int N, int fixed_graph, iq_stream_t stream) {
     IQ_REQUIRE(w && xyz && logits, "iq_dgcnn_forward: null pointer");
-    IQ_REQUIRE(B >= 0 && N >= 128 && N % 128 == 0 && N <= 32767, "iq_dgcnn_forward: N=%d must be a multiple of 128", N);
+    IQ_REQUIRE(B >= 0 && N >= 32 && N % 32 == 0 && N <= 32767, "iq_dgcnn_forward: N=%d must be a multiple of 32", N);
     IQ_REQUIRE(w->k == kK, "iq_dgcnn_forward: k=%d (only 20)", w->k);
     if (B == 0) return IQ_OK;
     const size_t need = carve_d(nullptr, B, N).bytes;
@@ -248,38 +425,34 @@ extern "C" int iq_dgcnn_forward(const iq_dgcnn_weights* w, const float* xyz, flo
     const int rows = B * N;
     int rc;
     iq::ProfileSpan call_span(iq::kSlotCall, st);
-
+    hipLaunchKernelGGL(dg_dense_layout_kernel, dim3((rows + 256) / 256), dim3(256), 0, st, s.roff, s.nkept, s.ncopy,
+                       s.row_cloud, B, N);
     hipLaunchKernelGGL(pad_xyz_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, xyz, s.x0, rows);
     if ((rc = iq::check_launch("pad_xyz_kernel"))) return rc;
-    const float* src = s.x0;
-    int ld = 8, cin = 8, creal = 3, col = 0;
-    for (int l = 0; l < 4; ++l) {
-        const int co = w->pq[l].cout / 2;
-        IQ_REQUIRE(w->pq[l].cin == cin, "iq_dgcnn_forward: layer %d expects %d inputs, got %d", l, cin, w->pq[l].cin);
-        if (l == 0 || !fixed_graph) {
-            iq::ProfileSpan span(iq::kSlotPrepool, st);
-            hipLaunchKernelGGL(rownorm_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, src, ld, creal, s.xx, rows);
-            if ((rc = launch_knn(src, ld, cin, s.xx, s.idx, B, N, st))) return rc;
-        }
-        {
-            iq::ProfileSpan span(iq::kSlotFstn, st);
-            if ((rc = iq::launch_linear(src, ld, w->pq[l], s.pq, 2 * co, rows, 0, st))) return rc;
-            const int nthreads = rows * (co / 4);
-            hipLaunchKernelGGL(gather_max_kernel, dim3((nthreads + kThreads - 1) / kThreads), dim3(kThreads), 0, st, s.pq, co,
-                               s.idx, s.xc + col, 512, N, rows);
-            if ((rc = iq::check_launch("gather_max_kernel"))) return rc;
-        }
-        src = s.xc + col; ld = 512; cin = co; creal = co; col += co;
-    }
-    IQ_REQUIRE(col == 512, "iq_dgcnn_forward: concatenated width %d != 512", col);
-    {
-        iq::ProfileSpan span(iq::kSlotTrunk, st);
-        if ((rc = iq::launch_linear(s.xc, 512, w->conv5, s.h, 1024, rows, 2, st))) return rc;
-        hipLaunchKernelGGL(pool_max_avg_kernel, dim3(1024 / kThreads, B), dim3(kThreads), 0, st, s.h, s.g, N, 1024);
-        if ((rc = iq::check_launch("pool_max_avg_kernel"))) return rc;
-    }
-    if ((rc = iq::launch_linear(s.g, 2048, w->fc1, s.f1, 512, B, 2, st))) return rc;
-    if ((rc = iq::launch_linear(s.f1, 512, w->fc2, s.f2, 256, B, 2, st))) return rc;
-    if ((rc = iq::launch_linear(s.f2, 256, w->fc3, logits, w->fc3.cout, B, 0, st))) return rc;
-    return IQ_OK;
+    return run_network(w, s, logits, B, N, rows, fixed_graph, st);
+}
+
+extern "C" int iq_dgcnn_coalitions(const iq_dgcnn_weights* w, const float* clouds, const float* centers,
+                                   const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of, float* logits,
+                                   void* workspace, size_t workspace_bytes, int B, int nclouds, int N, int fixed_graph,
+                                   iq_stream_t stream) {
+    IQ_REQUIRE(B >= 0 && nclouds >= 1, "iq_dgcnn_coalitions: B=%d nclouds=%d", B, nclouds);
+    IQ_REQUIRE(w && clouds && centers && region_id && (B == 0 || (keep && logits)), "iq_dgcnn_coalitions: null pointer");
+    IQ_REQUIRE(N >= 32 && N % 32 == 0 && N <= 32767, "iq_dgcnn_coalitions: N=%d must be a multiple of 32", N);
+    IQ_REQUIRE(cloud_of || nclouds == 1 || nclouds == B, "iq_dgcnn_coalitions: cloud_of required when 1 < nclouds != B");
+    IQ_REQUIRE(w->k == kK, "iq_dgcnn_coalitions: k=%d (only 20)", w->k);
+    if (B == 0) return IQ_OK;
+    const size_t need = carve_d(nullptr, B, N).bytes;
+    if (!workspace || workspace_bytes < need)
+        return iq::fail(IQ_EWORKSPACE, "iq_dgcnn_coalitions: workspace %zu < %zu bytes", workspace_bytes, need);
+    WsD s = carve_d(workspace, B, N);
+    hipStream_t st = iq::as_stream(stream);
+    int rc;
+    iq::ProfileSpan call_span(iq::kSlotCall, st);
+    hipLaunchKernelGGL(dg_count_kernel, dim3(B), dim3(64), 0, st, region_id, keep, cloud_of, s.nkept, s.ncopy, s.dpad, N, nclouds);
+    hipLaunchKernelGGL(dg_scan_kernel, dim3(1), dim3(1024), 0, st, s.dpad, s.roff, B);
+    hipLaunchKernelGGL(dg_compact_kernel, dim3(B), dim3(64), 0, st, clouds, centers, region_id, keep, cloud_of, s.roff, s.nkept,
+                       s.ncopy, s.x0, s.row_cloud, N, nclouds);
+    if ((rc = iq::check_launch("dg_compact_kernel"))) return rc;
+    return run_network(w, s, logits, B, N, B * N, fixed_graph, st);
 }

@@ -481,7 +481,8 @@ __global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __rest
                                                              const float* __restrict__ wp,
                                                              const float* __restrict__ bias,
                                                              float* __restrict__ out, int ldo, int M, int K,
-                                                             int Nout, int relu) {
+                                                             int Nout, int relu, const int32_t* __restrict__ m_dev) {
+    if (m_dev) M = min(M, *m_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = (blockIdx.x * WM + wm) * MT * 32;
@@ -564,18 +565,18 @@ void launch_chain(const ChainArgs& a, hipStream_t st) {
 }  // namespace
 
 int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,
-                      hipStream_t st) {
+                      hipStream_t st, const int32_t* m_dev) {
     if (M == 0) return IQ_OK;
     IQ_REQUIRE(L.w && L.b && L.cin % 8 == 0 && L.cout >= 1, "dense layer: bad descriptor (cin=%d cout=%d)", L.cin, L.cout);
     const int ntiles = (L.cout + 31) / 32;
     if (ntiles >= 4) {
         dim3 grid((M + 127) / 128, (ntiles + 3) / 4);
         hipLaunchKernelGGL((pn_linear_kernel<2, 2, 2, 2>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M,
-                           L.cin, L.cout, relu);
+                           L.cin, L.cout, relu, m_dev);
     } else {
         dim3 grid((M + 255) / 256, ntiles);
         hipLaunchKernelGGL((pn_linear_kernel<2, 1, 4, 1>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M,
-                           L.cin, L.cout, relu);
+                           L.cin, L.cout, relu, m_dev);
     }
     return iq::check_launch("pn_linear_kernel");
 }

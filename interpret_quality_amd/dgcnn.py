@@ -90,6 +90,29 @@ class DgcnnEngine:
         return logits
 
 
+def _coalition_logits(eng, clouds, centers, region_id, keep, cloud_of):
+    """iq_dgcnn_coalitions: clouds (nc,N,3), centers (nc,3), region_id (nc,N) i32, keep (B,) i64 bit masks,
+    cloud_of (B,) i32 or None -> logits (B,C).  The masked clouds are never written."""
+    for t, dt, nm in ((clouds, torch.float32, "clouds"), (centers, torch.float32, "centers"), (region_id, torch.int32, "region_id"),
+                      (keep, torch.int64, "keep"), (cloud_of, torch.int32, "cloud_of")):
+        if t is None and nm == "cloud_of":
+            continue
+        if t is None or not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+            raise _lib.IqError("%s must be a contiguous %s GPU tensor" % (nm, dt))
+    nc, n, _ = clouds.shape
+    b = keep.shape[0]
+    need = eng.lib.iq_dgcnn_workspace_bytes(b, n)
+    if eng._ws is None or eng._ws.numel() < need:
+        eng._ws = torch.empty(int(need), dtype=torch.uint8, device=eng.device)
+    logits = torch.empty((b, eng.weights.num_classes), dtype=torch.float32, device=eng.device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    rc = eng.lib.iq_dgcnn_coalitions(ctypes.byref(eng.weights.struct), p(clouds), p(centers), p(region_id), p(keep), p(cloud_of),
+                                     p(logits), p(eng._ws), eng._ws.numel(), b, nc, n, eng.fixed_graph,
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "iq_dgcnn_coalitions")
+    return logits
+
+
 class _GraphCnn(nn.Module):
     fixed_graph = False
     max_clouds_per_call = 1024  # bounds the workspace (8.2 MB per cloud)
@@ -138,6 +161,22 @@ class _GraphCnn(nn.Module):
     def forward(self, x):
         """x (B,3,N) as in the reference -> logits (B,10)."""
         return self.forward_points(x.permute(0, 2, 1).contiguous())
+
+    def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None, num_regions=None):
+        """Same call as PointNetCls.coalition_logits: logits of B coalitions given as region bit masks."""
+        eng = self.engine()
+        step = self.max_clouds_per_call
+        nc, b = clouds.shape[0], keep.shape[0]
+        if cloud_of is None and nc not in (1, b):
+            raise _lib.IqError("cloud_of is required when 1 < number of clouds != number of coalitions")
+        if b <= step:
+            return _coalition_logits(eng, clouds, centers, region_id, keep, cloud_of)
+        if cloud_of is None and nc == b:
+            cloud_of = torch.arange(b, dtype=torch.int32, device=keep.device)
+        out = [_coalition_logits(eng, clouds, centers, region_id, keep[i:i + step].contiguous(),
+                                 cloud_of[i:i + step].contiguous() if cloud_of is not None else None)
+               for i in range(0, b, step)]
+        return torch.cat(out, dim=0)
 
 
 class DGCNN_cls(_GraphCnn):

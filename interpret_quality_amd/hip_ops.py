@@ -158,7 +158,7 @@ def knn(x, k=20):
     lib = _lib.load()
     b, n, c = x.shape
     out = torch.empty((b, n, k), dtype=torch.int32, device=x.device)
-    tmp = torch.empty((b * n * 76 + 4096,), dtype=torch.uint8, device=x.device)
+    tmp = torch.empty((b * n * 80 + 16 * b + 8192,), dtype=torch.uint8, device=x.device)
     _lib.check(lib.iq_knn(_dev(x, torch.float32, "x"), _p(out), _p(tmp), tmp.numel(), b, n, c, k, _stream()), "iq_knn")
     return out
 

@@ -152,3 +152,29 @@ def test_interaction_path_matches_reference(cls, name):
         vmax = np.abs(hip_ops.reward(torch.from_numpy(want).reshape(-1, 10).to(dev()), label).cpu().numpy()).max()
         tol = RTOL if name == "gcnn" else max(RTOL, 40 * float(cond.max()))
         assert np.abs(inter - g["%s_%s_interaction" % (tag, name)]).max() < tol * vmax
+
+
+@pytest.mark.parametrize("cls", [DGCNN_cls, GCNN_cls])
+def test_compact_coalitions_equal_the_dense_forward_on_masked_clouds(cls):
+    """iq_dgcnn_coalitions (kept points + <= 20 centre copies per coalition) against iq_dgcnn_forward on the
+    materialised masked clouds: the same arithmetic on fewer rows, so agreement is to rounding of the mean pool.
+    Covers no / few (< 20) / many / all points masked and several source clouds (cloud_of)."""
+    model = make(cls)
+    d = dev()
+    rng = np.random.default_rng(3)
+    clouds = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in (0, 1)]).to(d)           # (2,1024,3)
+    rid = torch.from_numpy(rng.integers(0, 32, size=(2, 1024)).astype(np.int32))
+    rid[0, :12] = 40                                               # a 12-point region (fewer than 20 centre copies)
+    rid[0, 12:] = torch.clamp(rid[0, 12:], max=31)
+    centers = clouds.mean(dim=1)
+    full = (1 << 41) - 1
+    keep = [full, 0, full ^ (1 << 40), 1 << 40, 0x0f0f0f0f, (1 << 32) - 1, 1 << 5, full ^ 1, 0xaaaaaaaa | (1 << 40), 7]
+    cloud_of = [0, 0, 0, 0, 0, 1, 1, 1, 1, 1]
+    keep_t = hip_ops.masks_to_tensor(keep, d)
+    co_t = torch.tensor(cloud_of, dtype=torch.int32, device=d)
+    got = model.coalition_logits(clouds, centers, rid.to(d), keep_t, co_t, num_regions=41)
+    dense = []
+    for k, c in zip(keep, cloud_of):
+        dense.append(hip_ops.mask_coalitions(clouds[c], rid[c].to(d), hip_ops.masks_to_tensor([k], d), centers[c].contiguous())[0])
+    want = model.forward_points(torch.stack(dense))
+    assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-5

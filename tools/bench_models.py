@@ -26,6 +26,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--mode", default="shapley", choices=["shapley", "interaction"])
 ap.add_argument("--pairs", type=int, default=30)
 ap.add_argument("--contexts", type=int, default=100)
+ap.add_argument("--dense", action="store_true", help="materialise the masked clouds even if the model has a coalition path")
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -45,6 +46,14 @@ elif a.model == "pointconv":
 else:
     raise SystemExit("unknown model")
 model = model.to(dev).eval()
+if a.dense and hasattr(model, "coalition_logits"):
+    class DenseOnly:                       # hides coalition_logits: callers fall back to mask kernel + forward_points
+        def __init__(self, m):
+            self.forward_points, self.m = m.forward_points, m
+
+        def __call__(self, x):
+            return self.m(x)
+    model = DenseOnly(model)
 pts, label = synth.make_cloud(0)
 data = torch.from_numpy(pts).unsqueeze(0).to(dev)
 lbl = torch.tensor([label], device=dev)
