@@ -163,6 +163,7 @@ __global__ __launch_bounds__(kThreads, 2) void knn_kernel(const float* __restric
     constexpr int LD = C + 4, KB = C / 8;
     __shared__ __attribute__((aligned(16))) float keys[2][32 * LD];
     __shared__ float kxx[2][32];
+    __shared__ double queue[kThreads / 64][16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const int base = rg.roff[b];
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(kThreads, 2) void knn_kernel(const float* __restric
         if (tid < 32) kxx[buf][tid] = xxb[tile * 32 + tid];
     };
 
-    TopK<kK> top;
-    top.init();
+    QueuedTopK<kK, 16> top;
+    top.init(queue[wave]);
     const int ntiles = N / 32;
     stage(0, 0);
     __syncthreads();
@@ -209,14 +210,15 @@ __global__ __launch_bounds__(kThreads, 2) void knn_kernel(const float* __restric
             const float inner = -2.f * acc[r];                              // -2 * matmul
             d[r] = ((-kxx[buf][c_row(r, lane)]) - inner) - xxq;             // -xx - inner - xx^T (models/dgcnn.py:15)
         }
-        top.offer_tile(d, t * 32, fh);
+        top.offer_tile(d, t * 32, lane);
         __syncthreads();
     }
+    top.flush(lane);
     top.merge_halves();  // each half-wave saw half of the keys of every tile
     if (fh == 0 && wave_live) {
         int16_t* o = idx + ((size_t)base + q0 + fl) * kK;
 #pragma unroll
-        for (int q = 0; q < kK; ++q) o[q] = (int16_t)top.i[q];
+        for (int q = 0; q < kK; ++q) o[q] = (int16_t)top.index(q);
     }
 }
 

@@ -51,3 +51,89 @@ struct TopK {
         for (int q = 0; q < K; ++q) offer(pv[q], pi[q]);
     }
 };
+
+// ------------------------------------------------------------------------------------------------------------------
+// Queued top-K for the MFMA distance tiles (queries on lanes, 16 keys per lane and tile).
+//
+// Selection, not distance arithmetic, bounds kNN: a lane inserts ~K(1 + ln(n/K)) of its n keys, but with 64 queries in
+// lock-step nearly every key position has SOME lane inserting, so a wave that inserts "when any lane must" pays for
+// the maximum over lanes at every tile.  Two changes remove that:
+//  * the list is ONE sorted array of doubles: (double)distance with the key index OR-ed into mantissa bits far below
+//    fp32 precision.  Order by value (ties: by index), conversion back to fp32 is exact, and a sorted insert is
+//    v[q] = max(min(c, v[q-1]), v[q]) - two full-rate fp64 ops per slot, no index array, no minimum search;
+//  * candidates that beat the lane's threshold are appended to a small per-lane LDS queue and inserted in rounds that
+//    only run while at least a quarter of the lanes have work (or a queue could overflow), so the rounds per wave
+//    approach the busiest lane's total instead of the sum over tiles of the per-tile maximum.
+// A candidate may wait while the threshold rises; inserting it late is then a no-op, never an error.
+template <int K, int CAP = 16>
+struct QueuedTopK {
+    static constexpr int kIndexBits = 15;  // key index < 32768
+    double v[K];                           // descending
+    float thr;                             // (float)v[K-1]
+    int cnt;                               // queued candidates of this lane
+    double* q;                             // this wave's queue, slot-major: q[slot * 64 + lane]
+
+    __device__ __forceinline__ void init(double* wave_queue) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) v[i] = -INFINITY;
+        thr = -INFINITY;
+        cnt = 0;
+        q = wave_queue;
+    }
+    static __device__ __forceinline__ double pack(float d, int idx) {
+        return __longlong_as_double(__double_as_longlong((double)d) | (long long)idx);
+    }
+    __device__ __forceinline__ void insert(double c) {
+#pragma unroll
+        for (int i = K - 1; i >= 1; --i) v[i] = fmax(fmin(c, v[i - 1]), v[i]);
+        v[0] = fmax(c, v[0]);
+        thr = (float)v[K - 1];
+    }
+    __device__ __forceinline__ void round(int lane) {
+        double c = -INFINITY;
+        if (cnt > 0) c = q[(--cnt) * 64 + lane];
+        insert(c);
+    }
+    // make room for `need` more candidates per lane, and use rounds that are well filled anyway
+    __device__ __forceinline__ void drain(int lane, int need) {
+        for (;;) {
+            const unsigned long long busy = __ballot(cnt > 0);
+            if (busy == 0) break;
+            if (__popcll(busy) < 16 && !__any(cnt > CAP - need)) break;
+            round(lane);
+        }
+    }
+    __device__ __forceinline__ void flush(int lane) {
+        while (__any(cnt > 0)) round(lane);
+    }
+    // the 16 distances of one accumulator tile (rows c_row(r, lane) of the key tile starting at idx_base)
+    __device__ __forceinline__ void offer_tile(const float (&d)[16], int idx_base, int lane) {
+        const int fh = lane >> 5;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            drain(lane, 8);
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = half * 8 + rr;
+                if (d[r] > thr) {
+                    q[cnt * 64 + lane] = pack(d[r], idx_base + (r & 3) + 8 * (r >> 2) + 4 * fh);
+                    ++cnt;
+                }
+            }
+        }
+    }
+    // union with the partner half-wave (lane ^ 32), which saw the other half of every key tile: the K largest of two
+    // descending lists are max(a[i], b[K-1-i]) (first step of a bitonic merge; the result is an unordered set)
+    __device__ __forceinline__ void merge_halves() {
+        double m[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const long long pb = __double_as_longlong(v[K - 1 - i]);
+            const int lo = __shfl_xor((int)(pb & 0xffffffffll), 32), hi = __shfl_xor((int)(pb >> 32), 32);
+            m[i] = fmax(v[i], __longlong_as_double(((long long)hi << 32) | (unsigned int)lo));
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i) v[i] = m[i];
+    }
+    __device__ __forceinline__ int index(int i) const { return (int)(__double_as_longlong(v[i]) & ((1ll << kIndexBits) - 1)); }
+};
