@@ -162,6 +162,13 @@ typedef struct iq_pointnet_weights {
     iq_dense_layer feat_c2, feat_c3, cls_fc1, cls_fc2, cls_fc3;
 } iq_pointnet_weights;
 
+/* out (M,ldo) = act(A (M,lda) . W^T + b): the dense layer every model kernel shares (1x1 convolutions and
+ * fully connected layers with BatchNorm folded: models/pointnet.py:24-29, models/dgcnn.py:66-80,
+ * models/pointnet2.py:163-170 ...), exposed for tests and callers that fold their own layers.
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).  Device pointers; L->cin % 8 == 0. */
+int iq_linear(const float* A, int lda, const iq_dense_layer* L, float* out, int ldo, int M, int act,
+              iq_stream_t stream);
+
 /* Host-side packing helpers (host pointers).  iq_packed_floats = number of floats of the packed
  * image of a (cout, cin) weight; cin must be a multiple of 8. */
 size_t iq_packed_floats(int cout, int cin);
@@ -314,7 +321,9 @@ int iq_pointconv_forward(const iq_pointconv_weights* w /*host struct of device p
  * chain, 2 = trunk chain, 3 = whole iq_pointnet_coalitions call. */
 int iq_profile_enable(int on);
 /* Experiment knob: selects between co-compiled kernel variants so that they can be timed
- * interleaved in ONE process.  key 0 = L3 weight-streaming variant of the chain kernel. */
+ * interleaved in ONE process.  key 0 = L3 weight-streaming variant of the chain kernel; 1 = extra dynamic LDS
+ * of the chain kernel (occupancy experiment); 2 = 1: no LPT launch order; 3 = 1: dense layers never use the
+ * LDS-staged GEMM (pn_gemm_lds_kernel), only the register-streaming one. */
 int iq_set_tuning(int key, int value);
 /* Debug: workgroups per CU the runtime admits for the chain kernel variants (100*v0 + v2). */
 int iq_debug_chain_occupancy(void);

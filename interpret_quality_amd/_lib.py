@@ -84,6 +84,7 @@ SIGNATURES = {
     "iq_region_assign": (_I, [_P, _P, _P, _I, _I, _P]),
     "iq_fps": (_I, [_P, _P, _I, _I, _I, _P]),
     "iq_smoothness_enum": (_I, [_P, _P, _P, _I, _I, _I, _I, ctypes.POINTER(SmoothnessParams), _P, _P, _P, _P, _P, _P]),
+    "iq_linear": (_I, [_P, _I, ctypes.POINTER(DenseLayer), _P, _I, _I, _I, _P]),
     "iq_packed_floats": (_SZ, [_I, _I]),
     "iq_padded_cout": (_I, [_I]),
     "iq_pack_weight": (_I, [_P, _P, _I, _I]),

@@ -43,13 +43,14 @@ struct Ragged {
     const int32_t* nkept;      // (B) kept points = rows [0, nkept)
     const int32_t* ncopy;      // (B) centre copies = rows [nkept, nkept + ncopy)
     const int32_t* row_cloud;  // (rows) cloud of a row
+    float* row_w;              // (rows) pooling weight: kept 1, first centre copy M, other copies and dead rows 0
 };
 
 // dense forward: D_b = N
 __global__ void dg_dense_layout_kernel(int32_t* __restrict__ roff, int32_t* __restrict__ nkept, int32_t* __restrict__ ncopy,
-                                       int32_t* __restrict__ row_cloud, int B, int N) {
+                                       int32_t* __restrict__ row_cloud, float* __restrict__ row_w, int B, int N) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < B * N) row_cloud[t] = t / N;
+    if (t < B * N) { row_cloud[t] = t / N; if (row_w) row_w[t] = 1.f; }
     if (t <= B) roff[t] = t * N;
     if (t < B) { nkept[t] = N; ncopy[t] = 0; }
 }
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(64) void dg_compact_kernel(const float* __restrict_
                                                         const int32_t* __restrict__ region_id, const uint64_t* __restrict__ keep,
                                                         const int32_t* __restrict__ cloud_of, const int32_t* __restrict__ roff,
                                                         const int32_t* __restrict__ nkept, const int32_t* __restrict__ ncopy,
-                                                        float* __restrict__ x0, int32_t* __restrict__ row_cloud, int N,
-                                                        int nclouds) {
+                                                        float* __restrict__ x0, int32_t* __restrict__ row_cloud,
+                                                        float* __restrict__ row_w, int N, int nclouds) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int c = cloud_of ? cloud_of[b] : (nclouds == 1 ? 0 : b);
     const uint64_t k = keep[b];
@@ -128,7 +129,12 @@ __global__ __launch_bounds__(64) void dg_compact_kernel(const float* __restrict_
         reinterpret_cast<f32x4*>(x0)[(size_t)row * 2] = (row < base + live) ? ctr : z;
         reinterpret_cast<f32x4*>(x0)[(size_t)row * 2 + 1] = z;
     }
-    for (int row = base + lane; row < end; row += 64) row_cloud[row] = b;
+    const int nk = nkept[b];
+    for (int row = base + lane; row < end; row += 64) {
+        row_cloud[row] = b;
+        const int rl = row - base;
+        row_w[row] = rl < nk ? 1.f : (rl == nk && ncopy[b] > 0 ? (float)(N - nk) : 0.f);
+    }
 }
 
 // ---- xx[i] = sum_c x[i][c]^2 in channel order (torch.sum(x**2, dim=1)) ------------------------------
@@ -249,25 +255,20 @@ __global__ __launch_bounds__(kThreads) void gather_max_kernel(const float* __res
     *reinterpret_cast<f32x4*>(out + (size_t)pt * ldo + c4 * 4) = o;
 }
 
-// ---- global max and mean pooling over the N points of each cloud: (rows,C) -> (B,2C) --------------------------------
-// Kept rows count once, the centre (all copies identical) counts with its multiplicity M = N - kept.
-__global__ __launch_bounds__(kThreads) void pool_max_avg_kernel(const float* __restrict__ h, float* __restrict__ out,
-                                                                Ragged rg, int N, int C) {
+// ---- global max and mean pooling over the N points of each cloud: folded into conv5 (launch_linear_pool) -------------
+// Kept rows count once, the centre (all copies identical) counts with its multiplicity M = N - kept (row_w).
+// second stage of the pooling after launch_linear_pool: tiles of 32 rows never straddle clouds
+__global__ __launch_bounds__(kThreads) void pool_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                               Ragged rg, int N, int C) {
     const int b = blockIdx.y;
     const int c = blockIdx.x * kThreads + threadIdx.x;
     if (c >= C) return;
-    const int nk = rg.nkept[b];
-    const float* p = h + (size_t)rg.roff[b] * C + c;
+    const int t0 = rg.roff[b] >> 5, t1 = rg.roff[b + 1] >> 5;
     float m = -INFINITY, s = 0.f;
-    for (int i = 0; i < nk; ++i) {
-        const float v = p[(size_t)i * C];
-        m = fmaxf(m, v);
-        s += v;
-    }
-    if (rg.ncopy[b] > 0) {
-        const float v = p[(size_t)nk * C];
-        m = fmaxf(m, v);
-        s += (float)(N - nk) * v;
+    for (int t = t0; t < t1; ++t) {
+        const float* p = partial + (size_t)t * 2 * C;
+        m = fmaxf(m, p[c]);
+        s += p[C + c];
     }
     out[(size_t)b * 2 * C + c] = m;
     out[(size_t)b * 2 * C + C + c] = s / (float)N;
@@ -289,9 +290,10 @@ struct WsD {
     float* pq;      // (B,N,512)
     float* xx;      // (B,N)
     int16_t* idx;   // (B,N,20)
-    float* h;       // (B,N,1024)
+    float* h;       // (B*N/32, 2, 1024) per-tile max / weighted sum of conv5
     float *g, *f1, *f2;
     int32_t *roff, *nkept, *ncopy, *dpad, *row_cloud;  // ragged layout
+    float* row_w;
     size_t bytes;
 };
 
@@ -309,7 +311,7 @@ WsD carve_d(void* base, int B, int N) {
     s.pq = (float*)take(r * 512 * 4);
     s.xx = (float*)take(r * 4);
     s.idx = (int16_t*)take(r * kK * 2);
-    s.h = (float*)take(r * 1024 * 4);
+    s.h = (float*)take(r * 64 * 4);  // pooling partials of conv5: (rows/32, 2, 1024)
     s.g = (float*)take((size_t)B * 2048 * 4);
     s.f1 = (float*)take((size_t)B * 512 * 4);
     s.f2 = (float*)take((size_t)B * 256 * 4);
@@ -318,6 +320,7 @@ WsD carve_d(void* base, int B, int N) {
     s.ncopy = (int32_t*)take((size_t)B * 4);
     s.dpad = (int32_t*)take((size_t)B * 4);
     s.row_cloud = (int32_t*)take(r * 4);
+    s.row_w = (float*)take(r * 4);
     s.bytes = off;
     return s;
 }
@@ -354,8 +357,9 @@ extern "C" int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes,
     int32_t* roff = reinterpret_cast<int32_t*>(take((size_t)(B + 1) * 4));
     int32_t* nkept = reinterpret_cast<int32_t*>(take((size_t)B * 4));
     int32_t* ncopy = reinterpret_cast<int32_t*>(take((size_t)B * 4));
-    hipLaunchKernelGGL(dg_dense_layout_kernel, dim3((r + 256) / 256), dim3(256), 0, st, roff, nkept, ncopy, row_cloud, B, N);
-    const Ragged rg{roff, nkept, ncopy, row_cloud};
+    hipLaunchKernelGGL(dg_dense_layout_kernel, dim3((r + 256) / 256), dim3(256), 0, st, roff, nkept, ncopy, row_cloud,
+                       (float*)nullptr, B, N);
+    const Ragged rg{roff, nkept, ncopy, row_cloud, nullptr};
     const float* src = x;
     int ld = C, cpad = C;
     if (C == 3) {
@@ -375,7 +379,7 @@ namespace {
 // `rows` = upper bound of the row count (grid sizes); the live count is roff[B], on the device.
 int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, int N, int rows, int fixed_graph,
                 hipStream_t st) {
-    const Ragged rg{s.roff, s.nkept, s.ncopy, s.row_cloud};
+    const Ragged rg{s.roff, s.nkept, s.ncopy, s.row_cloud, s.row_w};
     const int32_t* live = s.roff + B;
     int rc;
     const float* src = s.x0;
@@ -401,9 +405,11 @@ int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, i
     IQ_REQUIRE(col == 512, "iq_dgcnn: concatenated width %d != 512", col);
     {
         iq::ProfileSpan span(iq::kSlotTrunk, st);
-        if ((rc = iq::launch_linear(s.xc, 512, w->conv5, s.h, 1024, rows, 2, st, live))) return rc;
-        hipLaunchKernelGGL(pool_max_avg_kernel, dim3(1024 / kThreads, B), dim3(kThreads), 0, st, s.h, s.g, rg, N, 1024);
-        if ((rc = iq::check_launch("pool_max_avg_kernel"))) return rc;
+        // conv5 + LeakyReLU with the pooling folded into the GEMM epilogue (s.h holds the per-tile partials)
+        IQ_REQUIRE(w->conv5.cout == 1024 && w->conv5.cin == 512, "iq_dgcnn: conv5 must be 512 -> 1024");
+        if ((rc = iq::launch_linear_pool(s.xc, 512, w->conv5, s.h, rows, 2, s.row_w, st, live))) return rc;
+        hipLaunchKernelGGL(pool_reduce_kernel, dim3(1024 / kThreads, B), dim3(kThreads), 0, st, s.h, s.g, rg, N, 1024);
+        if ((rc = iq::check_launch("pool_reduce_kernel"))) return rc;
     }
     if ((rc = iq::launch_linear(s.g, 2048, w->fc1, s.f1, 512, B, 2, st))) return rc;
     if ((rc = iq::launch_linear(s.f1, 512, w->fc2, s.f2, 256, B, 2, st))) return rc;
@@ -428,7 +434,7 @@ extern "C" int iq_dgcnn_forward(const iq_dgcnn_weights* w, const float* xyz, flo
     int rc;
     iq::ProfileSpan call_span(iq::kSlotCall, st);
     hipLaunchKernelGGL(dg_dense_layout_kernel, dim3((rows + 256) / 256), dim3(256), 0, st, s.roff, s.nkept, s.ncopy,
-                       s.row_cloud, B, N);
+                       s.row_cloud, s.row_w, B, N);
     hipLaunchKernelGGL(pad_xyz_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, xyz, s.x0, rows);
     if ((rc = iq::check_launch("pad_xyz_kernel"))) return rc;
     return run_network(w, s, logits, B, N, rows, fixed_graph, st);
@@ -454,7 +460,7 @@ extern "C" int iq_dgcnn_coalitions(const iq_dgcnn_weights* w, const float* cloud
     hipLaunchKernelGGL(dg_count_kernel, dim3(B), dim3(64), 0, st, region_id, keep, cloud_of, s.nkept, s.ncopy, s.dpad, N, nclouds);
     hipLaunchKernelGGL(dg_scan_kernel, dim3(1), dim3(1024), 0, st, s.dpad, s.roff, B);
     hipLaunchKernelGGL(dg_compact_kernel, dim3(B), dim3(64), 0, st, clouds, centers, region_id, keep, cloud_of, s.roff, s.nkept,
-                       s.ncopy, s.x0, s.row_cloud, N, nclouds);
+                       s.ncopy, s.x0, s.row_cloud, s.row_w, N, nclouds);
     if ((rc = iq::check_launch("dg_compact_kernel"))) return rc;
     return run_network(w, s, logits, B, N, B * N, fixed_graph, st);
 }

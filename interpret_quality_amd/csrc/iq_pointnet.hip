@@ -551,6 +551,171 @@ __global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __rest
     }
 }
 
+// Large-M variant: the A operand goes through LDS.  In pn_linear_kernel every A-fragment load touches 32 cache lines
+// (32 rows x 16 B) and is repeated by the wave beside it, which keeps the L1 address path - not the MFMA - busy
+// (measured 58 % of the fp32 MFMA peak on 512 -> 1024).  Here the workgroup copies a 128-row x 32-k chunk with
+// full-line coalesced loads (8 lanes per 128 B row segment), double-buffered, and the four waves (2 x 2, wave tile
+// 64 x NT*32) read their fragments from LDS (row stride 36 floats: conflict-free ds_read_b128); B fragments still
+// stream from the packed image, prefetched two k-blocks ahead.  Same MFMA order over k as pn_linear_kernel, so the
+// results are bit-identical.  Needs K % 32 == 0.
+// POOL: instead of the activations, every 32-row tile writes its column-wise maximum and row-weighted sum over the
+// rows with weight > 0 (out = (ceil(M/32), 2, Nout)): the input of a pooling layer without the round trip of the
+// (M, Nout) activations through HBM.
+template <int NT, bool POOL>
+__global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* __restrict__ A, int lda,
+                                                                  const float* __restrict__ wp,
+                                                                  const float* __restrict__ bias, float* __restrict__ out,
+                                                                  int ldo, int M, int K, int Nout, int relu,
+                                                                  const int32_t* __restrict__ m_dev,
+                                                                  const float* __restrict__ row_w) {
+    constexpr int KC = 32, LDA = KC + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][128 * LDA];
+    if (m_dev) M = min(M, *m_dev);
+    const int m0 = blockIdx.x * 128;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int KB = K >> 3, nchunks = K / KC;
+    const int ntiles = (Nout + 31) >> 5;
+    const int nt0 = (blockIdx.y * 2 + wn) * NT;
+
+    // chunk copy: 128 rows x 8 float4; thread t owns (row, c4) = (e >> 3, e & 7) for e = t + 256 i
+    const float* arow[4];
+    int soff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + kThreads * i, row = e >> 3, c4 = e & 7;
+        arow[i] = A + (size_t)min(m0 + row, M - 1) * lda + c4 * 4;
+        soff[i] = row * LDA + c4 * 4;
+    }
+    f32x4 stage[4];
+    auto load_chunk = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage[i] = *reinterpret_cast<const f32x4*>(arow[i] + kc * KC);
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&As[buf][soff[i]]) = stage[i];
+    };
+
+    const float* bp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bp[j] = wp + ((size_t)min(nt0 + j, ntiles - 1) * KB * 64 + lane) * 4;
+    // B fragments in a 2-deep register ring (k-blocks kb, kb + 1); the slot just consumed is refilled with kb + 2, i.e.
+    // 2 x 8 NT MFMAs (>= 4096 cycles) ahead of its use.  sched_group_barrier pins that order: left alone, the
+    // scheduler sinks the loads next to their uses and the MFMAs wait on L2.
+    f32x4 ring[2][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        ring[0][j] = *reinterpret_cast<const f32x4*>(bp[j]);
+        ring[1][j] = *reinterpret_cast<const f32x4*>(bp[j] + (size_t)min(1, KB - 1) * 256);
+    }
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x16){0};
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    const int aoff = (wm * 64 + (lane & 31)) * LDA + 4 * (lane >> 5);
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const float* as = As[kc & 1] + aoff;
+        f32x4 a0n = *reinterpret_cast<const f32x4*>(as), a1n = *reinterpret_cast<const f32x4*>(as + 32 * LDA);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const int kb = kc * 4 + k4;
+            const f32x4 a0 = a0n, a1 = a1n;
+            if (k4 < 3) {
+                a0n = *reinterpret_cast<const f32x4*>(as + 8 * (k4 + 1));
+                a1n = *reinterpret_cast<const f32x4*>(as + 32 * LDA + 8 * (k4 + 1));
+            }
+            const size_t kn = (size_t)min(kb + 2, KB - 1) * 256;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const f32x4 bk = ring[k4 & 1][j];
+                acc[0][j] = mfma4(a0, bk, acc[0][j]);
+                acc[1][j] = mfma4(a1, bk, acc[1][j]);
+                ring[k4 & 1][j] = *reinterpret_cast<const f32x4*>(bp[j] + kn);
+            }
+            if (k4 < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // next chunk's A rows: issued behind the first k-block so that no MFMA of this chunk has to wait for them
+            // (memory returns in order: a wait on an older B fragment never covers these)
+            if (k4 == 0 && kc + 1 < nchunks) {
+                load_chunk(kc + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (kc + 1 < nchunks) store_chunk((kc + 1) & 1);
+        __syncthreads();
+    }
+    if (POOL) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int trow = m0 + wm * 64 + i * 32;  // first row of this 32-row tile
+            if (trow >= M) continue;
+            float w[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = trow + c_row(r, lane);
+                w[r] = row < M ? row_w[row] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = (nt0 + j) * 32 + (lane & 31);
+                const bool ok = nt0 + j < ntiles && col < Nout;
+                const float b = ok ? bias[col] : 0.f;
+                float mx = -INFINITY, sm = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + b;
+                    if (relu == 1) v = fmaxf(v, 0.f);
+                    else if (relu == 2) v = v > 0.f ? v : 0.2f * v;
+                    if (w[r] > 0.f) {
+                        mx = fmaxf(mx, v);
+                        sm += w[r] * v;
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                sm += __shfl_xor(sm, 32);
+                if (ok && lane < 32) {
+                    float* o = out + (size_t)(trow >> 5) * 2 * Nout;
+                    o[col] = mx;
+                    o[Nout + col] = sm;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = (nt0 + j) * 32 + (lane & 31);
+        if (nt0 + j >= ntiles || col >= Nout) continue;
+        const float b = bias[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + c_row(r, lane);
+                if (row < M) {
+                    float v = acc[i][j][r] + b;
+                    if (relu == 1) v = fmaxf(v, 0.f);
+                    else if (relu == 2) v = v > 0.f ? v : 0.2f * v;
+                    out[(size_t)row * ldo + col] = v;
+                }
+            }
+        }
+    }
+}
+
 template <int MODE>
 void launch_chain(const ChainArgs& a, hipStream_t st) {
     const size_t extra_lds = (size_t)iq::tuning(iq::kTuneExtraLds);  // experiment: lower the occupancy
@@ -569,6 +734,18 @@ int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* o
     if (M == 0) return IQ_OK;
     IQ_REQUIRE(L.w && L.b && L.cin % 8 == 0 && L.cout >= 1, "dense layer: bad descriptor (cin=%d cout=%d)", L.cin, L.cout);
     const int ntiles = (L.cout + 31) / 32;
+    if (M >= 2048 && ntiles >= 4 && L.cin % 32 == 0 && iq::tuning(iq::kTuneNoLdsGemm) == 0) {
+        if (ntiles >= 16 && (long long)((M + 127) / 128) * ((ntiles + 7) / 8) >= 2048) {
+            dim3 grid((M + 127) / 128, (ntiles + 7) / 8);
+            hipLaunchKernelGGL((pn_gemm_lds_kernel<4, false>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
+                               L.cout, relu, m_dev, nullptr);
+        } else {
+            dim3 grid((M + 127) / 128, (ntiles + 3) / 4);
+            hipLaunchKernelGGL((pn_gemm_lds_kernel<2, false>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
+                               L.cout, relu, m_dev, nullptr);
+        }
+        return iq::check_launch("pn_gemm_lds_kernel");
+    }
     if (ntiles >= 4) {
         dim3 grid((M + 127) / 128, (ntiles + 3) / 4);
         hipLaunchKernelGGL((pn_linear_kernel<2, 2, 2, 2>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M,
@@ -579,6 +756,27 @@ int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* o
                            L.cin, L.cout, relu, m_dev);
     }
     return iq::check_launch("pn_linear_kernel");
+}
+
+int iq::launch_linear_pool(const float* A, int lda, const iq_dense_layer& L, float* partial, int M, int relu,
+                           const float* row_w, hipStream_t st, const int32_t* m_dev) {
+    if (M == 0) return IQ_OK;
+    IQ_REQUIRE(L.w && L.b && row_w && partial, "dense layer + pool: null pointer");
+    const int ntiles = (L.cout + 31) / 32;
+    if (L.cin % 32 != 0 || ntiles < 8 || L.cout % 32 != 0)
+        return iq::fail(IQ_EUNSUPPORTED, "dense layer + pool: cin=%d cout=%d", L.cin, L.cout);
+    dim3 grid((M + 127) / 128, (ntiles + 7) / 8);
+    hipLaunchKernelGGL((pn_gemm_lds_kernel<4, true>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, partial, 0, M, L.cin, L.cout,
+                       relu, m_dev, row_w);
+    return iq::check_launch("pn_gemm_lds_kernel<pool>");
+}
+
+extern "C" int iq_linear(const float* A, int lda, const iq_dense_layer* L, float* out, int ldo, int M, int act,
+                         iq_stream_t stream) {
+    IQ_REQUIRE(A && L && out, "iq_linear: null pointer");
+    IQ_REQUIRE(M >= 0 && act >= 0 && act <= 2 && lda >= L->cin && ldo >= L->cout, "iq_linear: M=%d act=%d lda=%d ldo=%d", M,
+               act, lda, ldo);
+    return iq::launch_linear(A, lda, *L, out, ldo, M, act, iq::as_stream(stream));
 }
 
 namespace {

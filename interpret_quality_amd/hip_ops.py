@@ -188,3 +188,28 @@ def smoothness_enum(cloud, region_id, num_regions, mode, objective, step=1e-3, e
                                       _p(out["data"]), _p(out["smoothness"]), _p(out["var"]), _p(out["orig"]),
                                       _p(out["stop_epoch"]), _stream()), "iq_smoothness_enum")
     return out
+
+
+class PackedLinear:
+    """A (cout,cin) weight + bias in the library's MFMA fragment order (iq_pack_weight) on the device."""
+
+    def __init__(self, weight, bias, device):
+        lib = _lib.load()
+        w = np.ascontiguousarray(weight, dtype=np.float32)
+        self.cout, self.cin = w.shape
+        packed = np.empty(lib.iq_packed_floats(self.cout, self.cin), dtype=np.float32)
+        _lib.check(lib.iq_pack_weight(w.ctypes.data, packed.ctypes.data, self.cout, self.cin), "iq_pack_weight")
+        bp = np.zeros(lib.iq_padded_cout(self.cout), dtype=np.float32)
+        bp[:self.cout] = np.asarray(bias, dtype=np.float32)
+        self.w, self.b = torch.from_numpy(packed).to(device), torch.from_numpy(bp).to(device)
+        self.struct = _lib.DenseLayer(self.w.data_ptr(), self.b.data_ptr(), self.cin, self.cout)
+
+
+def linear(x, layer, act=0):
+    """x (M,cin) f32 -> act(x W^T + b) (M,cout); act 0 none, 1 ReLU, 2 LeakyReLU(0.2)."""
+    lib = _lib.load()
+    m = x.shape[0]
+    out = torch.empty((m, layer.cout), dtype=torch.float32, device=x.device)
+    _lib.check(lib.iq_linear(_dev(x, torch.float32, "x"), x.shape[1], ctypes.byref(layer.struct), _p(out), layer.cout, m, int(act),
+                             _stream()), "iq_linear")
+    return out

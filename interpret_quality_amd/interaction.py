@@ -64,7 +64,8 @@ def compute_order_interaction_logits(model, data_disturb, region_id, region_pair
                 logits = model.coalition_logits(data_disturb.contiguous(), center.contiguous(), rid.reshape(1, -1),
                                                 hip_ops.masks_to_tensor(keep_np, dev), None, num_regions=r)
             else:
-                bs = 4 * args.interaction_batch_size
+                # config.py's knob is a floor: rows are independent in eval mode, larger launches give the same logits
+                bs = max(4 * args.interaction_batch_size, getattr(model, "preferred_clouds_per_call", 0))
                 keep = hip_ops.masks_to_tensor(keep_np, dev)
                 chunks = []
                 points_api = hasattr(model, "forward_points")  # consumes (B,N,3) directly: no transpose

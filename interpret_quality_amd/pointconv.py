@@ -121,6 +121,7 @@ class PointConvDensityClsSsg(nn.Module):
     """Parameter container with the reference's state-dict layout; forward runs on the HIP path."""
 
     max_clouds_per_call = 1024  # bounds the workspace (9.4 MB per cloud)
+    preferred_clouds_per_call = 1024  # drivers batch at least this many materialised clouds per launch
 
     def __init__(self, args=None):
         super().__init__()

@@ -128,6 +128,7 @@ class PointNet2ClsMsg(nn.Module):
     """Parameter container with the reference's state-dict layout; forward runs on the HIP path."""
 
     max_clouds_per_call = 2048  # bounds the workspace (2.9 MB per cloud)
+    preferred_clouds_per_call = 1024  # drivers batch at least this many materialised clouds per launch
 
     def __init__(self, args=None):
         super().__init__()

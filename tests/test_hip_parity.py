@@ -285,3 +285,33 @@ def test_pointnet_multi_cloud_batch(model, oracle):
                                      region_id[c:c + 1].contiguous(), hip_ops.masks_to_tensor([m], d), None,
                                      num_regions=8)
         assert torch.equal(got[k], one[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# the shared dense layer (register-streaming and LDS-staged GEMM variants)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,cin,cout,act", [(5000, 512, 1024, 2), (4133, 64, 128, 0), (2048, 128, 512, 1), (3000, 1024, 160, 1),
+                                             (300, 256, 40, 0), (2500, 8, 128, 0)])
+def test_linear_variants_agree_and_match_fp32_reference(m, cin, cout, act):
+    from interpret_quality_amd import _lib
+    rng = np.random.default_rng(m + cin)
+    w = (rng.standard_normal((cout, cin)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    x = rng.standard_normal((m, cin)).astype(np.float32)
+    d = dev()
+    layer = hip_ops.PackedLinear(w, b, d)
+    xt = torch.from_numpy(x).to(d)
+    lib = _lib.load()
+    got = hip_ops.linear(xt, layer, act)                       # LDS-staged GEMM where the shape allows it
+    lib.iq_set_tuning(3, 1)
+    try:
+        streaming = hip_ops.linear(xt, layer, act)             # register-streaming kernel only
+    finally:
+        lib.iq_set_tuning(3, 0)
+    assert torch.equal(got, streaming)                         # same MFMA order over k: bit-identical
+    ref = torch.from_numpy(x).double() @ torch.from_numpy(w).double().T + torch.from_numpy(b).double()
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.leaky_relu(ref, 0.2)
+    assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-5

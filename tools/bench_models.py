@@ -26,11 +26,15 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--mode", default="shapley", choices=["shapley", "interaction"])
 ap.add_argument("--pairs", type=int, default=30)
 ap.add_argument("--contexts", type=int, default=100)
+ap.add_argument("--tune", default="", help="iq_set_tuning pairs, e.g. 3=1 (no LDS GEMM)")
 ap.add_argument("--dense", action="store_true", help="materialise the masked clouds even if the model has a coalition path")
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
 lib = _lib.load()
+for kv in filter(None, a.tune.split(",")):
+    k, v = kv.split("=")
+    lib.iq_set_tuning(int(k), int(v))
 if a.model == "pointnet2":
     from interpret_quality_amd.pointnet2 import PointNet2ClsMsg
     model = PointNet2ClsMsg(None)
