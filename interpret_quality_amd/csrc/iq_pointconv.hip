@@ -69,6 +69,7 @@ __global__ __launch_bounds__(kThreads, 1) void pc_knn_kernel(const float* __rest
     constexpr int LD = 12;
     __shared__ __attribute__((aligned(16))) float tile[2][32 * LD];
     __shared__ float kxx[2][32];
+    __shared__ double queue[kThreads / 64][16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const float* kb = keys8 + (size_t)b * N * 8;
@@ -90,8 +91,8 @@ __global__ __launch_bounds__(kThreads, 1) void pc_knn_kernel(const float* __rest
             kxx[buf][tid - 64] = (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2];
         }
     };
-    TopK<K> top;
-    top.init();
+    QueuedTopK<K, 16> top;
+    top.init(queue[wave]);
     const int ntiles = N / 32;
     stage(0, 0);
     __syncthreads();
@@ -104,14 +105,15 @@ __global__ __launch_bounds__(kThreads, 1) void pc_knn_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r)  // -(((-2 q.p) + |q|^2) + |p|^2): largest = nearest
             d[r] = -(((-2.f * acc[r]) + xxq) + kxx[buf][c_row(r, lane)]);
-        top.offer_tile(d, t * 32, fh);
+        top.offer_tile(d, t * 32, lane);
         __syncthreads();
     }
+    top.flush(lane);
     top.merge_halves();
     if (fh == 0 && q0 + fl < S) {
         int16_t* o = idx + ((size_t)b * S + q0 + fl) * K;
 #pragma unroll
-        for (int q = 0; q < K; ++q) o[q] = (int16_t)top.i[q];
+        for (int q = 0; q < K; ++q) o[q] = (int16_t)top.index(q);
     }
 }
 

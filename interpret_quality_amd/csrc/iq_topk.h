@@ -1,56 +1,6 @@
-// Per-lane running top-K (largest values) kept in registers: replace-the-minimum insertion.
+// Per-lane running top-K (largest values) for the MFMA distance tiles of the kNN kernels.
 #pragma once
 #include <hip/hip_runtime.h>
-
-template <int K>
-struct TopK {
-    float v[K];
-    int i[K];
-    float minv;
-    int minp;
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int q = 0; q < K; ++q) { v[q] = -INFINITY; i[q] = 0; }
-        minv = -INFINITY; minp = 0;
-    }
-    __device__ __forceinline__ void offer(float val, int idx) {
-        if (val > minv) {
-#pragma unroll
-            for (int q = 0; q < K; ++q)
-                if (q == minp) { v[q] = val; i[q] = idx; }
-            minv = v[0]; minp = 0;
-#pragma unroll
-            for (int q = 1; q < K; ++q)
-                if (v[q] < minv) { minv = v[q]; minp = q; }
-        }
-    }
-    // insert the 16 candidates of one accumulator tile, best first; leaves as soon as no lane has one left
-    __device__ __forceinline__ void offer_tile(float (&d)[16], int idx_base, int fh) {
-        for (;;) {
-            float best = minv;
-            int br = -1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (d[r] > best) { best = d[r]; br = r; }
-            if (!__any(br >= 0)) break;
-            if (br >= 0) {
-                offer(best, idx_base + (br & 3) + 8 * (br >> 2) + 4 * fh);
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (r == br) d[r] = -INFINITY;
-            }
-        }
-    }
-    // merge with the partner half-wave (lane ^ 32)
-    __device__ __forceinline__ void merge_halves() {
-        float pv[K];
-        int pi[K];
-#pragma unroll
-        for (int q = 0; q < K; ++q) { pv[q] = __shfl_xor(v[q], 32); pi[q] = __shfl_xor(i[q], 32); }
-#pragma unroll
-        for (int q = 0; q < K; ++q) offer(pv[q], pi[q]);
-    }
-};
 
 // ------------------------------------------------------------------------------------------------------------------
 // Queued top-K for the MFMA distance tiles (queries on lanes, 16 keys per lane and tile).
@@ -125,15 +75,18 @@ struct QueuedTopK {
     // union with the partner half-wave (lane ^ 32), which saw the other half of every key tile: the K largest of two
     // descending lists are max(a[i], b[K-1-i]) (first step of a bitonic merge; the result is an unordered set)
     __device__ __forceinline__ void merge_halves() {
-        double m[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            const long long pb = __double_as_longlong(v[K - 1 - i]);
+        auto partner = [](double x) {
+            const long long pb = __double_as_longlong(x);
             const int lo = __shfl_xor((int)(pb & 0xffffffffll), 32), hi = __shfl_xor((int)(pb >> 32), 32);
-            m[i] = fmax(v[i], __longlong_as_double(((long long)hi << 32) | (unsigned int)lo));
-        }
+            return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        };
 #pragma unroll
-        for (int i = 0; i < K; ++i) v[i] = m[i];
+        for (int i = 0; i < K / 2; ++i) {  // positions i and K-1-i only depend on each other: in place
+            const double bi = partner(v[i]), bj = partner(v[K - 1 - i]);
+            v[i] = fmax(v[i], bj);
+            v[K - 1 - i] = fmax(v[K - 1 - i], bi);
+        }
+        if (K & 1) v[K / 2] = fmax(v[K / 2], partner(v[K / 2]));
     }
     __device__ __forceinline__ int index(int i) const { return (int)(__double_as_longlong(v[i]) & ((1ll << kIndexBits) - 1)); }
 };
