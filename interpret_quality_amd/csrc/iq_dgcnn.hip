@@ -138,48 +138,77 @@ __global__ __launch_bounds__(64) void dg_compact_kernel(const float* __restrict_
 }
 
 // ---- xx[i] = sum_c x[i][c]^2 in channel order (torch.sum(x**2, dim=1)) ------------------------------
-// 64 rows per workgroup, staged through LDS so the global reads are coalesced; each row is still summed
-// sequentially over its channels by one lane.
-// Dead (padding) rows get +inf: as keys they then score -inf and are never selected.
-__global__ __launch_bounds__(64) void rownorm_kernel(const float* __restrict__ x, int ldx, int C, float* __restrict__ xx,
-                                                     Ragged rg, int B) {
-    __shared__ float tile[64 * 129];
+// 64 rows per workgroup; 32-channel slices go through a small LDS tile (coalesced float4 reads, many workgroups per
+// CU) and each row is still summed sequentially over its channels by one lane - the order the golden kNN sets were
+// produced with.  Dead (padding) rows get +inf: as keys they then score -inf and are never selected.
+__global__ __launch_bounds__(kThreads) void rownorm_kernel(const float* __restrict__ x, int ldx, int C, float* __restrict__ xx,
+                                                           Ragged rg, int B) {
+    __shared__ float tile[64 * 33];
     const int rows = rg.roff[B];
     const int r0 = blockIdx.x * 64;
     if (r0 >= rows) return;
-    const int ld = C + 1;
-    for (int e = threadIdx.x; e < 64 * C; e += 64) {
-        const int r = e / C, c = e - r * C;
-        tile[r * ld + c] = (r0 + r < rows) ? x[(size_t)(r0 + r) * ldx + c] : 0.f;
-    }
-    __syncthreads();
-    const int r = r0 + threadIdx.x;
-    if (r >= rows) return;
-    const float* p = tile + threadIdx.x * ld;
+    const int tid = threadIdx.x;
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += p[c] * p[c];
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        const int cw = min(32, C - c0);
+        if (cw == 32) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + kThreads * i, row = e >> 3, c4 = e & 7;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r0 + row < rows) v = *reinterpret_cast<const f32x4*>(x + (size_t)(r0 + row) * ldx + c0 + c4 * 4);
+                float* t = tile + row * 33 + c4 * 4;
+                t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+            }
+        } else {
+            for (int e = tid; e < 64 * cw; e += kThreads) {
+                const int row = e / cw, c = e - row * cw;
+                tile[row * 33 + c] = (r0 + row < rows) ? x[(size_t)(r0 + row) * ldx + c0 + c] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const float* p = tile + tid * 33;
+            for (int c = 0; c < cw; ++c) s += p[c] * p[c];
+        }
+        __syncthreads();
+    }
+    const int r = r0 + tid;
+    if (tid >= 64 || r >= rows) return;
     const int b = rg.row_cloud[r];
     xx[r] = (r - rg.roff[b] < rg.nkept[b] + rg.ncopy[b]) ? s : INFINITY;
 }
 
 // ---- kNN ------------------------------------------------------------------------------------------
+// (A variant with two query tiles per wave and a v_permlane32_swap of the accumulator halves - one top-K list per
+// query instead of two half lists - was measured and dropped: 8 % faster at C = 64, 7 % slower at C = 8, spills at 128.)
+__device__ unsigned long long g_knn_dbg[3];  // rounds, busy lanes summed over rounds, waves (tuning key 4 = 3)
+__global__ void knn_dbg_fetch_kernel(unsigned long long* dst) {
+    for (int i = 0; i < 3; ++i) { dst[i] = g_knn_dbg[i]; g_knn_dbg[i] = 0; }
+}
+
+// One wave = one workgroup = 32 queries.  Key fragments come straight from L1/L2 (a key row's C floats are contiguous, so
+// the four k-blocks of a 128-B line are consumed back to back), one k-block ahead of the MFMAs; nothing is shared
+// between waves, so there is no barrier in the loop and waves drift freely past each other's selection rounds.  (The
+// first version staged key tiles through LDS for 4 waves: with a barrier per 32-key tile and 2 workgroups per CU the
+// MFMA + staging skeleton alone took 53 of the 91 ms of DGCNN's kNN.)
 template <int C>
-__global__ __launch_bounds__(kThreads, 2) void knn_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ xx,
-                                                          int16_t* __restrict__ idx, Ragged rg) {
-    constexpr int LD = C + 4, KB = C / 8;
-    __shared__ __attribute__((aligned(16))) float keys[2][32 * LD];
-    __shared__ float kxx[2][32];
-    __shared__ double queue[kThreads / 64][16 * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
+__global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ xx,
+                                                 int16_t* __restrict__ idx, Ragged rg, int B, int tiles_per_cloud, int dbg) {
+    constexpr int KB = C / 8;
+    __shared__ double queue[16 * 64];
+    const int lane = threadIdx.x;
+    // workgroups go round-robin over the 8 XCDs: give each XCD whole clouds, so that the ~17 waves which stream the same
+    // keys share one L2 (and often one L1) instead of pulling the cloud into all eight
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / tiles_per_cloud) * 8 + xcd;
+    if (b >= B) return;
     const int base = rg.roff[b];
     const int N = rg.roff[b + 1] - base;          // padded rows of this cloud (multiple of 32)
-    if ((int)blockIdx.x * 128 >= N) return;
+    const int q0 = (slot % tiles_per_cloud) * 32; // this wave's 32 queries
+    if (q0 >= N) return;
     const float* xb = x + (size_t)base * ldx;
     const float* xxb = xx + base;
-    const int q0w = blockIdx.x * 128 + wave * 32;  // this wave's 32 queries
-    const bool wave_live = q0w < N;
-    const int q0 = wave_live ? q0w : 0;            // idle waves of the last block shadow block 0's queries (no write)
     const int fl = lane & 31, fh = lane >> 5;
 
     // B operand: queries, stationary in registers
@@ -189,39 +218,72 @@ __global__ __launch_bounds__(kThreads, 2) void knn_kernel(const float* __restric
         qf[kb] = *reinterpret_cast<const f32x4*>(xb + (size_t)(q0 + fl) * ldx + 8 * kb + 4 * fh);
     const float xxq = xxb[q0 + fl];
 
-    auto stage = [&](int tile, int buf) {
-        for (int e = tid; e < 32 * C / 4; e += kThreads) {
-            const int row = e / (C / 4), c4 = e - row * (C / 4);
-            *reinterpret_cast<f32x4*>(&keys[buf][row * LD + c4 * 4]) =
-                *reinterpret_cast<const f32x4*>(xb + (size_t)(tile * 32 + row) * ldx + c4 * 4);
-        }
-        if (tid < 32) kxx[buf][tid] = xxb[tile * 32 + tid];
-    };
-
     QueuedTopK<kK, 16> top;
-    top.init(queue[wave]);
+    top.init(queue);
     const int ntiles = N / 32;
-    stage(0, 0);
-    __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
-        f32x16 acc = {0};
-        const float* abase = keys[buf] + fl * LD + 4 * fh;
+    const float* kp = xb + (size_t)fl * ldx + 4 * fh;   // A fragment of key row (32 t + fl), k-block kb: kp + 32 t ldx + 8 kb
+    const float* kxp = xxb + 4 * fh;                     // |key|^2 of rows 32 t + 8 j + 4 fh + (0..3): kxp + 32 t + 8 j
+    f32x4 an = *reinterpret_cast<const f32x4*>(kp);
+    f32x4 kxn[4];
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) acc = mfma4(lds_frag<LD>(abase, 0, kb), qf[kb], acc);
-        float d[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float inner = -2.f * acc[r];                              // -2 * matmul
-            d[r] = ((-kxx[buf][c_row(r, lane)]) - inner) - xxq;             // -xx - inner - xx^T (models/dgcnn.py:15)
+    for (int j = 0; j < 4; ++j) kxn[j] = *reinterpret_cast<const f32x4*>(kxp + 8 * j);
+    // ONE loop (a small state machine) instead of rounds nested in the tile loop: the 20-entry list is then carried
+    // by a single loop and stays in 40 registers; nested, the allocator kept copies per loop level (300 registers).
+    float d[16];
+    int dbg_rounds = 0, dbg_work = 0;
+    int t = 0, half = 2;  // half == 2: the current tile is used up
+    for (;;) {
+        const unsigned long long busy = __ballot(top.cnt > 0);
+        const bool last = half == 2 && t == ntiles;
+        if (busy != 0 && (last || __popcll(busy) >= 16 || __any(top.cnt > 8))) {
+            if (dbg == 3) { ++dbg_rounds; dbg_work += __popcll(busy); }
+            top.round(lane);
+            continue;
         }
-        top.offer_tile(d, t * 32, lane);
-        __syncthreads();
+        if (last) break;
+        if (half == 2) {  // distances of key tile t
+            f32x4 kx[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kx[j] = kxn[j];
+            const int tn = min(t + 1, ntiles - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kxn[j] = *reinterpret_cast<const f32x4*>(kxp + 32 * tn + 8 * j);
+            f32x16 acc = {0};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const f32x4 a = an;
+                an = *reinterpret_cast<const f32x4*>(kb + 1 < KB ? kp + (size_t)32 * t * ldx + 8 * (kb + 1) : kp + (size_t)32 * tn * ldx);
+                acc = mfma4(a, qf[kb], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float inner = -2.f * acc[r];                              // -2 * matmul
+                d[r] = ((-kx[r >> 2][r & 3]) - inner) - xxq;                    // -xx - inner - xx^T (models/dgcnn.py:15)
+            }
+            half = 0;
+            ++t;
+            if (dbg == 2) { half = 2; continue; }
+        }
+        // queue the candidates of this half of the tile (accumulator registers 8 half .. 8 half + 7)
+        const int ib = (t - 1) * 32 + 4 * fh + 16 * half;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const float v = half ? d[8 + rr] : d[rr];
+            if (v > top.thr) {
+                top.q[top.cnt * 64 + lane] = top.pack(v, ib + (rr & 3) + 8 * (rr >> 2));
+                ++top.cnt;
+            }
+        }
+        ++half;
+        if (dbg == 1) top.cnt = 0;
     }
-    top.flush(lane);
+    if (dbg == 3 && lane == 0) {  // diagnostic counters (tools/knn_probe.py)
+        atomicAdd(&g_knn_dbg[0], (unsigned long long)dbg_rounds);
+        atomicAdd(&g_knn_dbg[1], (unsigned long long)dbg_work);
+        atomicAdd(&g_knn_dbg[2], 1ull);
+    }
     top.merge_halves();  // each half-wave saw half of the keys of every tile
-    if (fh == 0 && wave_live) {
+    if (fh == 0) {
         int16_t* o = idx + ((size_t)base + q0 + fl) * kK;
 #pragma unroll
         for (int q = 0; q < kK; ++q) o[q] = (int16_t)top.index(q);
@@ -233,6 +295,8 @@ __global__ __launch_bounds__(kThreads) void gather_max_kernel(const float* __res
                                                               const int16_t* __restrict__ idx, float* __restrict__ out,
                                                               int ldo, Ragged rg, int B) {
     const int per = Co / 4;                               // float4 lanes per point
+    // (an XCD-contiguous block order was tried here and lost 30 %: the 8 L2s then stream 8 distant row ranges; in the
+    // plain order all XCDs work on the same few clouds at a time and the MALL absorbs the duplicates)
     const int t = blockIdx.x * kThreads + threadIdx.x;
     const int pt = t / per, c4 = t - pt * per;
     if (pt >= rg.roff[B]) return;
@@ -276,10 +340,11 @@ __global__ __launch_bounds__(kThreads) void pool_reduce_kernel(const float* __re
 
 int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, int B, int N, const Ragged& rg,
                hipStream_t st) {
-    dim3 grid((N + 127) / 128, B);
-    if (C == 8) hipLaunchKernelGGL(knn_kernel<8>, grid, dim3(kThreads), 0, st, x, ldx, xx, idx, rg);
-    else if (C == 64) hipLaunchKernelGGL(knn_kernel<64>, grid, dim3(kThreads), 0, st, x, ldx, xx, idx, rg);
-    else if (C == 128) hipLaunchKernelGGL(knn_kernel<128>, grid, dim3(kThreads), 0, st, x, ldx, xx, idx, rg);
+    const int tiles = (N + 31) / 32;
+    dim3 grid((unsigned)((B + 7) / 8 * 8 * tiles));
+    if (C == 8) hipLaunchKernelGGL(knn_kernel<8>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, iq::tuning(4));
+    else if (C == 64) hipLaunchKernelGGL(knn_kernel<64>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, iq::tuning(4));
+    else if (C == 128) hipLaunchKernelGGL(knn_kernel<128>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, iq::tuning(4));
     else return iq::fail(IQ_EUNSUPPORTED, "knn: C=%d has no kernel instantiation (8, 64, 128)", C);
     return iq::check_launch("knn_kernel");
 }
@@ -366,10 +431,12 @@ extern "C" int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes,
         hipLaunchKernelGGL(pad_xyz_kernel, dim3((r + 255) / 256), dim3(256), 0, st, x, x0, (int)r);
         src = x0; ld = 8; cpad = 8;
     }
-    hipLaunchKernelGGL(rownorm_kernel, dim3((r + 63) / 64), dim3(64), 0, st, src, ld, C, xx, rg, B);
+    hipLaunchKernelGGL(rownorm_kernel, dim3((r + 63) / 64), dim3(kThreads), 0, st, src, ld, C, xx, rg, B);
     int rc = launch_knn(src, ld, cpad, xx, i16, B, N, rg, st);
     if (rc) return rc;
     hipLaunchKernelGGL(widen_idx_kernel, dim3((r * kK + 255) / 256), dim3(256), 0, st, i16, idx, r * kK);
+    if (iq::tuning(4) == 3)  // diagnostic: selection statistics into the first 24 bytes of tmp
+        hipLaunchKernelGGL(knn_dbg_fetch_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long*>(tmp));
     return iq::check_launch("iq_knn");
 }
 
@@ -389,7 +456,7 @@ int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, i
         IQ_REQUIRE(w->pq[l].cin == cin, "iq_dgcnn: layer %d expects %d inputs, got %d", l, cin, w->pq[l].cin);
         if (l == 0 || !fixed_graph) {
             iq::ProfileSpan span(iq::kSlotPrepool, st);
-            hipLaunchKernelGGL(rownorm_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, src, ld, creal, s.xx, rg, B);
+            hipLaunchKernelGGL(rownorm_kernel, dim3((rows + 63) / 64), dim3(kThreads), 0, st, src, ld, creal, s.xx, rg, B);
             if ((rc = launch_knn(src, ld, cin, s.xx, s.idx, B, N, rg, st))) return rc;
         }
         {
