@@ -342,9 +342,9 @@ int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, in
                hipStream_t st) {
     const int tiles = (N + 31) / 32;
     dim3 grid((unsigned)((B + 7) / 8 * 8 * tiles));
-    if (C == 8) hipLaunchKernelGGL(knn_kernel<8>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, iq::tuning(4));
-    else if (C == 64) hipLaunchKernelGGL(knn_kernel<64>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, iq::tuning(4));
-    else if (C == 128) hipLaunchKernelGGL(knn_kernel<128>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, iq::tuning(4));
+    if (C == 8) hipLaunchKernelGGL(knn_kernel<8>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, iq::tuning(iq::kTuneKnnDebug));
+    else if (C == 64) hipLaunchKernelGGL(knn_kernel<64>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, iq::tuning(iq::kTuneKnnDebug));
+    else if (C == 128) hipLaunchKernelGGL(knn_kernel<128>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, iq::tuning(iq::kTuneKnnDebug));
     else return iq::fail(IQ_EUNSUPPORTED, "knn: C=%d has no kernel instantiation (8, 64, 128)", C);
     return iq::check_launch("knn_kernel");
 }
@@ -435,7 +435,7 @@ extern "C" int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes,
     int rc = launch_knn(src, ld, cpad, xx, i16, B, N, rg, st);
     if (rc) return rc;
     hipLaunchKernelGGL(widen_idx_kernel, dim3((r * kK + 255) / 256), dim3(256), 0, st, i16, idx, r * kK);
-    if (iq::tuning(4) == 3)  // diagnostic: selection statistics into the first 24 bytes of tmp
+    if (iq::tuning(iq::kTuneKnnDebug) == 3)  // diagnostic: selection statistics into the first 24 bytes of tmp
         hipLaunchKernelGGL(knn_dbg_fetch_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long*>(tmp));
     return iq::check_launch("iq_knn");
 }
