@@ -65,15 +65,18 @@ __global__ __launch_bounds__(kThreads) void pc_density_kernel(const float* __res
 template <int K>
 __global__ __launch_bounds__(kThreads, 1) void pc_knn_kernel(const float* __restrict__ keys8 /*(B,N,8)*/,
                                                              const float* __restrict__ q8 /*(B,S,8)*/,
-                                                             int16_t* __restrict__ idx /*(B,S,K)*/, int N, int S) {
+                                                             int16_t* __restrict__ idx /*(B,S,K)*/, int N, int S, int B,
+                                                             int wgs_per_cloud) {
     constexpr int LD = 12;
     __shared__ __attribute__((aligned(16))) float tile[2][32 * LD];
     __shared__ float kxx[2][32];
     __shared__ double queue[kThreads / 64][16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;   // XCD-aware: a cloud's workgroups share one L2
+    const int b = (slot / wgs_per_cloud) * 8 + xcd;
+    if (b >= B) return;
     const float* kb = keys8 + (size_t)b * N * 8;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = (slot % wgs_per_cloud) * 128 + wave * 32;
     const int fl = lane & 31, fh = lane >> 5;
     const int qrow = min(q0 + fl, S - 1);
     const float* qp = q8 + ((size_t)b * S + qrow) * 8;
@@ -177,7 +180,7 @@ struct PcGroupArgs {
     const float* w3; const float* b3;
     TinyNets nets;
     float* out;                // (B,S,C3*16): [c][w]
-    int N, S, K;
+    int N, S, K;    int B, wgs_per_cloud;
 };
 
 template <int C1, int C2, int C3>
@@ -193,10 +196,14 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_kernel(PcGroupArgs a) {
     __shared__ float rho[kMC];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
+    // 1-D grid; workgroups go round-robin over the 8 XCDs: keep all workgroups of a cloud on one XCD (one L2 holds its
+    // U rows, coordinates, densities and indices)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / a.wgs_per_cloud) * 8 + xcd;
+    if (b >= a.B) return;
     const int K = a.K;                       // 32 (two groups per chunk) or 64 (one group per chunk)
     const int gpc = kMC / K;                 // groups per chunk
-    const int g_first = blockIdx.x * gpc;    // one chunk per workgroup
+    const int g_first = (slot % a.wgs_per_cloud) * gpc;    // one chunk per workgroup
     if (g_first >= a.S) return;
     const int fl = lane & 31, fh = lane >> 5;
     const float* a1base = act1 + fl * LD1 + 4 * fh;
@@ -440,7 +447,9 @@ template <int K>
 int launch_pc_knn(const float* keys, int nkeys, const float* queries, int S, WsC& s, int16_t* idx, int B, hipStream_t st) {
     hipLaunchKernelGGL(pc_pad8_kernel, dim3((B * nkeys + 255) / 256), dim3(256), 0, st, keys, s.k8, B * nkeys);
     hipLaunchKernelGGL(pc_pad8_kernel, dim3((B * S + 255) / 256), dim3(256), 0, st, queries, s.q8, B * S);
-    hipLaunchKernelGGL(pc_knn_kernel<K>, dim3((S + 127) / 128, B), dim3(kThreads), 0, st, s.k8, s.q8, idx, nkeys, S);
+    const int wpc = (S + 127) / 128;
+    hipLaunchKernelGGL(pc_knn_kernel<K>, dim3((unsigned)((B + 7) / 8 * 8 * wpc)), dim3(kThreads), 0, st, s.k8, s.q8, idx, nkeys, S, B,
+                       wpc);
     return iq::check_launch("pc_knn_kernel");
 }
 
@@ -449,7 +458,9 @@ int launch_pc_group(const iq_pointconv_sa& sa, PcGroupArgs a, int B, hipStream_t
     a.w2 = sa.l2.w; a.b2 = sa.l2.b; a.w3 = sa.l3.w; a.b3 = sa.l3.b;
     a.nets.dn = sa.densitynet; a.nets.wn = sa.weightnet;
     const int gpc = kMC / a.K;
-    dim3 grid((a.S + gpc - 1) / gpc, B);
+    a.B = B;
+    a.wgs_per_cloud = (a.S + gpc - 1) / gpc;
+    dim3 grid((unsigned)((B + 7) / 8 * 8 * a.wgs_per_cloud));
     const int c1 = sa.l2.cin, c2 = sa.l2.cout, c3 = sa.l3.cout;
     if (c1 == 64 && c2 == 64 && c3 == 128) hipLaunchKernelGGL((pc_group_kernel<64, 64, 128>), grid, dim3(kThreads), 0, st, a);
     else if (c1 == 128 && c2 == 128 && c3 == 256) hipLaunchKernelGGL((pc_group_kernel<128, 128, 256>), grid, dim3(kThreads), 0, st, a);

@@ -168,6 +168,7 @@ struct GroupArgs {
     float* out;              // (B,S,ldo) at the scale's column offset, zero-initialised
     int ldo;
     int N, S, K, blocks_per_wg;
+    int B, wgs_per_cloud;
 };
 
 __device__ __forceinline__ void merge_max(float* addr, float v) {
@@ -205,11 +206,15 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
     __shared__ int blk_group[2 * (kMC / kBlk)];                      // owner group of a chunk's 4 blocks (-1 = none)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
+    // 1-D grid, workgroups round-robin over the 8 XCDs: all workgroups of a cloud on one XCD (its U rows, coordinates and
+    // indices are then fetched into one L2)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / a.wgs_per_cloud) * 8 + xcd;
+    if (b >= a.B) return;
     const int K = a.K;
     const int32_t* bstart = a.block_start + (size_t)b * (a.S + 1);
     const int nblocks = bstart[a.S];
-    const int j0 = blockIdx.x * a.blocks_per_wg;
+    const int j0 = (slot % a.wgs_per_cloud) * a.blocks_per_wg;
     if (j0 >= nblocks) return;
     const int jend = min(nblocks, j0 + a.blocks_per_wg);
     const int nchunks = (jend - j0 + (kMC / kBlk) - 1) / (kMC / kBlk);
@@ -363,8 +368,10 @@ __global__ void colmax_kernel(const float* __restrict__ in, float* __restrict__ 
 }
 
 template <int C1, int C2, int C3>
-int launch_group_t(const GroupArgs& a, int B, hipStream_t st) {
-    dim3 grid((a.maxblocks + a.blocks_per_wg - 1) / a.blocks_per_wg, B);  // workgroups past a cloud's block count exit
+int launch_group_t(GroupArgs a, int B, hipStream_t st) {
+    a.B = B;
+    a.wgs_per_cloud = (a.maxblocks + a.blocks_per_wg - 1) / a.blocks_per_wg;  // workgroups past a cloud's block count exit
+    dim3 grid((unsigned)((B + 7) / 8 * 8 * a.wgs_per_cloud));
     hipLaunchKernelGGL((pn2_group_kernel<C1, C2, C3>), grid, dim3(kThreads), 0, st, a);
     return iq::check_launch("pn2_group_kernel");
 }
