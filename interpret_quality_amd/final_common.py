@@ -67,7 +67,8 @@ def shapley_logits(model, data, lbl, region_id, orders, args, center=None):
         return model.coalition_logits(data.contiguous(), center.reshape(1, 3).contiguous(), rid.reshape(1, -1),
                                       keep, None, num_regions=r)
     # config.py's knob is a floor: rows are independent in eval mode, so larger launches give the same logits
-    bs = max(args.shapley_batch_size, -(-getattr(model, "preferred_clouds_per_call", 0) // (r + 1)))
+    # (stage 1 sets no batch size: the reference evaluates one permutation per forward there, final_shapley_value.py:138-144)
+    bs = max(getattr(args, "shapley_batch_size", 1), -(-getattr(model, "preferred_clouds_per_call", 0) // (r + 1)))
     chunks = []
     points_api = hasattr(model, "forward_points")  # consumes (B,N,3) directly: no transpose
     for i in range(0, len(orders), bs):

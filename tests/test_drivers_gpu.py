@@ -225,3 +225,17 @@ def test_exp_interaction_full_pipeline_incl_gen_pair(tmp_path, monkeypatch):
             assert it.shape[0] == 0
         else:
             assert lg.shape[1] == 12 and it.shape == (lg.shape[0], 3)
+
+
+@pytest.mark.parametrize("model_name", ["pointnet2", "dgcnn", "pointconv"])
+def test_stage1_and_a_sweep_for_models_without_the_fused_pointnet_path(tmp_path, monkeypatch, model_name):
+    """exp_shapley.sh stage 1 + the scale sweep for the other model families (materialised clouds / compact clouds):
+    artefacts and the efficiency axiom."""
+    monkeypatch.chdir(tmp_path)
+    common = ["--model", model_name, "--dataset", "modelnet10", "--synthetic", "--num_clouds", "1"]
+    shapley_stage.main(common + ["--num_samples_save", "100", "--num_regions", "8"])
+    root = "checkpoints/exp_MODEL_%s_DATA_modelnet10_POINTNUM_1024_REGIONNUM_8_shapley_test/synthetic_00/" % model_name
+    nf = float(np.load(root + "norm_factor.npy"))
+    sv_all = np.load(root + "region_sv_all.npy")
+    assert sv_all.shape == (100, 8)
+    np.testing.assert_allclose(sv_all.sum(1), nf, rtol=0, atol=1e-3 * max(1.0, abs(nf)))
