@@ -243,6 +243,22 @@ int iq_pointnet2_forward(const iq_pointnet2_weights* w /*host struct of device p
                          float* logits, void* workspace, size_t workspace_bytes, int B, int N,
                          iq_stream_t stream);
 
+/* The same network on B coalitions given as region bit masks (argument convention of iq_pointnet_coalitions):
+ * replaces the masking + forward of tools/final_common.py:88-91 and
+ * final_point_binary_interaction_logits.py:45-60 for PointNet++.  The masked clouds are written internally
+ * (FPS, ball query and sa2 / sa3 run on them as in iq_pointnet2_forward), but sa1 - which has no input
+ * features, so a member row is a function of the point pair only - is a gather-max over per-source-cloud tables
+ * MLP_s(P[q] - P[p]) of all pairs inside each radius (P = the cloud's points plus the centre masked points
+ * collapse to), built once per call with the ball query's own distance expression and the grouped kernel's layer
+ * arithmetic: bit-identical features.  A scale whose pair count exceeds the table capacity (192 pairs per point
+ * on average) falls back to the grouped MLP.  Reads the pair counts back once per call (the only host round
+ * trip); otherwise asynchronous on `stream`. */
+size_t iq_pointnet2_coalitions_workspace_bytes(int B, int nclouds, int N);
+int iq_pointnet2_coalitions(const iq_pointnet2_weights* w, const float* clouds, const float* centers,
+                            const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of,
+                            float* logits, void* workspace, size_t workspace_bytes, int B, int nclouds, int N,
+                            iq_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * DGCNN / GCNN (models/dgcnn.py:12-194)
  * ------------------------------------------------------------------------------------------- */

@@ -96,6 +96,8 @@ SIGNATURES = {
     "iq_ball_query": (_I, [_P, _P, ctypes.c_float, _I, _P, _I, _I, _I, _P]),
     "iq_pointnet2_workspace_bytes": (_SZ, [_I]),
     "iq_pointnet2_forward": (_I, [ctypes.POINTER(PointNet2Weights), _P, _P, _P, _SZ, _I, _I, _P]),
+    "iq_pointnet2_coalitions_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "iq_pointnet2_coalitions": (_I, [ctypes.POINTER(PointNet2Weights), _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "iq_knn": (_I, [_P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
     "iq_dgcnn_workspace_bytes": (_SZ, [_I, _I]),
     "iq_dgcnn_forward": (_I, [ctypes.POINTER(DgcnnWeights), _P, _P, _P, _SZ, _I, _I, _I, _P]),

@@ -413,6 +413,191 @@ int launch_ball(const float* xyz, const float* new_xyz, int ldc, const iq_pn2_sc
     return iq::check_launch("ball_query_kernel");
 }
 
+// ==== sa1 from pair tables (iq_pointnet2_coalitions) ==================================================================
+// sa1 has no input features: a member row is MLP_s(x_q - x_p), a function of the POINT PAIR only.  All coalitions of a
+// call are masked copies of a few source clouds, so every pair that a ball query can ever return - both points kept,
+// or one / both of them the centre that masked points collapse to (index N below) - is known up front.  Per source
+// cloud and scale the rows MLP_s(P[q] - P[p]) of all pairs inside the radius are computed ONCE (a few coalitions' worth
+// of work) and sa1 of every coalition becomes a gather-max over table rows.  The pair predicate is the ball query's
+// own expression, and the rows are produced by the same layer arithmetic as pn2_group_kernel (same fma chain for
+// layer 1, same MFMA order over k in the dense layers), so the features are bit-identical to the grouped MLP.
+
+struct PairTabs {
+    const int32_t* map[3];   // (nc, N+1, N+1) row of pair (p, q) in feat, or -1
+    const float* feat[3];    // (rows, C3)
+    int c3[3];
+    bool use[3];
+};
+
+__device__ __forceinline__ float pt_dist(const float* c, const float* v) {  // ball_query_kernel's expression
+    const float sc = __fadd_rn(__fadd_rn(__fmul_rn(c[0], c[0]), __fmul_rn(c[1], c[1])), __fmul_rn(c[2], c[2]));
+    const float sv = __fadd_rn(__fadd_rn(__fmul_rn(v[0], v[0]), __fmul_rn(v[1], v[1])), __fmul_rn(v[2], v[2]));
+    float dot = __fmul_rn(c[0], v[0]);
+    dot = __fmaf_rn(c[1], v[1], dot);
+    dot = __fmaf_rn(c[2], v[2], dot);
+    return __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), sc), sv);
+}
+
+// masked clouds: X[b][i] = kept ? clouds[c][i] : centers[c]
+__global__ void pn2_mask_kernel(const float* __restrict__ clouds, const float* __restrict__ centers,
+                                const int32_t* __restrict__ region_id, const uint64_t* __restrict__ keep,
+                                const int32_t* __restrict__ cloud_of, float* __restrict__ out, int N, int B, int nclouds) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * N) return;
+    const int b = t / N, i = t - b * N;
+    const int c = cloud_of ? cloud_of[b] : (nclouds == 1 ? 0 : b);
+    const bool kept = (keep[b] >> region_id[(size_t)c * N + i]) & 1ull;
+    const float* src = kept ? clouds + ((size_t)c * N + i) * 3 : centers + (size_t)c * 3;
+    out[(size_t)t * 3] = src[0]; out[(size_t)t * 3 + 1] = src[1]; out[(size_t)t * 3 + 2] = src[2];
+}
+
+// points of source cloud c: P[0..N-1] = cloud, P[N] = centre  -> (nc, N+1, 4) padded
+__global__ void pt_points_kernel(const float* __restrict__ clouds, const float* __restrict__ centers, float* __restrict__ P,
+                                 int N, int nclouds) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nclouds * (N + 1)) return;
+    const int c = t / (N + 1), i = t - c * (N + 1);
+    const float* src = i < N ? clouds + ((size_t)c * N + i) * 3 : centers + (size_t)c * 3;
+    P[(size_t)t * 4] = src[0]; P[(size_t)t * 4 + 1] = src[1]; P[(size_t)t * 4 + 2] = src[2]; P[(size_t)t * 4 + 3] = 0.f;
+}
+
+// one workgroup per (p, c): number of q inside each radius -> cnt[(c*3 + s)*(N+1) + p]
+__global__ __launch_bounds__(kThreads) void pt_count_kernel(const float* __restrict__ P, int N, float r0, float r1, float r2,
+                                                            int32_t* __restrict__ cnt) {
+    __shared__ int part[3][kThreads / 64];
+    const int p = blockIdx.x, c = blockIdx.y;
+    const float* Pc = P + (size_t)c * (N + 1) * 4;
+    const float ctr[3] = {Pc[p * 4], Pc[p * 4 + 1], Pc[p * 4 + 2]};
+    int n[3] = {0, 0, 0};
+    for (int q = threadIdx.x; q <= N; q += kThreads) {
+        const float d = pt_dist(ctr, Pc + q * 4);
+        n[0] += !(d > r0); n[1] += !(d > r1); n[2] += !(d > r2);
+    }
+    for (int s = 0; s < 3; ++s) {
+        int v = n[s];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) part[s][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        int v = 0;
+        for (int w = 0; w < kThreads / 64; ++w) v += part[threadIdx.x][w];
+        cnt[((size_t)c * 3 + threadIdx.x) * (N + 1) + p] = v;
+    }
+}
+
+// exclusive scan over p for each (c, s); total[c*3+s]
+__global__ __launch_bounds__(1024) void pt_scan_kernel(const int32_t* __restrict__ cnt, int32_t* __restrict__ off,
+                                                       int32_t* __restrict__ total, int N) {
+    __shared__ int32_t part[1024];
+    const int cs = blockIdx.x, t = threadIdx.x, n = N + 1;
+    const int per = (n + 1023) / 1024;
+    const int lo = t * per, hi = min(lo + per, n);
+    const int32_t* c = cnt + (size_t)cs * n;
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += c[i];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int i = lo; i < hi; ++i) { off[(size_t)cs * n + i] = run; run += c[i]; }
+    if (t == 1023) total[cs] = part[1023];
+}
+
+// one workgroup per (p, c), scale s: map row + pair list, q ascending.  row0 = first table row of this (c, s).
+__global__ __launch_bounds__(64) void pt_fill_kernel(const float* __restrict__ P, int N, float r2, const int32_t* __restrict__ off,
+                                                     int row0, int32_t* __restrict__ map, uint32_t* __restrict__ pairs) {
+    const int p = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+    const float* Pc = P + (size_t)c * (N + 1) * 4;
+    const float ctr[3] = {Pc[p * 4], Pc[p * 4 + 1], Pc[p * 4 + 2]};
+    int32_t* mrow = map + ((size_t)c * (N + 1) + p) * (N + 1);
+    int pos = row0 + off[p];
+    for (int q0 = 0; q0 <= N; q0 += 64) {
+        const int q = q0 + lane;
+        const bool in = q <= N && !(pt_dist(ctr, Pc + q * 4) > r2);
+        const unsigned long long m = __ballot(in);
+        if (q <= N) {
+            const int row = pos + __popcll(m & ((1ull << lane) - 1ull));
+            mrow[q] = in ? row : -1;
+            if (in) pairs[row] = (uint32_t)p | ((uint32_t)q << 16);
+        }
+        pos += __popcll(m);
+    }
+}
+
+// layer 1 of the scale on the pair rows: h1[row][ch] = relu(w . (P[q] - P[p]) + b), pn2_group_kernel's expression
+__global__ void pt_l1_kernel(const float* __restrict__ Pc, const uint32_t* __restrict__ pairs, const float* __restrict__ w1x,
+                             float* __restrict__ h1, int C1, int rows) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * C1) return;
+    const int row = t / C1, ch = t - row * C1;
+    const uint32_t pq = pairs[row];
+    const float* x = Pc + (size_t)(pq >> 16) * 4;
+    const float* c = Pc + (size_t)(pq & 0xffff) * 4;
+    const float v0 = x[0] - c[0], v1 = x[1] - c[1], v2 = x[2] - c[2];
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(w1x + ch * 4);
+    const float h = fmaf(w1[2], v2, fmaf(w1[1], v1, w1[0] * v0)) + w1[3] + 0.f;
+    h1[t] = fmaxf(h, 0.f);
+}
+
+// sa1 of coalition b, group s, scale with table `feat`: max over the group's true members of the pair rows
+struct GatherArgs {
+    const int32_t* fps;        // (B,S) centroid indices into the masked cloud
+    const int16_t* idx;        // (B,S,K)
+    const int32_t* cnt;        // (B,S)
+    const int32_t* n_unique;   // (B)
+    const int32_t* region_id;  // (nc,N)
+    const uint64_t* keep;      // (B)
+    const int32_t* cloud_of;   // (B) or null
+    const int32_t* map;        // (nc,N+1,N+1)
+    const float* feat;         // (rows,C3)
+    float* out;                // (B,S,ldo) at the scale's column offset
+    int ldo, N, S, K, C3, nclouds, B;
+};
+
+__global__ __launch_bounds__(kThreads) void pt_gather_kernel(GatherArgs a) {
+    const int per = a.C3 / 4;                       // float4 lanes per group (16 or 32)
+    const int gpb = kThreads / per;                 // groups per workgroup
+    const int t = threadIdx.x, gl = t / per, c4 = t - gl * per;
+    // XCD-aware: a coalition's groups on one XCD (its index lists and the cloud's table rows stay in one L2)
+    const int wgs_per_cloud = (a.S + gpb - 1) / gpb;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / wgs_per_cloud) * 8 + xcd;
+    if (b >= a.B) return;
+    const int s = (slot % wgs_per_cloud) * gpb + gl;
+    if (s >= a.S || s >= a.n_unique[b]) return;     // duplicate centroids are filled from group 0 afterwards
+    const int c = a.cloud_of ? a.cloud_of[b] : (a.nclouds == 1 ? 0 : b);
+    const uint64_t k = a.keep[b];
+    const int32_t* rid = a.region_id + (size_t)c * a.N;
+    const int pi = a.fps[(size_t)b * a.S + s];
+    const int p = ((k >> rid[pi]) & 1ull) ? pi : a.N;
+    const int32_t* mrow = a.map + ((size_t)c * (a.N + 1) + p) * (a.N + 1);
+    const int16_t* mem = a.idx + ((size_t)b * a.S + s) * a.K;
+    const int n = a.cnt[(size_t)b * a.S + s];
+    const f32x4* F = reinterpret_cast<const f32x4*>(a.feat);
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};                 // rows are post-ReLU (>= 0) and every group has >= 1 member
+    bool centre_done = false;
+    for (int j = 0; j < n; ++j) {
+        const int qi = mem[j];
+        const bool kept = (k >> rid[qi]) & 1ull;
+        if (!kept) {
+            if (centre_done) continue;              // all masked members are the same point
+            centre_done = true;
+        }
+        const int row = mrow[kept ? qi : a.N];
+        const f32x4 v = F[(size_t)row * per + c4];
+        m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+    }
+    *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.S + s) * a.ldo + c4 * 4) = m;
+}
+
+
 struct Ws2 {
     int32_t *fps1, *nu1, *fps2, *nu2;
     float *nx1;            // (B,512,3)
@@ -480,18 +665,12 @@ extern "C" int iq_ball_query(const float* xyz, const float* new_xyz, float radiu
     return iq::check_launch("ball_query_kernel");
 }
 
-extern "C" int iq_pointnet2_forward(const iq_pointnet2_weights* w, const float* xyz, float* logits, void* workspace,
-                                    size_t workspace_bytes, int B, int N, iq_stream_t stream) {
-    IQ_REQUIRE(w && xyz && logits, "iq_pointnet2_forward: null pointer");
-    IQ_REQUIRE(B >= 0 && N >= 1 && N <= 4096, "iq_pointnet2_forward: B=%d N=%d", B, N);
-    if (B == 0) return IQ_OK;
-    const size_t need = carve2(nullptr, B, w).bytes;
-    if (!workspace || workspace_bytes < need)
-        return iq::fail(IQ_EWORKSPACE, "iq_pointnet2_forward: workspace %zu < %zu bytes", workspace_bytes, need);
-    Ws2 s = carve2(workspace, B, w);
-    hipStream_t st = iq::as_stream(stream);
+namespace {
+
+// The network on B materialised clouds xyz (B,N,3).  tab != null: sa1 scales with tab->use[q] come from pair tables.
+int run_pn2(const iq_pointnet2_weights* w, const float* xyz, float* logits, const Ws2& s, int B, int N, hipStream_t st,
+            const PairTabs* tab, const GatherArgs* gat) {
     int rc;
-    iq::ProfileSpan call_span(iq::kSlotCall, st);
     constexpr int S1 = 512, S2 = 128, F1 = 320, LD3 = 648;
 
     // ---- sa1 ---------------------------------------------------------------------------------------
@@ -504,6 +683,18 @@ extern "C" int iq_pointnet2_forward(const iq_pointnet2_weights* w, const float* 
     int col = 0;
     for (int q = 0; q < 3; ++q) {
         IQ_REQUIRE(w->sa1[q].nsample <= 128 && w->sa2[q].nsample <= 128, "pointnet2: nsample > 128");
+        if (tab && tab->use[q]) {  // sa1 of this scale = gather-max over the pair table
+            GatherArgs g = *gat;
+            g.fps = s.fps1; g.idx = s.idx1[q]; g.cnt = s.cnt1[q]; g.n_unique = s.nu1;
+            g.map = tab->map[q]; g.feat = tab->feat[q]; g.C3 = tab->c3[q];
+            g.out = s.l1 + col; g.ldo = F1; g.N = N; g.S = S1; g.K = w->sa1[q].nsample; g.B = B;
+            const int gpb = kThreads / (g.C3 / 4);
+            iq::ProfileSpan span(iq::kSlotPrepool, st);
+            hipLaunchKernelGGL(pt_gather_kernel, dim3((unsigned)((B + 7) / 8 * 8 * ((S1 + gpb - 1) / gpb))), dim3(kThreads), 0, st, g);
+            if ((rc = iq::check_launch("pt_gather_kernel"))) return rc;
+            col += w->sa1[q].l3.cout;
+            continue;
+        }
         GroupArgs a{};
         a.xyz = xyz; a.ldx = 3; a.new_xyz = s.nx1; a.ldc = 3; a.idx = s.idx1[q]; a.cnt = s.cnt1[q];
         a.block_start = s.bstart; a.blockmap = s.bmap;
@@ -555,4 +746,133 @@ extern "C" int iq_pointnet2_forward(const iq_pointnet2_weights* w, const float* 
     if ((rc = iq::launch_linear(s.f1, 512, w->fc2, s.f2, 256, B, 1, st))) return rc;
     if ((rc = iq::launch_linear(s.f2, 256, w->fc3, logits, w->fc3.cout, B, 0, st))) return rc;
     return IQ_OK;
+}
+
+}  // namespace
+
+extern "C" int iq_pointnet2_forward(const iq_pointnet2_weights* w, const float* xyz, float* logits, void* workspace,
+                                    size_t workspace_bytes, int B, int N, iq_stream_t stream) {
+    IQ_REQUIRE(w && xyz && logits, "iq_pointnet2_forward: null pointer");
+    IQ_REQUIRE(B >= 0 && N >= 1 && N <= 4096, "iq_pointnet2_forward: B=%d N=%d", B, N);
+    if (B == 0) return IQ_OK;
+    const size_t need = carve2(nullptr, B, w).bytes;
+    if (!workspace || workspace_bytes < need)
+        return iq::fail(IQ_EWORKSPACE, "iq_pointnet2_forward: workspace %zu < %zu bytes", workspace_bytes, need);
+    Ws2 s = carve2(workspace, B, w);
+    hipStream_t st = iq::as_stream(stream);
+    iq::ProfileSpan call_span(iq::kSlotCall, st);
+    return run_pn2(w, xyz, logits, s, B, N, st, nullptr, nullptr);
+}
+
+// ---- coalitions -------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kPairFan = 192;  // table capacity per source cloud and scale: kPairFan * (N + 1) pair rows
+
+struct WsC {
+    float* X;          // (B,N,3) masked clouds
+    float* P;          // (nc,N+1,4)
+    int32_t *cntp, *off, *total;   // (nc*3*(N+1)) x2, (nc*3)
+    int32_t* map[3];   // (nc,(N+1)^2)
+    uint32_t* pairs;   // (cap) of the scale being built
+    float *h1, *h2;    // (cap, C1 / C2) of the scale being built
+    float* feat[3];    // (cap, C3)
+    size_t bytes;
+};
+
+WsC carve_c(void* base, int B, int nc, int N) {
+    WsC s{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = iq::align_up(off + bytes, 256);
+        return reinterpret_cast<char*>(base) + o;
+    };
+    const size_t n1 = (size_t)N + 1, cap = (size_t)nc * kPairFan * n1;
+    s.X = (float*)take((size_t)B * N * 3 * 4);
+    s.P = (float*)take((size_t)nc * n1 * 4 * 4);
+    s.cntp = (int32_t*)take((size_t)nc * 3 * n1 * 4);
+    s.off = (int32_t*)take((size_t)nc * 3 * n1 * 4);
+    s.total = (int32_t*)take((size_t)nc * 3 * 4);
+    for (int q = 0; q < 3; ++q) s.map[q] = (int32_t*)take((size_t)nc * n1 * n1 * 4);
+    s.pairs = (uint32_t*)take(cap * 4);
+    s.h1 = (float*)take(cap * 64 * 4);
+    s.h2 = (float*)take(cap * 96 * 4);
+    const int c3[3] = {64, 128, 128};
+    for (int q = 0; q < 3; ++q) s.feat[q] = (float*)take(cap * c3[q] * 4);
+    s.bytes = off;
+    return s;
+}
+
+}  // namespace
+
+extern "C" size_t iq_pointnet2_coalitions_workspace_bytes(int B, int nclouds, int N) {
+    if (B < 0 || nclouds < 1 || N < 1) return 0;
+    return iq::align_up(carve2(nullptr, B, nullptr).bytes, 256) + carve_c(nullptr, B, nclouds, N).bytes;
+}
+
+extern "C" int iq_pointnet2_coalitions(const iq_pointnet2_weights* w, const float* clouds, const float* centers,
+                                       const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of,
+                                       float* logits, void* workspace, size_t workspace_bytes, int B, int nclouds, int N,
+                                       iq_stream_t stream) {
+    IQ_REQUIRE(B >= 0 && nclouds >= 1 && nclouds <= 64, "iq_pointnet2_coalitions: B=%d nclouds=%d", B, nclouds);
+    IQ_REQUIRE(w && clouds && centers && region_id && (B == 0 || (keep && logits)), "iq_pointnet2_coalitions: null pointer");
+    IQ_REQUIRE(N >= 1 && N <= 4096, "iq_pointnet2_coalitions: N=%d", N);
+    IQ_REQUIRE(cloud_of || nclouds == 1 || nclouds == B, "iq_pointnet2_coalitions: cloud_of required when 1 < nclouds != B");
+    if (B == 0) return IQ_OK;
+    const size_t base_bytes = iq::align_up(carve2(nullptr, B, w).bytes, 256);
+    const size_t need = base_bytes + carve_c(nullptr, B, nclouds, N).bytes;
+    if (!workspace || workspace_bytes < need)
+        return iq::fail(IQ_EWORKSPACE, "iq_pointnet2_coalitions: workspace %zu < %zu bytes", workspace_bytes, need);
+    Ws2 s = carve2(workspace, B, w);
+    WsC t = carve_c(reinterpret_cast<char*>(workspace) + base_bytes, B, nclouds, N);
+    hipStream_t st = iq::as_stream(stream);
+    int rc;
+    iq::ProfileSpan call_span(iq::kSlotCall, st);
+    const int n1 = N + 1;
+
+    hipLaunchKernelGGL(pn2_mask_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, clouds, centers, region_id, keep, cloud_of,
+                       t.X, N, B, nclouds);
+    hipLaunchKernelGGL(pt_points_kernel, dim3((nclouds * n1 + 255) / 256), dim3(256), 0, st, clouds, centers, t.P, N, nclouds);
+    float r2[3];
+    for (int q = 0; q < 3; ++q) r2[q] = (float)((double)w->sa1[q].radius * (double)w->sa1[q].radius);
+    IQ_REQUIRE(r2[0] <= r2[1] && r2[1] <= r2[2], "iq_pointnet2_coalitions: sa1 radii must ascend");
+    hipLaunchKernelGGL(pt_count_kernel, dim3(n1, nclouds), dim3(kThreads), 0, st, t.P, N, r2[0], r2[1], r2[2], t.cntp);
+    hipLaunchKernelGGL(pt_scan_kernel, dim3(nclouds * 3), dim3(1024), 0, st, t.cntp, t.off, t.total, N);
+    if ((rc = iq::check_launch("pt_scan_kernel"))) return rc;
+    // the one host round trip of the call: pair counts decide, per scale, between the table and the grouped MLP
+    int32_t totals[64 * 3];
+    if (hipMemcpyAsync(totals, t.total, (size_t)nclouds * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return iq::fail(IQ_ELAUNCH, "iq_pointnet2_coalitions: reading the pair counts failed");
+    const size_t cap = (size_t)nclouds * kPairFan * n1;
+    PairTabs tab{};
+    for (int q = 0; q < 3; ++q) {
+        const iq_pn2_scale& sc = w->sa1[q];
+        size_t rows = 0;
+        for (int c = 0; c < nclouds; ++c) rows += (size_t)totals[c * 3 + q];
+        tab.use[q] = rows <= cap && sc.l2.cin <= 64 && sc.l2.cout <= 96 && sc.l3.cout % 4 == 0 && sc.l3.cout <= 128 &&
+                     kThreads % (sc.l3.cout / 4) == 0 && sc.l3.cin == sc.l2.cout && N < 65535;
+        tab.map[q] = t.map[q]; tab.feat[q] = t.feat[q]; tab.c3[q] = sc.l3.cout;
+        if (!tab.use[q]) continue;
+        int row0 = 0;
+        for (int c = 0; c < nclouds; ++c) {  // rows of cloud c: [row0, row0 + totals)
+            hipLaunchKernelGGL(pt_fill_kernel, dim3(n1, 1), dim3(64), 0, st, t.P + (size_t)c * n1 * 4, N, r2[q],
+                               t.off + ((size_t)c * 3 + q) * n1, row0, t.map[q] + (size_t)c * n1 * n1, t.pairs);
+            const int nr = totals[c * 3 + q];
+            if (nr > 0) {
+                hipLaunchKernelGGL(pt_l1_kernel, dim3((unsigned)(((size_t)nr * sc.l2.cin + 255) / 256)), dim3(256), 0, st,
+                                   t.P + (size_t)c * n1 * 4, t.pairs + row0, sc.w1x, t.h1 + (size_t)row0 * sc.l2.cin, sc.l2.cin, nr);
+            }
+            row0 += nr;
+        }
+        if ((rc = iq::check_launch("pt_fill_kernel"))) return rc;
+        if (row0 > 0) {
+            if ((rc = iq::launch_linear(t.h1, sc.l2.cin, sc.l2, t.h2, sc.l2.cout, row0, 1, st))) return rc;
+            if ((rc = iq::launch_linear(t.h2, sc.l2.cout, sc.l3, t.feat[q], sc.l3.cout, row0, 1, st))) return rc;
+        }
+    }
+    GatherArgs g{};
+    g.region_id = region_id; g.keep = keep; g.cloud_of = cloud_of; g.nclouds = nclouds;
+    return run_pn2(w, t.X, logits, s, B, N, st, &tab, &g);
 }

@@ -109,6 +109,29 @@ class PointNet2Engine:
         return logits
 
 
+    def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None):
+        """iq_pointnet2_coalitions: clouds (nc,N,3), centers (nc,3), region_id (nc,N) i32, keep (B,) i64 bit masks,
+        cloud_of (B,) i32 or None -> logits (B,C)."""
+        for t, dt, nm in ((clouds, torch.float32, "clouds"), (centers, torch.float32, "centers"), (region_id, torch.int32, "region_id"),
+                          (keep, torch.int64, "keep"), (cloud_of, torch.int32, "cloud_of")):
+            if t is None and nm == "cloud_of":
+                continue
+            if t is None or not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+                raise _lib.IqError("%s must be a contiguous %s GPU tensor" % (nm, dt))
+        nc, n, _ = clouds.shape
+        b = keep.shape[0]
+        need = self.lib.iq_pointnet2_coalitions_workspace_bytes(b, nc, n)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        logits = torch.empty((b, self.weights.num_classes), dtype=torch.float32, device=self.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+        rc = self.lib.iq_pointnet2_coalitions(ctypes.byref(self.weights.struct), p(clouds), p(centers), p(region_id), p(keep),
+                                              p(cloud_of), p(logits), p(self._ws), self._ws.numel(), b, nc, n,
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "iq_pointnet2_coalitions")
+        return logits
+
+
 def _holder_msg(cfg):
     m = nn.Module()
     m.conv_blocks, m.bn_blocks = nn.ModuleList(), nn.ModuleList()
@@ -174,3 +197,20 @@ class PointNet2ClsMsg(nn.Module):
     def forward(self, xyz):
         """xyz (B,3,N) as in the reference -> logits (B,10)."""
         return self.forward_points(xyz.permute(0, 2, 1).contiguous())
+
+    def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None, num_regions=None):
+        """Same call as PointNetCls.coalition_logits: logits of B coalitions given as region bit masks (sa1 from the
+        per-cloud pair tables, csrc/iq_pointnet2.hip)."""
+        eng = self.engine()
+        step = self.max_clouds_per_call
+        nc, b = clouds.shape[0], keep.shape[0]
+        if cloud_of is None and nc not in (1, b):
+            raise _lib.IqError("cloud_of is required when 1 < number of clouds != number of coalitions")
+        if b <= step:
+            return eng.coalition_logits(clouds, centers, region_id, keep, cloud_of)
+        if cloud_of is None and nc == b:
+            cloud_of = torch.arange(b, dtype=torch.int32, device=keep.device)
+        out = [eng.coalition_logits(clouds, centers, region_id, keep[i:i + step].contiguous(),
+                                    cloud_of[i:i + step].contiguous() if cloud_of is not None else None)
+               for i in range(0, b, step)]
+        return torch.cat(out, dim=0)

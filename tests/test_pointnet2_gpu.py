@@ -113,3 +113,26 @@ def test_pointnet2_raw_clouds_vs_oracle(model, oracle):
     want = oracle.PointNet2Oracle(synth.to_torch(synth.pointnet2_state_dict(0)))(x)
     got = model(x.to(dev()))
     assert rel_err(got.cpu().numpy(), want.numpy()) < RTOL
+
+
+def test_coalitions_with_pair_tables_equal_the_forward_on_masked_clouds(model):
+    """iq_pointnet2_coalitions (sa1 = gather-max over per-cloud pair tables) against iq_pointnet2_forward on the
+    materialised masked clouds: nothing / few / many / everything masked, two source clouds (cloud_of)."""
+    d = dev()
+    rng = np.random.default_rng(5)
+    clouds = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in (0, 1)]).to(d)           # (2,1024,3)
+    rid = torch.from_numpy(rng.integers(0, 32, size=(2, 1024)).astype(np.int32))
+    for c in range(2):   # spatially coherent regions as in the real pipeline
+        data = clouds[c:c + 1]
+        rid[c] = hip_ops.region_assign(data[0].contiguous(), hip_ops.fps(data, 32)[0].contiguous()).cpu()
+    centers = clouds.mean(dim=1)
+    full = (1 << 32) - 1
+    keep = [full, 0, full ^ (1 << 7), 1 << 3, 0x0f0f0f0f, 0xffff, full, 1 << 5, full ^ 1, 0xaaaaaaaa, 7, 0]
+    cloud_of = [0] * 6 + [1] * 6
+    keep_t = hip_ops.masks_to_tensor(keep, d)
+    co_t = torch.tensor(cloud_of, dtype=torch.int32, device=d)
+    got = model.coalition_logits(clouds, centers, rid.to(d), keep_t, co_t, num_regions=32)
+    dense = [hip_ops.mask_coalitions(clouds[c], rid[c].to(d), hip_ops.masks_to_tensor([k], d), centers[c].contiguous())[0]
+             for k, c in zip(keep, cloud_of)]
+    want = model.forward_points(torch.stack(dense))
+    assert torch.equal(got, want)   # same arithmetic per member row, max is order-independent
