@@ -239,3 +239,39 @@ def test_stage1_and_a_sweep_for_models_without_the_fused_pointnet_path(tmp_path,
     sv_all = np.load(root + "region_sv_all.npy")
     assert sv_all.shape == (100, 8)
     np.testing.assert_allclose(sv_all.sum(1), nf, rtol=0, atol=1e-3 * max(1.0, abs(nf)))
+
+
+def test_full_size_shapley_properties(model, oracle, pointnet_sd):
+    """BASELINE configs[1] at full size (32 regions x 1000 permutations = 33 000 coalitions of one cloud), through
+    size-independent properties: efficiency of every permutation, exact float64 additivity over blocks of permutations,
+    permutation-order equivariance of the logits, and a spot check of 3 random permutations against the CPU oracle."""
+    pts, label = synth.make_cloud(3)
+    data = torch.from_numpy(pts).unsqueeze(0).to(dev())
+    lbl = torch.tensor([label], device=dev())
+    region_id = hip_ops.region_assign(data[0].contiguous(), hip_ops.fps(data, 32)[0].contiguous()).cpu().numpy().astype(np.int64)
+    orders = synth.make_orders(1000, 32, seed=1)
+    args = ns(num_regions=32, num_samples=1000, shapley_batch_size=50)
+    phi, logits = final_common.shap_sampling_all_regions_batch(model, data, lbl, region_id, orders, args)
+    assert tuple(logits.shape) == (33000, 10)
+    v = hip_ops.reward(logits.contiguous(), label, True).reshape(1000, 33).double().cpu().numpy()
+    # efficiency: the telescoping sum of a permutation is v(all) - v(none); rows 0 / 32 are the same two clouds everywhere
+    assert np.abs(v[:, 0] - v[0, 0]).max() == 0 and np.abs(v[:, 32] - v[0, 32]).max() == 0
+    np.testing.assert_allclose(phi.sum(), v[0, 32] - v[0, 0], rtol=0, atol=5e-5 * max(1.0, abs(v[0, 32] - v[0, 0])))
+    # additivity: phi over 1000 permutations = mean of the 10 block results (float64 sums of float32 differences)
+    blocks = []
+    for k in range(10):
+        a = ns(num_regions=32, num_samples=100, shapley_batch_size=50)
+        pk, lk = final_common.shap_sampling_all_regions_batch(model, data, lbl, region_id, orders[100 * k:100 * (k + 1)], a)
+        assert torch.equal(lk, logits[3300 * k:3300 * (k + 1)])         # a coalition's logits do not depend on the batch
+        blocks.append(pk)
+    np.testing.assert_allclose(np.mean(blocks, axis=0), phi, rtol=0, atol=1e-12)
+    # spot check against the oracle
+    rng = np.random.default_rng(0)
+    pick = rng.choice(1000, size=3, replace=False)
+    want, _ = oracle.shap_sampling_all_regions_batch(oracle.PointNetOracle(pointnet_sd), data.cpu(), lbl.cpu(), region_id,
+                                                     orders[pick], 3, 3, 32)
+    got = np.zeros(32)
+    for o in pick:
+        dv = v[o, 1:] - v[o, :-1]
+        got[orders[o]] += dv
+    assert np.abs(got / 3 - want).max() < RTOL * max(np.abs(want).max(), 1e-3) + 1e-6
