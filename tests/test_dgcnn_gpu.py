@@ -178,3 +178,30 @@ def test_compact_coalitions_equal_the_dense_forward_on_masked_clouds(cls):
         dense.append(hip_ops.mask_coalitions(clouds[c], rid[c].to(d), hip_ops.masks_to_tensor([k], d), centers[c].contiguous())[0])
     want = model.forward_points(torch.stack(dense))
     assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-5
+
+
+def test_interaction_shape_properties_at_bench_size():
+    """BASELINE configs[3] shape (30 pairs x 100 contexts x 4 = 12 000 coalitions): a coalition's logits do not depend on
+    what else is in the launch (bitwise), and the interaction of (i, j | S) equals that of (j, i | S) exactly."""
+    model = make(DGCNN_cls)
+    d = dev()
+    pts, label = synth.make_cloud(0)
+    data = torch.from_numpy(pts).unsqueeze(0).to(d)
+    lbl = torch.tensor([label], device=d)
+    region_id = hip_ops.region_assign(data[0].contiguous(), hip_ops.fps(data, 32)[0].contiguous()).cpu().numpy().astype(np.int64)
+    rng = np.random.default_rng(1)
+    all_pairs = np.array([[i, j] for i in range(32) for j in range(32) if j > i])
+    pairs = all_pairs[rng.choice(len(all_pairs), size=30, replace=False)]
+    ctx = np.stack([np.stack([rng.choice([r for r in range(32) if r not in pr], 15, replace=False) for _ in range(100)]) for pr in pairs])
+    args = argparse.Namespace(model="dgcnn", softmax_type="modified", num_regions=32, interaction_batch_size=25)
+    logits = interaction.compute_order_interaction_logits(model, data, region_id, pairs, ctx, args)          # (30, 400, 10)
+    assert tuple(logits.shape) == (30, 400, 10) and torch.isfinite(logits).all()
+    part = interaction.compute_order_interaction_logits(model, data, region_id, pairs[7:19], ctx[7:19], args)
+    assert torch.equal(part, logits[7:19])
+    swapped = interaction.compute_order_interaction_logits(model, data, region_id, pairs[:, ::-1].copy(), ctx, args)
+    # rows 4k+1 / 4k+2 (S+i / S+j) trade places, rows 4k and 4k+3 are the same coalitions
+    assert torch.equal(swapped[:, 0::4], logits[:, 0::4]) and torch.equal(swapped[:, 3::4], logits[:, 3::4])
+    assert torch.equal(swapped[:, 1::4], logits[:, 2::4]) and torch.equal(swapped[:, 2::4], logits[:, 1::4])
+    i1 = interaction.compute_order_interaction(logits, lbl, args)
+    i2 = interaction.compute_order_interaction(swapped, lbl, args)
+    assert i1.shape == (30, 100) and np.abs(i1 - i2).max() < 1e-6   # (v0 + v3) - v1 - v2 vs (v0 + v3) - v2 - v1 in float32
