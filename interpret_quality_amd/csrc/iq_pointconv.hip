@@ -532,7 +532,8 @@ extern "C" int iq_pointconv_forward(const iq_pointconv_weights* w, const float* 
         if ((rc = iq::launch_linear(s.h2, 512, w->sa[2].l3, s.h3, 1024, B * S2, 1, st))) return rc;
         hipLaunchKernelGGL(pc_all_contract_kernel, dim3(1024 / kThreads, B), dim3(kThreads), 0, st, s.h3, s.sw3, s.g3, S2, 1024);
         if ((rc = iq::check_launch("pc_all_contract_kernel"))) return rc;
-        if ((rc = iq::launch_linear(s.g3, 16384, w->sa[2].linear, s.l3, 1024, B, 1, st))) return rc;
+        // 16384 -> 1024 on only B rows: split K over workgroups (scratch: the h3 buffer, free by now, B*128*1024 floats)
+        if ((rc = iq::launch_linear_splitk(s.g3, 16384, w->sa[2].linear, s.l3, 1024, B, 1, s.h3, (size_t)B * 128 * 1024, st))) return rc;
     }
     if ((rc = iq::launch_linear(s.l3, 1024, w->fc1, s.f1, 512, B, 1, st))) return rc;
     if ((rc = iq::launch_linear(s.f1, 512, w->fc2, s.f2, 256, B, 1, st))) return rc;

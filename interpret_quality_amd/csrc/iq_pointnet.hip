@@ -15,6 +15,8 @@
 // v_mfma_f32_32x32x2_f32 throughout (exact fp32 fma chains).  A operands come from LDS
 // (XOR-swizzled, conflict-free ds_read_b128), B operands (weights) stream from L2 in a
 // pre-packed fragment order (1 KiB contiguous per wave-load).  LDS = 52 KB -> 3 workgroups/CU.
+#include <algorithm>
+
 #include "iq_common.h"
 #include "iq_profile.h"
 
@@ -481,27 +483,34 @@ __global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __rest
                                                              const float* __restrict__ wp,
                                                              const float* __restrict__ bias,
                                                              float* __restrict__ out, int ldo, int M, int K,
-                                                             int Nout, int relu, const int32_t* __restrict__ m_dev) {
+                                                             int Nout, int relu, const int32_t* __restrict__ m_dev,
+                                                             int kb_per_split) {
     if (m_dev) M = min(M, *m_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = (blockIdx.x * WM + wm) * MT * 32;
     const int nt0 = (blockIdx.y * WN + wn) * NT;
-    const int KB = K >> 3;
+    const int KBT = K >> 3;                               // k-blocks of the whole layer (weight image stride)
+    // split-K (kb_per_split > 0): workgroup z accumulates k-blocks [z kb_per_split, ...) and stores the raw partial
+    // sums to out + z M ldo; bias and activation are applied by splitk_reduce_kernel
+    const bool split = kb_per_split > 0;
+    const int kb0 = split ? blockIdx.z * kb_per_split : 0;
+    const int KB = split ? min(kb_per_split, KBT - kb0) : KBT;
     const int ntiles = (Nout + 31) >> 5;
     if (m0 >= M || nt0 >= ntiles) return;
+    if (split) out += (size_t)blockIdx.z * M * ldo;
 
     const float* ap[MT];
     const float* bp[NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int row = min(m0 + i * 32 + (lane & 31), M - 1);
-        ap[i] = A + (size_t)row * lda + 4 * (lane >> 5);
+        ap[i] = A + (size_t)row * lda + 4 * (lane >> 5) + 8 * kb0;
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int nt = min(nt0 + j, ntiles - 1);
-        bp[j] = wp + ((size_t)nt * KB * 64 + lane) * 4;
+        bp[j] = wp + (((size_t)nt * KBT + kb0) * 64 + lane) * 4;
     }
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -534,7 +543,7 @@ __global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __rest
     for (int j = 0; j < NT; ++j) {
         const int col = (nt0 + j) * 32 + (lane & 31);
         if (nt0 + j >= ntiles || col >= Nout) continue;
-        const float b = bias[col];
+        const float b = split ? 0.f : bias[col];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -542,6 +551,7 @@ __global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __rest
                 const int row = m0 + i * 32 + c_row(r, lane);
                 if (row < M) {
                     float v = acc[i][j][r] + b;
+                    if (split) { out[(size_t)row * ldo + col] = acc[i][j][r]; continue; }
                     if (relu == 1) v = fmaxf(v, 0.f);
                     else if (relu == 2) v = v > 0.f ? v : 0.2f * v;  // LeakyReLU(0.2), models/dgcnn.py:66-80
                     out[(size_t)row * ldo + col] = v;
@@ -749,13 +759,52 @@ int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* o
     if (ntiles >= 4) {
         dim3 grid((M + 127) / 128, (ntiles + 3) / 4);
         hipLaunchKernelGGL((pn_linear_kernel<2, 2, 2, 2>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M,
-                           L.cin, L.cout, relu, m_dev);
+                           L.cin, L.cout, relu, m_dev, 0);
     } else {
         dim3 grid((M + 255) / 256, ntiles);
         hipLaunchKernelGGL((pn_linear_kernel<2, 1, 4, 1>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M,
-                           L.cin, L.cout, relu, m_dev);
+                           L.cin, L.cout, relu, m_dev, 0);
     }
     return iq::check_launch("pn_linear_kernel");
+}
+
+namespace {
+// out[row][col] = act(bias[col] + sum_z partial[z][row][col]), z ascending: fixed summation order
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias, float* __restrict__ out,
+                                     int ldo, int M, int N, int splits, int relu) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * N) return;
+    const int row = t / N, col = t - row * N;
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += partial[((size_t)z * M + row) * N + col];
+    v += bias[col];
+    if (relu == 1) v = fmaxf(v, 0.f);
+    else if (relu == 2) v = v > 0.f ? v : 0.2f * v;
+    out[(size_t)row * ldo + col] = v;
+}
+}  // namespace
+
+// Few rows, very long K (PointConv's 16384 -> 1024 layer on B rows): a plain launch has ceil(M/128) x cout/128 workgroups -
+// 48 for 660 rows - each walking all of K.  Split K over blockIdx.z until the grid fills the chip; partial sums go
+// through `scratch` (splits x M x cout floats) and are added in a fixed order.
+int iq::launch_linear_splitk(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,
+                             float* scratch, size_t scratch_floats, hipStream_t st) {
+    if (M == 0) return IQ_OK;
+    IQ_REQUIRE(L.w && L.b && L.cin % 8 == 0 && L.cout >= 1, "dense layer: bad descriptor (cin=%d cout=%d)", L.cin, L.cout);
+    const int ntiles = (L.cout + 31) / 32, KB = L.cin / 8;
+    const int wgs = ((M + 127) / 128) * ((ntiles + 3) / 4);
+    int splits = wgs >= 512 ? 1 : (1024 + wgs - 1) / wgs;
+    splits = std::min(splits, std::max(1, KB / 64));                                        // >= 512 k per split
+    while (splits > 1 && (size_t)splits * M * L.cout > scratch_floats) --splits;
+    if (splits <= 1 || ntiles < 4 || !scratch) return launch_linear(A, lda, L, out, ldo, M, relu, st);
+    const int kbs = (KB + splits - 1) / splits;
+    splits = (KB + kbs - 1) / kbs;
+    dim3 grid((M + 127) / 128, (ntiles + 3) / 4, splits);
+    hipLaunchKernelGGL((pn_linear_kernel<2, 2, 2, 2>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, scratch, L.cout, M, L.cin,
+                       L.cout, 0, nullptr, kbs);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * L.cout + 255) / 256)), dim3(256), 0, st, scratch, L.b,
+                       out, ldo, M, L.cout, splits, relu);
+    return iq::check_launch("pn_linear_kernel<split-K>");
 }
 
 int iq::launch_linear_pool(const float* A, int lda, const iq_dense_layer& L, float* partial, int M, int relu,
