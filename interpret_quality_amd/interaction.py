@@ -59,7 +59,9 @@ def compute_order_interaction_logits(model, data_disturb, region_id, region_pair
     rid = hip_ops.as_i32(region_id, dev)
     with torch.no_grad():
         if hi > lo:
-            keep_np = context_keep_masks(pairs[lo:hi], ctx[lo:hi])
+            # equal sets are equal clouds (few-region contexts repeat a lot): evaluate the distinct ones once
+            keep_np, inv = final_common.distinct_coalitions(context_keep_masks(pairs[lo:hi], ctx[lo:hi]))
+            inv_t = torch.from_numpy(inv.astype(np.int64)).to(dev)
             if hasattr(model, "coalition_logits"):
                 logits = model.coalition_logits(data_disturb.contiguous(), center.contiguous(), rid.reshape(1, -1),
                                                 hip_ops.masks_to_tensor(keep_np, dev), None, num_regions=r)
@@ -74,7 +76,7 @@ def compute_order_interaction_logits(model, data_disturb, region_id, region_pair
                                                 center.reshape(3).contiguous(), channel_first=not points_api)
                     chunks.append(model.forward_points(x) if points_api else model(x))
                 logits = torch.cat(chunks, dim=0)
-            logits = logits.reshape(hi - lo, 4 * num_context, -1)
+            logits = logits.index_select(0, inv_t).reshape(hi - lo, 4 * num_context, -1)
         else:
             logits = torch.zeros((0, 4 * num_context, 10), dtype=torch.float32, device=dev)
         all_logits = iqdist.all_gather_rows(logits, num_pairs)

@@ -122,15 +122,19 @@ def shapley_over_poses(model, poses, lbl, region_id, orders, args, pose_batch=8)
     per = s * (r + 1)
     phis, all_logits = [], []
     if hasattr(model, "coalition_logits"):
-        keep1 = final_common.prefix_keep_masks(orders, r)
+        # every pose uses the same permutations, hence the same sets: evaluate the distinct ones (final_common.distinct_coalitions)
+        uniq, inv = final_common.distinct_coalitions(final_common.prefix_keep_masks(orders, r))
+        nu = len(uniq)
+        inv_t = torch.from_numpy(inv.astype(np.int64)).to(dev)
         for lo in range(0, p, pose_batch):
             clouds = poses[lo:lo + pose_batch].contiguous()
             nb = clouds.shape[0]
             centers = torch.mean(clouds, dim=1).contiguous()  # centre of the PERTURBED cloud, tools/final_common.py:80
-            keep = hip_ops.masks_to_tensor(np.tile(keep1, nb), dev)
-            cloud_of = torch.arange(nb, dtype=torch.int32, device=dev).repeat_interleave(per).contiguous()
+            keep = hip_ops.masks_to_tensor(np.tile(uniq, nb), dev)
+            cloud_of = torch.arange(nb, dtype=torch.int32, device=dev).repeat_interleave(nu).contiguous()
             logits = model.coalition_logits(clouds, centers, rid.reshape(1, -1).expand(nb, -1).contiguous(), keep,
                                             cloud_of, num_regions=r)
+            logits = logits.reshape(nb, nu, -1).index_select(1, inv_t).reshape(nb * per, -1)
             v = final_common.get_reward(logits, lbl, args)
             for k in range(nb):
                 phi_sum, _, _ = hip_ops.shapley_accum(v[k * per:(k + 1) * per].contiguous(), orders_dev)
