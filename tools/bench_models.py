@@ -26,12 +26,16 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--mode", default="shapley", choices=["shapley", "interaction"])
 ap.add_argument("--pairs", type=int, default=30)
 ap.add_argument("--contexts", type=int, default=100)
+ap.add_argument("--dedup", action="store_true", help="let the drivers evaluate each distinct coalition once (default: every row "
+                "is a forward pass, so the figure is kernel throughput)")
 ap.add_argument("--tune", default="", help="iq_set_tuning pairs, e.g. 3=1 (no LDS GEMM)")
 ap.add_argument("--dense", action="store_true", help="materialise the masked clouds even if the model has a coalition path")
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
 lib = _lib.load()
+if not a.dedup:   # identity "dedup": every coalition row is evaluated
+    final_common.distinct_coalitions = lambda k: (np.asarray(k, dtype=np.uint64), np.arange(len(k)))
 for kv in filter(None, a.tune.split(",")):
     k, v = kv.split("=")
     lib.iq_set_tuning(int(k), int(v))
