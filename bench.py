@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--regions", type=int, default=NUM_REGIONS)
     ap.add_argument("--cpu-baseline", type=int, default=1, help="time the CPU oracle on rank 0 at N=1")
     ap.add_argument("--cpu-perms", type=int, default=40, help="permutations of the bounded CPU sample")
+    ap.add_argument("--other-models", type=int, default=1, help="after the timed region (N=1 only): coalitions/s of the other "
+                    "model families on BASELINE configs[2..3] shapes, reported under 'other_models'")
     return ap.parse_args()
 
 
@@ -75,6 +77,69 @@ def cpu_baseline(num_regions, perms, bs=10):
             "sample": "oracle/ref_cpu.py shap_sampling_all_regions_batch, PointNet, 1 synthetic cloud, R=%d, "
                       "%d permutations (bs=%d, %d clouds per forward) = %d coalitions in %.1f s"
                       % (num_regions, perms, bs, bs * (num_regions + 1), n, dt)}
+
+
+def other_models(dev, regions=32):
+    """Not the headline: coalitions/s of the other model families through the same C ABI, each on the shape BASELINE.json
+    names for it (PointNet++ / PointConv: Shapley, 100 permutations = 3300 coalitions per step; DGCNN / GCNN: interaction,
+    30 pairs x 100 contexts x 4 = 12 000 coalitions per step).  Every coalition row is a forward pass (no driver-level
+    de-duplication).  Failures are reported, never raised: the headline line must still be printed."""
+    import argparse as ap
+    from interpret_quality_amd import final_common, hip_ops, interaction, synth
+    from interpret_quality_amd.dgcnn import DGCNN_cls, GCNN_cls
+    from interpret_quality_amd.pointconv import PointConvDensityClsSsg
+    from interpret_quality_amd.pointnet2 import PointNet2ClsMsg
+    import contextlib
+    import io
+    saved = final_common.distinct_coalitions
+    final_common.distinct_coalitions = lambda k: (np.asarray(k, dtype=np.uint64), np.arange(len(k)))
+    out = {}
+    try:
+        pts, label = synth.make_cloud(0)
+        data = torch.from_numpy(pts).unsqueeze(0).to(dev)
+        lbl = torch.tensor([label], device=dev)
+        region_id = hip_ops.region_assign(data[0].contiguous(), hip_ops.fps(data, regions)[0].contiguous()).cpu().numpy()
+        orders = synth.make_orders(100, regions, seed=1)
+        rng = np.random.default_rng(0)
+        all_pairs = np.array([[i, j] for i in range(regions) for j in range(regions) if j > i])
+        pairs = all_pairs[rng.choice(len(all_pairs), size=30, replace=False)]
+        ctx = np.stack([np.stack([rng.choice([r for r in range(regions) if r not in pr], 15, replace=False) for _ in range(100)])
+                        for pr in pairs])
+        specs = (("pointnet2", PointNet2ClsMsg, synth.pointnet2_state_dict, "shapley"),
+                 ("dgcnn", DGCNN_cls, synth.dgcnn_state_dict, "interaction"),
+                 ("gcnn", GCNN_cls, synth.dgcnn_state_dict, "interaction"),
+                 ("pointconv", PointConvDensityClsSsg, synth.pointconv_state_dict, "shapley"))
+        for name, cls, sd, mode in specs:
+            try:
+                m = cls(ap.Namespace(dataset="modelnet10", k=20) if "cnn" in name else None)
+                m.load_state_dict(synth.to_torch(sd(0)))
+                m = m.to(dev).eval()
+                a = ap.Namespace(model=name, softmax_type="modified", num_points=NUM_POINTS, num_regions=regions, num_samples=100,
+                                 shapley_batch_size=20, interaction_batch_size=100, verbose=False)
+                if mode == "shapley":
+                    run = lambda: final_common.shap_sampling_all_regions_batch(m, data, lbl, region_id, orders, a)
+                    n = 100 * (regions + 1)
+                else:
+                    def run():
+                        with contextlib.redirect_stdout(io.StringIO()):
+                            return interaction.compute_order_interaction_logits(m, data, region_id, pairs, ctx, a)
+                    n = 30 * 100 * 4
+                run()
+                torch.cuda.synchronize()
+                steps = 3
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    run()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                out[name] = {"value": n * steps / dt, "unit": "coalitions/s", "steps": steps,
+                             "workload": "%s, %d regions, %d coalitions per step" % (mode, regions, n)}
+                del m
+            except Exception as e:  # noqa: BLE001
+                out[name] = {"error": repr(e)[:200]}
+    finally:
+        final_common.distinct_coalitions = saved
+    return out
 
 
 def main():
@@ -192,6 +257,8 @@ def main():
                          "step_tflops_algorithmic": step_flops / (elapsed / args.steps) / 1e12,
                          "prepool_ms_per_launch": pre_ms / max(pre_n, 1), "call_ms": call_ms / max(call_n, 1)},
         }
+        if world == 1 and args.other_models:
+            out["other_models"] = other_models(dev, R)
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(R, args.cpu_perms)
         print(json.dumps(out), flush=True)
