@@ -216,3 +216,39 @@ def test_coalition_paths_on_smaller_clouds_and_max_regions(name):
     want = m.forward_points(dense)
     assert np.isfinite(got.cpu().numpy()).all()
     assert np.abs((got - want).cpu().numpy()).max() / np.abs(want.cpu().numpy()).max() < 1e-5
+
+
+def test_abi_error_reporting_of_the_coalition_and_enumeration_entry_points():
+    import argparse
+    from interpret_quality_amd.dgcnn import DGCNN_cls
+    from interpret_quality_amd.pointnet2 import PointNet2ClsMsg
+    lib = _lib.load()
+    d = dev()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    clouds = torch.zeros((1, 1024, 3), device=d)
+    centers = torch.zeros((1, 3), device=d)
+    rid = torch.zeros((1, 1024), dtype=torch.int32, device=d)
+    keep = torch.zeros((4,), dtype=torch.int64, device=d)
+    logits = torch.empty((4, 10), device=d)
+    tiny = torch.empty(4096, dtype=torch.uint8, device=d)
+    dg = DGCNN_cls(argparse.Namespace(dataset="modelnet10", k=20))
+    dg.load_state_dict(synth.to_torch(synth.dgcnn_state_dict(0)))
+    eng = dg.to(d).eval().engine()
+    args = (ctypes.byref(eng.weights.struct), p(clouds), p(centers), p(rid), p(keep), None, p(logits), p(tiny), tiny.numel())
+    assert lib.iq_dgcnn_coalitions(*args, 4, 1, 1024, 0, None) == -3 and b"workspace" in lib.iq_last_error()
+    assert lib.iq_dgcnn_coalitions(*args, 4, 1, 1000, 0, None) == -1 and b"multiple of 32" in lib.iq_last_error()
+    assert lib.iq_dgcnn_coalitions(*args, 4, 3, 1024, 0, None) == -1 and b"cloud_of" in lib.iq_last_error()
+    assert lib.iq_dgcnn_coalitions(*args, 0, 1, 1024, 0, None) == 0                       # empty batch: nothing to do
+    pn = PointNet2ClsMsg(None)
+    pn.load_state_dict(synth.to_torch(synth.pointnet2_state_dict(0)))
+    e2 = pn.to(d).eval().engine()
+    args2 = (ctypes.byref(e2.weights.struct), p(clouds), p(centers), p(rid), p(keep), None, p(logits), p(tiny), tiny.numel())
+    assert lib.iq_pointnet2_coalitions(*args2, 4, 1, 1024, None) == -3 and b"workspace" in lib.iq_last_error()
+    assert lib.iq_pointnet2_coalitions(*args2, 4, 0, 1024, None) == -1
+    assert lib.iq_pointnet2_coalitions_workspace_bytes(4, 1, 1024) > lib.iq_pointnet2_workspace_bytes(4)
+    with pytest.raises(_lib.IqError, match="N=2048"):
+        hip_ops.smoothness_enum(torch.zeros((2048, 3), device=d), torch.zeros(2048, dtype=torch.int32, device=d), 4, "linearity", "inc")
+    with pytest.raises(_lib.IqError, match="mode"):
+        hip_ops.smoothness_enum(torch.zeros((64, 3), device=d), torch.zeros(64, dtype=torch.int32, device=d), 4, "roundness", "inc")
+    with pytest.raises(_lib.IqError):
+        hip_ops.linear(torch.zeros((4, 12), device=d), hip_ops.PackedLinear(np.zeros((8, 16), np.float32), np.zeros(8, np.float32), d))
