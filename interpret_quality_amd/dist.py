@@ -27,8 +27,13 @@ def init_from_env(device_type="cuda"):
     w = int(os.environ.get("WORLD_SIZE", "1"))
     r = int(os.environ.get("RANK", "0"))
     lr = int(os.environ.get("LOCAL_RANK", "0"))
+    # IQ_REHEARSAL=1: rehearse the N > 1 code path on a one-GPU box - every rank on device 0, gloo collectives
+    # (RCCL needs one device per rank).  For tests only; never set by the drivers' users.
+    rehearsal = os.environ.get("IQ_REHEARSAL") == "1"
+    if rehearsal:
+        lr = 0
     if w > 1 and not dist.is_initialized():
-        dist.init_process_group("nccl" if device_type == "cuda" else "gloo", rank=r, world_size=w)
+        dist.init_process_group("nccl" if device_type == "cuda" and not rehearsal else "gloo", rank=r, world_size=w)
     return r, w, lr
 
 
