@@ -591,6 +591,7 @@ __global__ __launch_bounds__(kThreads) void pt_gather_kernel(GatherArgs a) {
             centre_done = true;
         }
         const int row = mrow[kept ? qi : a.N];
+        if (row < 0) continue;                      // cannot happen (same predicate as the ball query); never read out of bounds
         const f32x4 v = F[(size_t)row * per + c4];
         m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
     }
