@@ -341,7 +341,8 @@ int iq_profile_enable(int on);
  * of the chain kernel (occupancy experiment); 2 = 1: no LPT launch order; 3 = 1: dense layers never use the
  * LDS-staged GEMM (pn_gemm_lds_kernel), only the register-streaming one; 4 = kNN diagnostics (results are NOT valid
  * except for 3): 1 queue appends without insertion rounds, 2 no selection at all (MFMA + load skeleton), 3 normal
- * selection + round / busy-lane counters returned in the first 24 bytes of iq_knn's tmp (tools/knn_probe.py). */
+ * selection + round / busy-lane counters returned in the first 24 bytes of iq_knn's tmp (tools/knn_probe.py);
+ * 6 = 16-row member blocks per workgroup of the PointNet++ grouped kernel (0 = default 12). */
 int iq_set_tuning(int key, int value);
 /* Debug: workgroups per CU the runtime admits for the chain kernel variants (100*v0 + v2). */
 int iq_debug_chain_occupancy(void);
