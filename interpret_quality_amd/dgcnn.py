@@ -115,7 +115,7 @@ def _coalition_logits(eng, clouds, centers, region_id, keep, cloud_of):
 
 class _GraphCnn(nn.Module):
     fixed_graph = False
-    max_clouds_per_call = 2048  # bounds the workspace (4.4 MB per cloud)
+    max_clouds_per_call = 4096  # bounds the workspace (4.4 MB per cloud)
 
     def __init__(self, args=None):
         super().__init__()
