@@ -165,3 +165,33 @@ def test_modelnet_loader_and_sample_names_match_reference(tmp_path, monkeypatch)
     assert tuple(data.shape) == (1, 1024, 3) and data.dtype == torch.float32 and tuple(lbl.shape) == (1,) and lbl.dtype == torch.long
     with pytest.raises(Exception, match="mode"):
         data_shapley.ModelNet_Loader_Shapley_test(args, partition="test", num_points=1024)
+
+
+def test_distinct_coalitions_roundtrip_and_expected_savings():
+    """final_common.distinct_coalitions: unique[inverse] reproduces the rows; prefix coalitions of 100 / 1000
+    permutations over 32 regions collapse to ~2950 / ~27 700 distinct sets (empty and full set once, 32 + 32 singletons /
+    co-singletons, ...)."""
+    for perms, lo, hi in ((100, 2900, 3000), (1000, 27000, 28500)):
+        orders = synth.make_orders(perms, 32, seed=1)
+        keep = final_common.prefix_keep_masks(orders, 32)
+        uniq, inv = final_common.distinct_coalitions(keep)
+        assert np.array_equal(uniq[inv], keep) and len(np.unique(uniq)) == len(uniq)
+        assert lo < len(uniq) < hi
+        assert (keep.reshape(perms, 33)[:, 0] == 0).all() and (keep.reshape(perms, 33)[:, 32] == (1 << 32) - 1).all()
+    # interaction contexts with one region (ratio 0.04): the 4 coalitions of many (pair, context) rows coincide
+    pairs = np.array([[1, 5], [1, 7]])
+    ctx = np.array([[[9], [9], [12]], [[9], [3], [3]]])
+    keep = interaction.context_keep_masks(pairs, ctx)
+    uniq, inv = final_common.distinct_coalitions(keep)
+    assert keep.shape == (24,) and np.array_equal(uniq[inv], keep) and len(uniq) < 24
+
+
+def test_smoothness_epoch_count_rule():
+    """The sweep evaluates epochs 0 .. max stop epoch (the reference breaks once every indicator is False), at least one
+    and at most EPOCH."""
+    from interpret_quality_amd import smoothness
+
+    def n_epochs(stop, epoch=50):
+        return max(1, min(epoch, int(np.asarray(stop).max()) + 1))
+    assert n_epochs([0, 0, 0]) == 1 and n_epochs([3, 1, 2]) == 4 and n_epochs([50, 2]) == 50 and n_epochs([-1, -1]) == 1
+    assert smoothness.EPOCH == 50 and smoothness.ENUM_STEP == 0.05 and smoothness.STEP == 1e-3
