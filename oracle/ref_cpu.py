@@ -673,3 +673,23 @@ def smoothness_enumerate(data, region_id, num_regions, mode, objective, start=No
             break
     orig = np.array([reg["var0"] + [reg["sm0"]] for reg in info])
     return np.array(data_list), np.array(smooth_list), orig
+
+
+# --------------------------------------------------------------------------------------------
+# Consumers of the artefacts (final_result.py) - only what the format-compatibility test needs
+# --------------------------------------------------------------------------------------------
+
+def consumer_sensitivity(base_folder, mode):
+    """final_result.py:83-104 (cal_sensitivity): per-region range of the Shapley values over the enumeration, normalised
+    by the mean L1 norm; reads ``<mode>_all/region_shapley_value.npy`` or, for the smoothness modes, the inc / dec pair."""
+    if mode in ("linearity", "planarity", "scattering"):
+        vals = np.concatenate((np.load(base_folder + "%s_all/allregion_inc/region_shapley_value.npy" % mode),
+                               np.load(base_folder + "%s_all/allregion_dec/region_shapley_value.npy" % mode)), axis=0)
+    else:
+        vals = np.load(base_folder + "%s_all/region_shapley_value.npy" % mode)
+    return (vals.max(axis=0) - vals.min(axis=0)) / np.mean(np.sum(np.abs(vals), axis=1))
+
+
+def consumer_mean_sv_intensity(base_folder, mode):
+    """final_result.py:62-80 for one cloud: E_pose |phi_region|."""
+    return np.mean(np.abs(np.load(base_folder + "%s_all/region_shapley_value.npy" % mode)), axis=0)
