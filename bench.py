@@ -27,6 +27,7 @@ sys.path.insert(0, REPO)
 
 NUM_POINTS, NUM_REGIONS, NUM_PERMS = 1024, 32, 1000
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak (no xf32/TF32 on gfx950)
+SUSTAINED_F32_MFMA_TFLOPS = 138.7  # bare MFMA loop on random operands, this chip: profiles/r01_mfma_shape_microbench.txt
 
 
 def parse():
@@ -234,6 +235,13 @@ def main():
         flop_per_launch = 2.0 * 143360.0 * NUM_POINTS * n_coal
         avg_launch_s = (f_ms + t_ms) / max(f_n + t_n, 1) * 1e-3
         achieved = flop_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+        # what the kernel actually executes: each coalition's DISTINCT rows (kept points + the centre), in 32-row MFMA tiles
+        sizes = np.bincount(region_id.cpu().numpy().reshape(-1), minlength=R).astype(np.int64)
+        bits = ((final_common.prefix_keep_masks(orders_np, R)[:, None] >> np.arange(R, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.int64)
+        kept = bits @ sizes
+        rows = kept + (kept < NUM_POINTS)
+        rows32 = (rows + 31) // 32 * 32
+        executed = 2.0 * 143360.0 * float(rows32.sum()) / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic_r01.json")
         if os.path.exists(tpath):
@@ -252,8 +260,12 @@ def main():
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic, "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n + t_n,
                          "algorithmic_flop_per_launch": flop_per_launch,
-                         "note": "algorithmic FLOP of the dense reference layers this kernel implements; the "
-                                 "kernel evaluates each coalition's distinct points only (exact), so frac can exceed 1",
+                         "executed": executed, "executed_frac_of_peak": executed / PEAK_F32_MFMA_TFLOPS,
+                         "sustained_mfma_random_operands": SUSTAINED_F32_MFMA_TFLOPS,
+                         "executed_frac_of_sustained": executed / SUSTAINED_F32_MFMA_TFLOPS,
+                         "note": "achieved/frac: algorithmic FLOP of the dense reference layers this kernel implements; the "
+                                 "kernel evaluates each coalition's distinct points only (exact), so frac can exceed 1. "
+                                 "executed: FLOP of the 32-row MFMA tiles it really issues",
                          "step_tflops_algorithmic": step_flops / (elapsed / args.steps) / 1e12,
                          "prepool_ms_per_launch": pre_ms / max(pre_n, 1), "call_ms": call_ms / max(call_n, 1)},
         }
