@@ -53,8 +53,8 @@ def _config():
 
 
 def mkdir(path):
-    if not os.path.exists(path):
-        os.makedirs(path)
+    """tools/final_util.py:85-87; race-free when every rank of a multi-GPU run creates the same folder."""
+    os.makedirs(path, exist_ok=True)
 
 
 class IOStream:

@@ -18,6 +18,7 @@ from . import final_common
 from .final_util import (BALL_QUERY_COEF, cal_rank, get_folder_name_list, load_model, mkdir)
 from .interaction import DEFAULT_RATIOS
 from .pose_sweep import rotate_xyz, translate_pc
+from . import dist as iqdist
 from .shapley_stage import data_loader, finish_args
 
 
@@ -197,10 +198,14 @@ def main(argv=None):
     p.add_argument("--num_clouds", type=int, default=30)
     args = p.parse_args(argv)
     finish_args(args)
-    names = get_folder_name_list(args)
-    disturb_fn = translate_pc if args.mode == "trans" else rotate_xyz
-    save_pair_random(args, names)
-    check_adv_success(args, disturb_fn, names)
-    save_pair_single_region(args, names)
-    save_context(args, names)
-    save_pred_label(args, disturb_fn, names)
+    # host RNG streams + one small search per cloud: not sharded.  Under a multi-rank launch rank 0 does the work and
+    # the others wait, so that no two ranks write the same files.
+    if iqdist.rank() == 0:
+        names = get_folder_name_list(args)
+        disturb_fn = translate_pc if args.mode == "trans" else rotate_xyz
+        save_pair_random(args, names)
+        check_adv_success(args, disturb_fn, names)
+        save_pair_single_region(args, names)
+        save_context(args, names)
+        save_pred_label(args, disturb_fn, names)
+    iqdist.barrier()

@@ -147,7 +147,8 @@ def cal_interaction_all_orders(lbl, save_path, args):
         all_logits = torch.load(save_path + "ratio%d_all_logits.pt" % int(ratio * 100), map_location=args.device)
         all_interaction = compute_order_interaction(all_logits, lbl, args)
         print(all_interaction.shape)
-        np.save(save_path + "ratio%d_%s_interaction.npy" % (int(ratio * 100), args.output_type), all_interaction)
+        if iqdist.rank() == 0:
+            np.save(save_path + "ratio%d_%s_interaction.npy" % (int(ratio * 100), args.output_type), all_interaction)
 
 
 def cal_interaction(args):

@@ -129,7 +129,10 @@ def shapley_over_poses(model, poses, lbl, region_id, orders, args, pose_batch=8)
         for lo in range(0, p, pose_batch):
             clouds = poses[lo:lo + pose_batch].contiguous()
             nb = clouds.shape[0]
-            centers = torch.mean(clouds, dim=1).contiguous()  # centre of the PERTURBED cloud, tools/final_common.py:80
+            # centre of the PERTURBED cloud (tools/final_common.py:80), reduced one (1,N,3) cloud at a time as the reference
+            # does: torch.mean over a (nb,N,3) batch picks a different reduction order for some nb, which moved the centre by
+            # an ulp and made the result depend on how the poses were sharded (found by the two-rank test)
+            centers = torch.cat([torch.mean(clouds[k:k + 1], dim=1) for k in range(nb)], dim=0).contiguous()
             keep = hip_ops.masks_to_tensor(np.tile(uniq, nb), dev)
             cloud_of = torch.arange(nb, dtype=torch.int32, device=dev).repeat_interleave(nu).contiguous()
             logits = model.coalition_logits(clouds, centers, rid.reshape(1, -1).expand(nb, -1).contiguous(), keep,

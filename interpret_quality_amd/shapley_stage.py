@@ -36,7 +36,9 @@ def save_fps(args, loader=None):
     loader = loader if loader is not None else data_loader(args)
     rows = [farthest_point_sample(data.to(args.device), args.num_regions).cpu().numpy() for data, _ in loader]
     out = np.concatenate(rows)
-    np.save(fps_index_path(args), out)
+    tmp = fps_index_path(args) + ".tmp.npy"
+    np.save(tmp, out)
+    os.replace(tmp, fps_index_path(args))  # never a half-written file under its final name
     return out
 
 
@@ -140,8 +142,9 @@ def test(args):
     """final_shapley_value.py:159-174."""
     model = load_model(args)
     folder_name_list = get_folder_name_list(args)
-    if not os.path.exists(fps_index_path(args)):
+    if iqdist.rank() == 0 and not os.path.exists(fps_index_path(args)):
         save_fps(args)  # the reference runs final_save_fps.py by hand before exp_shapley.sh
+    iqdist.barrier()    # the other ranks read the file below
     shap_sampling(model, data_loader(args), args, folder_name_list)
 
 

@@ -277,31 +277,45 @@ def test_full_size_shapley_properties(model, oracle, pointnet_sd):
     assert np.abs(got / 3 - want).max() < RTOL * max(np.abs(want).max(), 1e-3) + 1e-6
 
 
-def test_two_rank_sweep_writes_the_same_artefacts_as_one_process(tmp_path, monkeypatch):
-    """The N > 1 driver path end to end on the HIP kernels: stage 1 + the scale sweep of one cloud with 2 ranks
-    (torch.distributed.run, IQ_REHEARSAL=1: both ranks on cuda:0, gloo instead of RCCL) against a single process.
-    Shards: 100 permutations -> 50 + 50 (stage 1), 30 poses -> 15 + 15 (sweep); rank 0 writes."""
+def test_two_rank_pipelines_write_the_same_artefacts_as_one_process(tmp_path, monkeypatch):
+    """The N > 1 driver path end to end on the HIP kernels: stage 1, the rotation sweep and the whole interaction pipeline of
+    one cloud with 2 ranks (torch.distributed.run, IQ_REHEARSAL=1: both ranks on cuda:0, gloo instead of RCCL) against a
+    single process.  Shards: 100 permutations -> 50 + 50, 216 poses -> 108 + 108, 4 pairs -> 2 + 2; rank 0 writes.
+    (An earlier version of this test caught two races: every rank creating `checkpoints/`, and every rank writing the
+    FPS index file while another was already reading it.)"""
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--model", "pointnet", "--dataset", "modelnet10", "--synthetic", "--num_clouds", "1"]
     env = dict(os.environ, PYTHONPATH=repo, IQ_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     root = "checkpoints/exp_MODEL_pointnet_DATA_modelnet10_POINTNUM_1024_REGIONNUM_32_shapley_test/synthetic_00/"
+    stages = (("final_shapley_value.py", ["--num_samples_save", "100"]), ("final_rotate_center_enum_all.py", []),
+              ("final_gen_pair.py", ["--num_pairs_random", "4", "--num_save_context_max", "3"]),
+              ("final_point_binary_interaction_logits.py", []), ("final_cal_interactions.py", []))
     results = {}
     for tag, launcher in (("one", [sys.executable]),
                           ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                                    "--master-addr", "127.0.0.1", "--master-port", "29573"])):
         work = tmp_path / tag
         work.mkdir()
-        for script, extra in (("final_shapley_value.py", ["--num_samples_save", "100"]), ("final_scale_center_enum_all.py", [])):
-            r = subprocess.run(launcher + [os.path.join(repo, script)] + common + extra, cwd=str(work), env=env,
+        for k, (script, extra) in enumerate(stages):
+            cmd = list(launcher)
+            if tag == "two":
+                cmd[cmd.index("29573")] = str(29573 + k)       # a fresh rendezvous port per launch
+            r = subprocess.run(cmd + [os.path.join(repo, script)] + common + extra, cwd=str(work), env=env,
                                capture_output=True, text=True, timeout=600)
-            assert r.returncode == 0, r.stderr[-2000:]
+            assert r.returncode == 0, (script, r.stderr[-3000:])
+        inter = work / root / "interaction_seed1"
         results[tag] = {
             "sv": np.load(str(work / root / "region_sv_all.npy")),
-            "phi": np.load(str(work / root / "scale_all" / "region_shapley_value.npy")),
-            "logits": torch.load(str(work / root / "scale_all" / "all_logits.pt"), map_location="cpu"),
+            "phi": np.load(str(work / root / "rotate_all" / "region_shapley_value.npy")),
+            "logits": torch.load(str(work / root / "rotate_all" / "all_logits.pt"), map_location="cpu"),
+            "pairs": np.load(str(inter / "region_pair_list.npy")),
+            "inter_logits": torch.load(str(inter / "normal" / "ratio50_all_logits.pt"), map_location="cpu"),
+            "inter": np.load(str(inter / "rotate_adv" / "ratio50_pred_interaction.npy")),
         }
-    assert np.array_equal(results["one"]["sv"], results["two"]["sv"])          # float64 accumulation in permutation order
-    assert np.array_equal(results["one"]["phi"], results["two"]["phi"])
-    assert torch.equal(results["one"]["logits"], results["two"]["logits"])
+    one, two = results["one"], results["two"]
+    assert np.array_equal(one["sv"], two["sv"])          # float64 accumulation in permutation order
+    assert np.array_equal(one["phi"], two["phi"]) and torch.equal(one["logits"], two["logits"])
+    assert np.array_equal(one["pairs"], two["pairs"]) and torch.equal(one["inter_logits"], two["inter_logits"])
+    assert np.array_equal(one["inter"], two["inter"]) and one["inter"].shape[0] == 4
