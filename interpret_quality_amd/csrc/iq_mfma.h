@@ -84,8 +84,8 @@ namespace iq {
 // known on the device (ragged batches); M is then the upper bound the grid is sized for.
 int launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,
                   hipStream_t st, const int32_t* m_dev = nullptr);
-// Same layer for few rows and a very long K: K is split over workgroups, partial sums pass through `scratch`
-// (up to 16 x M x cout floats are used if available) and are added in a fixed order.
+// Same layer for few rows and a very long K: K is split over workgroups in slices of 512 (independent of M), partial
+// sums pass through `scratch` (cin/512 x M x cout floats) and are added in a fixed order.
 int launch_linear_splitk(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu, float* scratch,
                          size_t scratch_floats, hipStream_t st);
 // Dense layer fused with the first stage of a pooling layer: partial (ceil(M/32), 2, cout) receives, per 32-row tile,

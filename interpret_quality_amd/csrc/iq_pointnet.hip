@@ -792,13 +792,13 @@ int iq::launch_linear_splitk(const float* A, int lda, const iq_dense_layer& L, f
     if (M == 0) return IQ_OK;
     IQ_REQUIRE(L.w && L.b && L.cin % 8 == 0 && L.cout >= 1, "dense layer: bad descriptor (cin=%d cout=%d)", L.cin, L.cout);
     const int ntiles = (L.cout + 31) / 32, KB = L.cin / 8;
-    const int wgs = ((M + 127) / 128) * ((ntiles + 3) / 4);
-    int splits = wgs >= 512 ? 1 : (1024 + wgs - 1) / wgs;
-    splits = std::min(splits, std::max(1, KB / 64));                                        // >= 512 k per split
-    while (splits > 1 && (size_t)splits * M * L.cout > scratch_floats) --splits;
-    if (splits <= 1 || ntiles < 4 || !scratch) return launch_linear(A, lda, L, out, ldo, M, relu, st);
-    const int kbs = (KB + splits - 1) / splits;
-    splits = (KB + kbs - 1) / kbs;
+    // 512 k per split, whatever M is: the summation order must not depend on how many rows share the launch, or a
+    // coalition's logits would change with the batch it travels in (found by the two-rank artefact comparison)
+    const int kbs = 64;
+    const int splits = (KB + kbs - 1) / kbs;
+    if (splits <= 1 || ntiles < 4) return launch_linear(A, lda, L, out, ldo, M, relu, st);
+    IQ_REQUIRE(scratch && (size_t)splits * M * L.cout <= scratch_floats, "split-K dense layer: scratch %zu floats < %zu",
+               scratch_floats, (size_t)splits * M * L.cout);
     dim3 grid((M + 127) / 128, (ntiles + 3) / 4, splits);
     hipLaunchKernelGGL((pn_linear_kernel<2, 2, 2, 2>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, scratch, L.cout, M, L.cin,
                        L.cout, 0, nullptr, kbs);
