@@ -252,3 +252,36 @@ def test_abi_error_reporting_of_the_coalition_and_enumeration_entry_points():
         hip_ops.smoothness_enum(torch.zeros((64, 3), device=d), torch.zeros(64, dtype=torch.int32, device=d), 4, "roundness", "inc")
     with pytest.raises(_lib.IqError):
         hip_ops.linear(torch.zeros((4, 12), device=d), hip_ops.PackedLinear(np.zeros((8, 16), np.float32), np.zeros(8, np.float32), d))
+
+
+@pytest.mark.parametrize("name", ["pointnet", "pointnet2", "dgcnn", "gcnn", "pointconv"])
+def test_a_coalitions_logits_do_not_depend_on_the_batch_it_travels_in(name):
+    """Bitwise: logits of coalitions 10..24 evaluated alone equal rows 10..24 of the 40-coalition launch.  (Sharding over
+    ranks and the drivers' batching rely on this; a row-count-dependent split-K once broke it for PointConv.)"""
+    import argparse
+    from interpret_quality_amd import final_common
+    from interpret_quality_amd.dgcnn import DGCNN_cls, GCNN_cls
+    from interpret_quality_amd.pointconv import PointConvDensityClsSsg
+    from interpret_quality_amd.pointnet2 import PointNet2ClsMsg
+    cls, sd = {"pointnet": (PointNetCls, synth.pointnet_state_dict), "pointnet2": (PointNet2ClsMsg, synth.pointnet2_state_dict),
+               "dgcnn": (DGCNN_cls, synth.dgcnn_state_dict), "gcnn": (GCNN_cls, synth.dgcnn_state_dict),
+               "pointconv": (PointConvDensityClsSsg, synth.pointconv_state_dict)}[name]
+    m = cls(argparse.Namespace(dataset="modelnet10", k=20) if "cnn" in name else None)
+    m.load_state_dict(synth.to_torch(sd(0)))
+    m = m.to(dev()).eval()
+    d = dev()
+    pts, _ = synth.make_cloud(11)
+    cloud = torch.from_numpy(pts).unsqueeze(0).to(d)
+    rid = hip_ops.region_assign(cloud[0].contiguous(), hip_ops.fps(cloud, 32)[0].contiguous()).reshape(1, -1)
+    center = cloud.mean(dim=1)
+    rng = np.random.default_rng(4)
+    keep = [int(x) for x in rng.integers(0, 1 << 32, size=40)]
+
+    def logits(ks):
+        kt = hip_ops.masks_to_tensor(ks, d)
+        if hasattr(m, "coalition_logits"):
+            return m.coalition_logits(cloud, center, rid, kt, None, num_regions=32)
+        return m.forward_points(hip_ops.mask_coalitions(cloud[0], rid[0].contiguous(), kt, center[0].contiguous()))
+    full = logits(keep)
+    assert torch.equal(logits(keep[10:25]), full[10:25])
+    assert torch.equal(logits(keep[39:]), full[39:])
