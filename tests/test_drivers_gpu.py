@@ -338,3 +338,26 @@ def test_bench_n2_rehearsal_prints_one_valid_json_line(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["unit"] == "coalitions/s" and d["value"] > 0 and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+
+
+def test_checkpoint_file_in_the_references_layout_is_loaded(tmp_path, monkeypatch):
+    """tools/final_util.py:236-262: a `.t7` saved from an nn.DataParallel model (keys prefixed with `module.`) at the
+    reference's path is what the drivers load; --synthetic only stands in when the file is absent."""
+    from interpret_quality_amd import final_util
+    monkeypatch.chdir(tmp_path)
+    args = argparse.Namespace(model="pointnet", dataset="modelnet10", synthetic=True, device=dev())
+    final_util.set_model_args(args)
+    os.makedirs(os.path.dirname(args.model_path))
+    sd = synth.to_torch(synth.pointnet_state_dict(1))                      # NOT the seed-0 stand-in
+    torch.save({"module." + k: v for k, v in sd.items()}, args.model_path)
+    from_file = final_util.load_model(args)
+    x = torch.from_numpy(synth.make_cloud(0)[0]).unsqueeze(0).permute(0, 2, 1).contiguous().to(dev())
+    want = PointNetCls(None)
+    want.load_state_dict(sd)
+    assert torch.equal(from_file(x)[0], want.to(dev()).eval()(x)[0])
+    os.remove(args.model_path)
+    stand_in = final_util.load_model(args)                                  # file gone: the seed-0 stand-in
+    assert not torch.equal(stand_in(x)[0], from_file(x)[0])
+    args.synthetic = False
+    with pytest.raises(FileNotFoundError):
+        final_util.load_model(args)
