@@ -361,3 +361,24 @@ def test_checkpoint_file_in_the_references_layout_is_loaded(tmp_path, monkeypatc
     args.synthetic = False
     with pytest.raises(FileNotFoundError):
         final_util.load_model(args)
+
+
+def test_stage1_on_a_real_format_dataset_tree_without_the_synthetic_flag(tmp_path, monkeypatch):
+    """exp_shapley.sh stage 1 exactly as a user of the reference would run it: ShapeNet-format scans under data/,
+    misc/ lists, a .t7 checkpoint - no --synthetic.  Folder names, FPS index file and artefacts per cloud."""
+    from interpret_quality_amd import final_util
+    synth.write_dataset_tree(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    args = argparse.Namespace(model="pointnet", dataset="shapenet")
+    final_util.set_model_args(args)
+    os.makedirs(os.path.dirname(args.model_path))
+    torch.save({"module." + k: v for k, v in synth.to_torch(synth.pointnet_state_dict(0)).items()}, args.model_path)
+    shapley_stage.main(["--model", "pointnet", "--dataset", "shapenet", "--num_samples_save", "20", "--num_regions", "8"])
+    fps = np.load("fps_shapenet_1024_8_index_final30.npy")
+    assert fps.shape == (3, 8) and fps.dtype == np.int64 and (fps[:, 0] == 0).all()
+    root = "checkpoints/exp_MODEL_pointnet_DATA_shapenet_POINTNUM_1024_REGIONNUM_8_shapley_test/"
+    for name in ("Bag_aaaa0001", "Mug_bbbb0002", "Rocket_cccc0003"):          # classname_uuid, tools/final_util.py:275-276
+        sv = np.load(root + name + "/region_sv_all.npy")
+        nf = float(np.load(root + name + "/norm_factor.npy"))
+        assert sv.shape == (20, 8) and np.abs(sv.sum(1) - nf).max() < 2e-4 * max(1.0, abs(nf))
+        assert np.load(root + name + "/region_id.npy").shape == (1024,)
