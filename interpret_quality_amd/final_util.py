@@ -40,6 +40,35 @@ def model_path(dataset, model):
     return "checkpoints/exp_MODEL_%s_DATA_%s_POINTNUM_1024_clean/models/model_best.t7" % (model, dataset)
 
 
+# the reference's module-level names (tools/final_util.py:52-66)
+for _ds in ("modelnet10", "shapenet"):
+    for _m in ("pointnet", "pointnet2", "pointconv", "dgcnn", "gcnn", "gcnn_adv"):
+        globals()["MODEL_PATH_%s_%s" % ("MODELNET" if _ds == "modelnet10" else "SHAPENET", _m.upper())] = model_path(_ds, _m)
+del _ds, _m
+
+
+def square_distance_np(x):
+    """tools/final_util.py:122-132 (host, NumPy; used on the 32 region centres)."""
+    xx = np.sum(x ** 2, axis=1, keepdims=True)
+    return xx + xx.T - 2 * np.matmul(x, x.T)
+
+
+def square_distance(src, dst):
+    """tools/final_util.py:134-147: (B,N,3), (B,M,3) -> (B,N,M) expanded-form squared distances (torch; the region
+    assignment itself runs in iq_region_assign with the same expression)."""
+    b, n, _ = src.shape
+    m = dst.shape[1]
+    dist = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    dist += torch.sum(src ** 2, -1).view(b, n, 1)
+    dist += torch.sum(dst ** 2, -1).view(b, 1, m)
+    return dist
+
+
+def ball_query(x, r):
+    """tools/final_util.py:150-160: boolean neighbour matrix of the region centres."""
+    return square_distance_np(x) < r ** 2
+
+
 def exp_folder(args):
     """Artefact root shared by every stage (final_shapley_value.py:194-195)."""
     return "./checkpoints/exp_MODEL_%s_DATA_%s_POINTNUM_%d_REGIONNUM_%d_shapley_test/" % (

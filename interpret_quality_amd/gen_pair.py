@@ -15,22 +15,12 @@ import torch
 from scipy.special import comb
 
 from . import final_common
-from .final_util import (BALL_QUERY_COEF, cal_rank, get_folder_name_list, load_model, mkdir)
+from .final_util import (BALL_QUERY_COEF, ball_query, cal_rank, get_folder_name_list, load_model, mkdir,
+                         square_distance_np)  # noqa: F401
 from .interaction import DEFAULT_RATIOS
 from .pose_sweep import rotate_xyz, translate_pc
 from . import dist as iqdist
 from .shapley_stage import data_loader, finish_args
-
-
-def square_distance_np(x):
-    """tools/final_util.py:122-132."""
-    xx = np.sum(x ** 2, axis=1, keepdims=True)
-    return xx + xx.T - 2 * np.matmul(x, x.T)
-
-
-def ball_query(x, r):
-    """tools/final_util.py:150-160: boolean neighbour matrix of the region centres."""
-    return square_distance_np(x) < r ** 2
 
 
 def gen_context(region_pair_list, save_path, args):

@@ -195,3 +195,38 @@ def test_smoothness_epoch_count_rule():
         return max(1, min(epoch, int(np.asarray(stop).max()) + 1))
     assert n_epochs([0, 0, 0]) == 1 and n_epochs([3, 1, 2]) == 4 and n_epochs([50, 2]) == 50 and n_epochs([-1, -1]) == 1
     assert smoothness.EPOCH == 50 and smoothness.ENUM_STEP == 0.05 and smoothness.STEP == 1e-3
+
+
+def test_reference_import_paths_resolve_to_this_build():
+    """`from tools.final_common import ...`, `from tools.final_util import ...` and the functions the reference defines at
+    module level in its stage scripts are importable under the same names (Python API)."""
+    import importlib
+    surface = {
+        "tools.final_common": "get_reward cal_reward mask_data_batch shap_sampling_all_regions_batch test",
+        "tools.final_util": "NUM_POINTS NUM_REGIONS NUM_SAMPLES_SAVE NUM_SAMPLES K_FOR_DGCNN DATA_MODELNET_SHAPLEY_TEST "
+                            "DATA_SHAPENET_SHAPLEY_TEST MODELNET_INTER_SELECTED_SAMPLE SHAPENET_INTER_SELECTED_SAMPLE SHAPENET_CLASS "
+                            "SHAPENET_ID2CAT SHAPENET_CAT2ID MODEL_PATH_MODELNET_POINTNET MODEL_PATH_SHAPENET_GCNN_ADV BALL_QUERY_COEF "
+                            "IOStream cal_rank mkdir set_random square_distance_np square_distance ball_query set_model_args "
+                            "set_shapley_batch_size set_interaction_batch_size load_model get_folder_name_list",
+        "final_shapley_value": "cal_region_id cal_norm_factor generate_all_orders mask_data save_shapley shap_sampling test main",
+        "final_trans_center_enum_all": "translate_pc generate_trans_vector print_trans_info save_trans_info",
+        "final_rotate_center_enum_all": "rotate_xyz generate_rotate_angle print_rotate_info save_rotate_info",
+        "final_scale_center_enum_all": "scale_pc generate_scale print_scale_info save_scale_info",
+        "final_point_binary_interaction_logits": "compute_order_interaction_logits save_logits_all_orders save_logits",
+        "final_cal_interactions": "compute_order_interaction cal_interaction_all_orders cal_interaction",
+        "final_gen_pair": "gen_context save_context gen_pred_label save_pred_label gen_pair_single_region save_pair_single_region "
+                          "check_adv_success gen_pair_random save_pair_random",
+        "final_save_fps": "farthest_point_sample save_fps",
+        "final_data_shapley": "ModelNet_Loader_Shapley_test ShapeNetDataset_Shapley_test farthest_point_sample_np make_dataset_modelnet10",
+    }
+    for mod, names in surface.items():
+        m = importlib.import_module(mod)
+        missing = [n for n in names.split() if not hasattr(m, n)]
+        assert not missing, (mod, missing)
+    import tools.final_util as fu
+    assert fu.MODEL_PATH_MODELNET_POINTNET == "checkpoints/exp_MODEL_pointnet_DATA_modelnet10_POINTNUM_1024_clean/models/model_best.t7"
+    x = np.random.default_rng(0).standard_normal((5, 3))
+    d = fu.square_distance_np(x)
+    assert np.allclose(d, ((x[:, None] - x[None]) ** 2).sum(-1)) and fu.ball_query(x, 10.0).all()
+    t = torch.from_numpy(x).float().unsqueeze(0)
+    assert torch.allclose(fu.square_distance(t, t)[0], torch.from_numpy(d).float(), atol=1e-5)
