@@ -79,7 +79,7 @@ __device__ __forceinline__ void mfma_ntile(const float* abase, const float* wcur
 }
 
 namespace iq {
-// Batched dense layer out = act(A W^T + b) on packed weights (iq_pointnet.hip).
+// Batched dense layer out = act(A W^T + b) on packed weights (iq_linear.hip).
 // relu: 0 = none, 1 = ReLU, 2 = LeakyReLU(0.2).  m_dev (optional, device): the live row count when it is only
 // known on the device (ragged batches); M is then the upper bound the grid is sized for.
 int launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,

@@ -475,257 +475,6 @@ __global__ __launch_bounds__(kThreads) void pn_stn_gather_kernel(const float* __
     reinterpret_cast<f32x4*>(out)[(size_t)item * (kFeat / 4) + threadIdx.x] = m;
 }
 
-// ---- batched dense layer  out = act(A W^T + b)  --------------------------------------------
-// No LDS: the fp32 MFMA is slow enough (64 cycles) that both operands stream straight from
-// L1/L2 into registers, one K-block ahead.  Wave tile (MT*32) x (NT*32); 4 waves as WM x WN.
-template <int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __restrict__ A, int lda,
-                                                             const float* __restrict__ wp,
-                                                             const float* __restrict__ bias,
-                                                             float* __restrict__ out, int ldo, int M, int K,
-                                                             int Nout, int relu, const int32_t* __restrict__ m_dev,
-                                                             int kb_per_split) {
-    if (m_dev) M = min(M, *m_dev);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int m0 = (blockIdx.x * WM + wm) * MT * 32;
-    const int nt0 = (blockIdx.y * WN + wn) * NT;
-    const int KBT = K >> 3;                               // k-blocks of the whole layer (weight image stride)
-    // split-K (kb_per_split > 0): workgroup z accumulates k-blocks [z kb_per_split, ...) and stores the raw partial
-    // sums to out + z M ldo; bias and activation are applied by splitk_reduce_kernel
-    const bool split = kb_per_split > 0;
-    const int kb0 = split ? blockIdx.z * kb_per_split : 0;
-    const int KB = split ? min(kb_per_split, KBT - kb0) : KBT;
-    const int ntiles = (Nout + 31) >> 5;
-    if (m0 >= M || nt0 >= ntiles) return;
-    if (split) out += (size_t)blockIdx.z * M * ldo;
-
-    const float* ap[MT];
-    const float* bp[NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int row = min(m0 + i * 32 + (lane & 31), M - 1);
-        ap[i] = A + (size_t)row * lda + 4 * (lane >> 5) + 8 * kb0;
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int nt = min(nt0 + j, ntiles - 1);
-        bp[j] = wp + (((size_t)nt * KBT + kb0) * 64 + lane) * 4;
-    }
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x16){0};
-
-    f32x4 av[MT], bv[NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) av[i] = *reinterpret_cast<const f32x4*>(ap[i]);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(bp[j]);
-    for (int kb = 0; kb < KB; ++kb) {
-        f32x4 an[MT], bn[NT];
-        const int kn = min(kb + 1, KB - 1);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) an[i] = *reinterpret_cast<const f32x4*>(ap[i] + 8 * kn);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bn[j] = *reinterpret_cast<const f32x4*>(bp[j] + (size_t)kn * 256);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = mfma4(av[i], bv[j], acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) av[i] = an[i];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bv[j] = bn[j];
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int col = (nt0 + j) * 32 + (lane & 31);
-        if (nt0 + j >= ntiles || col >= Nout) continue;
-        const float b = split ? 0.f : bias[col];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + i * 32 + c_row(r, lane);
-                if (row < M) {
-                    float v = acc[i][j][r] + b;
-                    if (split) { out[(size_t)row * ldo + col] = acc[i][j][r]; continue; }
-                    if (relu == 1) v = fmaxf(v, 0.f);
-                    else if (relu == 2) v = v > 0.f ? v : 0.2f * v;  // LeakyReLU(0.2), models/dgcnn.py:66-80
-                    out[(size_t)row * ldo + col] = v;
-                }
-            }
-        }
-    }
-}
-
-// Large-M variant: the A operand goes through LDS.  In pn_linear_kernel every A-fragment load touches 32 cache lines
-// (32 rows x 16 B) and is repeated by the wave beside it, which keeps the L1 address path - not the MFMA - busy
-// (measured 58 % of the fp32 MFMA peak on 512 -> 1024).  Here the workgroup copies a 128-row x 32-k chunk with
-// full-line coalesced loads (8 lanes per 128 B row segment), double-buffered, and the four waves (2 x 2, wave tile
-// 64 x NT*32) read their fragments from LDS (row stride 36 floats: conflict-free ds_read_b128); B fragments still
-// stream from the packed image, prefetched two k-blocks ahead.  Same MFMA order over k as pn_linear_kernel, so the
-// results are bit-identical.  Needs K % 32 == 0.
-// POOL: instead of the activations, every 32-row tile writes its column-wise maximum and row-weighted sum over the
-// rows with weight > 0 (out = (ceil(M/32), 2, Nout)): the input of a pooling layer without the round trip of the
-// (M, Nout) activations through HBM.
-template <int NT, bool POOL>
-__global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* __restrict__ A, int lda,
-                                                                  const float* __restrict__ wp,
-                                                                  const float* __restrict__ bias, float* __restrict__ out,
-                                                                  int ldo, int M, int K, int Nout, int relu,
-                                                                  const int32_t* __restrict__ m_dev,
-                                                                  const float* __restrict__ row_w) {
-    constexpr int KC = 32, LDA = KC + 4;
-    __shared__ __attribute__((aligned(16))) float As[2][128 * LDA];
-    if (m_dev) M = min(M, *m_dev);
-    const int m0 = blockIdx.x * 128;
-    if (m0 >= M) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int KB = K >> 3, nchunks = K / KC;
-    const int ntiles = (Nout + 31) >> 5;
-    const int nt0 = (blockIdx.y * 2 + wn) * NT;
-
-    // chunk copy: 128 rows x 8 float4; thread t owns (row, c4) = (e >> 3, e & 7) for e = t + 256 i
-    const float* arow[4];
-    int soff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = tid + kThreads * i, row = e >> 3, c4 = e & 7;
-        arow[i] = A + (size_t)min(m0 + row, M - 1) * lda + c4 * 4;
-        soff[i] = row * LDA + c4 * 4;
-    }
-    f32x4 stage[4];
-    auto load_chunk = [&](int kc) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) stage[i] = *reinterpret_cast<const f32x4*>(arow[i] + kc * KC);
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&As[buf][soff[i]]) = stage[i];
-    };
-
-    const float* bp[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bp[j] = wp + ((size_t)min(nt0 + j, ntiles - 1) * KB * 64 + lane) * 4;
-    // B fragments in a 2-deep register ring (k-blocks kb, kb + 1); the slot just consumed is refilled with kb + 2, i.e.
-    // 2 x 8 NT MFMAs (>= 4096 cycles) ahead of its use.  sched_group_barrier pins that order: left alone, the
-    // scheduler sinks the loads next to their uses and the MFMAs wait on L2.
-    f32x4 ring[2][NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        ring[0][j] = *reinterpret_cast<const f32x4*>(bp[j]);
-        ring[1][j] = *reinterpret_cast<const f32x4*>(bp[j] + (size_t)min(1, KB - 1) * 256);
-    }
-    f32x16 acc[2][NT];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x16){0};
-
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-    const int aoff = (wm * 64 + (lane & 31)) * LDA + 4 * (lane >> 5);
-    for (int kc = 0; kc < nchunks; ++kc) {
-        const float* as = As[kc & 1] + aoff;
-        f32x4 a0n = *reinterpret_cast<const f32x4*>(as), a1n = *reinterpret_cast<const f32x4*>(as + 32 * LDA);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-            const int kb = kc * 4 + k4;
-            const f32x4 a0 = a0n, a1 = a1n;
-            if (k4 < 3) {
-                a0n = *reinterpret_cast<const f32x4*>(as + 8 * (k4 + 1));
-                a1n = *reinterpret_cast<const f32x4*>(as + 32 * LDA + 8 * (k4 + 1));
-            }
-            const size_t kn = (size_t)min(kb + 2, KB - 1) * 256;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const f32x4 bk = ring[k4 & 1][j];
-                acc[0][j] = mfma4(a0, bk, acc[0][j]);
-                acc[1][j] = mfma4(a1, bk, acc[1][j]);
-                ring[k4 & 1][j] = *reinterpret_cast<const f32x4*>(bp[j] + kn);
-            }
-            if (k4 < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // next chunk's A rows: issued behind the first k-block so that no MFMA of this chunk has to wait for them
-            // (memory returns in order: a wait on an older B fragment never covers these)
-            if (k4 == 0 && kc + 1 < nchunks) {
-                load_chunk(kc + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (kc + 1 < nchunks) store_chunk((kc + 1) & 1);
-        __syncthreads();
-    }
-    if (POOL) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int trow = m0 + wm * 64 + i * 32;  // first row of this 32-row tile
-            if (trow >= M) continue;
-            float w[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = trow + c_row(r, lane);
-                w[r] = row < M ? row_w[row] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int col = (nt0 + j) * 32 + (lane & 31);
-                const bool ok = nt0 + j < ntiles && col < Nout;
-                const float b = ok ? bias[col] : 0.f;
-                float mx = -INFINITY, sm = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r] + b;
-                    if (relu == 1) v = fmaxf(v, 0.f);
-                    else if (relu == 2) v = v > 0.f ? v : 0.2f * v;
-                    if (w[r] > 0.f) {
-                        mx = fmaxf(mx, v);
-                        sm += w[r] * v;
-                    }
-                }
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                sm += __shfl_xor(sm, 32);
-                if (ok && lane < 32) {
-                    float* o = out + (size_t)(trow >> 5) * 2 * Nout;
-                    o[col] = mx;
-                    o[Nout + col] = sm;
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int col = (nt0 + j) * 32 + (lane & 31);
-        if (nt0 + j >= ntiles || col >= Nout) continue;
-        const float b = bias[col];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + c_row(r, lane);
-                if (row < M) {
-                    float v = acc[i][j][r] + b;
-                    if (relu == 1) v = fmaxf(v, 0.f);
-                    else if (relu == 2) v = v > 0.f ? v : 0.2f * v;
-                    out[(size_t)row * ldo + col] = v;
-                }
-            }
-        }
-    }
-}
-
 template <int MODE>
 void launch_chain(const ChainArgs& a, hipStream_t st) {
     const size_t extra_lds = (size_t)iq::tuning(iq::kTuneExtraLds);  // experiment: lower the occupancy
@@ -738,95 +487,6 @@ void launch_chain(const ChainArgs& a, hipStream_t st) {
 }
 
 }  // namespace
-
-int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,
-                      hipStream_t st, const int32_t* m_dev) {
-    if (M == 0) return IQ_OK;
-    IQ_REQUIRE(L.w && L.b && L.cin % 8 == 0 && L.cout >= 1, "dense layer: bad descriptor (cin=%d cout=%d)", L.cin, L.cout);
-    const int ntiles = (L.cout + 31) / 32;
-    if (M >= 2048 && ntiles >= 4 && L.cin % 32 == 0 && iq::tuning(iq::kTuneNoLdsGemm) == 0) {
-        if (ntiles >= 16 && (long long)((M + 127) / 128) * ((ntiles + 7) / 8) >= 2048) {
-            dim3 grid((M + 127) / 128, (ntiles + 7) / 8);
-            hipLaunchKernelGGL((pn_gemm_lds_kernel<4, false>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
-                               L.cout, relu, m_dev, nullptr);
-        } else {
-            dim3 grid((M + 127) / 128, (ntiles + 3) / 4);
-            hipLaunchKernelGGL((pn_gemm_lds_kernel<2, false>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
-                               L.cout, relu, m_dev, nullptr);
-        }
-        return iq::check_launch("pn_gemm_lds_kernel");
-    }
-    if (ntiles >= 4) {
-        dim3 grid((M + 127) / 128, (ntiles + 3) / 4);
-        hipLaunchKernelGGL((pn_linear_kernel<2, 2, 2, 2>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M,
-                           L.cin, L.cout, relu, m_dev, 0);
-    } else {
-        dim3 grid((M + 255) / 256, ntiles);
-        hipLaunchKernelGGL((pn_linear_kernel<2, 1, 4, 1>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M,
-                           L.cin, L.cout, relu, m_dev, 0);
-    }
-    return iq::check_launch("pn_linear_kernel");
-}
-
-namespace {
-// out[row][col] = act(bias[col] + sum_z partial[z][row][col]), z ascending: fixed summation order
-__global__ void splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias, float* __restrict__ out,
-                                     int ldo, int M, int N, int splits, int relu) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= M * N) return;
-    const int row = t / N, col = t - row * N;
-    float v = 0.f;
-    for (int z = 0; z < splits; ++z) v += partial[((size_t)z * M + row) * N + col];
-    v += bias[col];
-    if (relu == 1) v = fmaxf(v, 0.f);
-    else if (relu == 2) v = v > 0.f ? v : 0.2f * v;
-    out[(size_t)row * ldo + col] = v;
-}
-}  // namespace
-
-// Few rows, very long K (PointConv's 16384 -> 1024 layer on B rows): a plain launch has ceil(M/128) x cout/128 workgroups -
-// 48 for 660 rows - each walking all of K.  Split K over blockIdx.z until the grid fills the chip; partial sums go
-// through `scratch` (splits x M x cout floats) and are added in a fixed order.
-int iq::launch_linear_splitk(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,
-                             float* scratch, size_t scratch_floats, hipStream_t st) {
-    if (M == 0) return IQ_OK;
-    IQ_REQUIRE(L.w && L.b && L.cin % 8 == 0 && L.cout >= 1, "dense layer: bad descriptor (cin=%d cout=%d)", L.cin, L.cout);
-    const int ntiles = (L.cout + 31) / 32, KB = L.cin / 8;
-    // 512 k per split, whatever M is: the summation order must not depend on how many rows share the launch, or a
-    // coalition's logits would change with the batch it travels in (found by the two-rank artefact comparison)
-    const int kbs = 64;
-    const int splits = (KB + kbs - 1) / kbs;
-    if (splits <= 1 || ntiles < 4) return launch_linear(A, lda, L, out, ldo, M, relu, st);
-    IQ_REQUIRE(scratch && (size_t)splits * M * L.cout <= scratch_floats, "split-K dense layer: scratch %zu floats < %zu",
-               scratch_floats, (size_t)splits * M * L.cout);
-    dim3 grid((M + 127) / 128, (ntiles + 3) / 4, splits);
-    hipLaunchKernelGGL((pn_linear_kernel<2, 2, 2, 2>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, scratch, L.cout, M, L.cin,
-                       L.cout, 0, nullptr, kbs);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * L.cout + 255) / 256)), dim3(256), 0, st, scratch, L.b,
-                       out, ldo, M, L.cout, splits, relu);
-    return iq::check_launch("pn_linear_kernel<split-K>");
-}
-
-int iq::launch_linear_pool(const float* A, int lda, const iq_dense_layer& L, float* partial, int M, int relu,
-                           const float* row_w, hipStream_t st, const int32_t* m_dev) {
-    if (M == 0) return IQ_OK;
-    IQ_REQUIRE(L.w && L.b && row_w && partial, "dense layer + pool: null pointer");
-    const int ntiles = (L.cout + 31) / 32;
-    if (L.cin % 32 != 0 || ntiles < 8 || L.cout % 32 != 0)
-        return iq::fail(IQ_EUNSUPPORTED, "dense layer + pool: cin=%d cout=%d", L.cin, L.cout);
-    dim3 grid((M + 127) / 128, (ntiles + 7) / 8);
-    hipLaunchKernelGGL((pn_gemm_lds_kernel<4, true>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, partial, 0, M, L.cin, L.cout,
-                       relu, m_dev, row_w);
-    return iq::check_launch("pn_gemm_lds_kernel<pool>");
-}
-
-extern "C" int iq_linear(const float* A, int lda, const iq_dense_layer* L, float* out, int ldo, int M, int act,
-                         iq_stream_t stream) {
-    IQ_REQUIRE(A && L && out, "iq_linear: null pointer");
-    IQ_REQUIRE(M >= 0 && act >= 0 && act <= 2 && lda >= L->cin && ldo >= L->cout, "iq_linear: M=%d act=%d lda=%d ldo=%d", M,
-               act, lda, ldo);
-    return iq::launch_linear(A, lda, *L, out, ldo, M, act, iq::as_stream(stream));
-}
 
 namespace {
 using iq::launch_linear;
@@ -1028,24 +688,7 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
     return IQ_OK;
 }
 
-// ---- host-side weight packing ---------------------------------------------------------------
-extern "C" int iq_padded_cout(int cout) { return (cout + 31) / 32 * 32; }
-
-extern "C" size_t iq_packed_floats(int cout, int cin) { return (size_t)iq_padded_cout(cout) * cin; }
-
-extern "C" int iq_pack_weight(const float* w, float* out, int cout, int cin) {
-    IQ_REQUIRE(w && out && cout >= 1 && cin >= 8 && cin % 8 == 0, "iq_pack_weight: cout=%d cin=%d", cout, cin);
-    const int KB = cin / 8, ntiles = iq_padded_cout(cout) / 32;
-    for (int nt = 0; nt < ntiles; ++nt)
-        for (int kb = 0; kb < KB; ++kb)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int j = 0; j < 4; ++j) {
-                    const int n = nt * 32 + (lane & 31), k = 8 * kb + 4 * (lane >> 5) + j;
-                    out[(((size_t)nt * KB + kb) * 64 + lane) * 4 + j] = n < cout ? w[(size_t)n * cin + k] : 0.f;
-                }
-    return IQ_OK;
-}
-
+// ---- host-side packing of the feature-STN output layer (generic packing: iq_linear.hip) ------------
 extern "C" int iq_pack_fstn_fc3(const float* w, const float* b, float* out_w, float* out_b, int32_t* perm) {
     IQ_REQUIRE(w && b && out_w && out_b, "iq_pack_fstn_fc3: null pointer");
     // Output element e of the layer must be element e of the packed B image of trans_feat for the
