@@ -285,3 +285,11 @@ def test_a_coalitions_logits_do_not_depend_on_the_batch_it_travels_in(name):
     full = logits(keep)
     assert torch.equal(logits(keep[10:25]), full[10:25])
     assert torch.equal(logits(keep[39:]), full[39:])
+
+
+@pytest.mark.parametrize("n", [100, 1000])
+def test_pointnet_coalitions_on_odd_cloud_sizes(model, oracle_model, n):
+    """N that is not a multiple of the 64-row chunk / 32-row MFMA tile (the reference accepts any N)."""
+    pts, _ = synth.make_cloud(12, num_points=n)
+    rng = np.random.default_rng(n)
+    check_against_oracle(model, oracle_model, pts, rng.integers(0, 16, size=n), 16, [0, 0xffff, 0x00ff, 0x8001, 0x5a5a])
