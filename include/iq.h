@@ -282,7 +282,8 @@ size_t iq_dgcnn_workspace_bytes(int B, int N);
 
 /* Eval-mode DGCNN_cls.forward (models/dgcnn.py:83-120; fixed_graph = 0) or GCNN_cls.forward
  * (:156-194; fixed_graph = 1: one xyz graph for all four EdgeConv layers) on B materialised clouds.
- * xyz (B,N,3) channel-last -> logits (B,10). */
+ * xyz (B,N,3) channel-last -> logits (B,10).  Any 20 <= N <= 32767 (clouds are padded to a multiple of 32 rows
+ * internally with rows no query can select). */
 int iq_dgcnn_forward(const iq_dgcnn_weights* w /*host struct of device pointers*/, const float* xyz,
                      float* logits, void* workspace, size_t workspace_bytes, int B, int N,
                      int fixed_graph, iq_stream_t stream);

@@ -29,12 +29,19 @@ constexpr int kThreads = 256;
 constexpr int kK = 20;  // K_FOR_DGCNN, tools/final_util.py:19
 
 // ---- pad xyz (B,N,3) -> (B,N,8) -------------------------------------------------------------------
-__global__ void pad_xyz_kernel(const float* __restrict__ xyz, float* __restrict__ out, int total) {
+// (B,N,3) -> (B,Np,8), Np = N rounded up to 32; rows N..Np-1 of a cloud are dead (zero; rownorm gives them +inf)
+__global__ void pad_xyz_kernel(const float* __restrict__ xyz, float* __restrict__ out, int B, int N, int Np) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    f32x4 a = {xyz[t * 3], xyz[t * 3 + 1], xyz[t * 3 + 2], 0.f}, z = {0.f, 0.f, 0.f, 0.f};
-    reinterpret_cast<f32x4*>(out)[t * 2] = a;
-    reinterpret_cast<f32x4*>(out)[t * 2 + 1] = z;
+    if (t >= B * Np) return;
+    const int b = t / Np, i = t - b * Np;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a = z;
+    if (i < N) {
+        const float* src = xyz + ((size_t)b * N + i) * 3;
+        a = (f32x4){src[0], src[1], src[2], 0.f};
+    }
+    reinterpret_cast<f32x4*>(out)[(size_t)t * 2] = a;
+    reinterpret_cast<f32x4*>(out)[(size_t)t * 2 + 1] = z;
 }
 
 // ---- ragged layout ---------------------------------------------------------------------------------------------
@@ -48,10 +55,10 @@ struct Ragged {
 
 // dense forward: D_b = N
 __global__ void dg_dense_layout_kernel(int32_t* __restrict__ roff, int32_t* __restrict__ nkept, int32_t* __restrict__ ncopy,
-                                       int32_t* __restrict__ row_cloud, float* __restrict__ row_w, int B, int N) {
+                                       int32_t* __restrict__ row_cloud, float* __restrict__ row_w, int B, int N, int Np) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < B * N) { row_cloud[t] = t / N; if (row_w) row_w[t] = 1.f; }
-    if (t <= B) roff[t] = t * N;
+    if (t < B * Np) { row_cloud[t] = t / Np; if (row_w) row_w[t] = (t % Np) < N ? 1.f : 0.f; }
+    if (t <= B) roff[t] = t * Np;
     if (t < B) { nkept[t] = N; ncopy[t] = 0; }
 }
 
@@ -370,7 +377,7 @@ WsD carve_d(void* base, int B, int N) {
         off = iq::align_up(off + bytes, 256);
         return reinterpret_cast<char*>(base) + o;
     };
-    const size_t r = (size_t)B * N;
+    const size_t r = (size_t)B * ((N + 31) / 32 * 32);
     s.x0 = (float*)take(r * 8 * 4);
     s.xc = (float*)take(r * 512 * 4);
     s.pq = (float*)take(r * 512 * 4);
@@ -423,12 +430,12 @@ extern "C" int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes,
     int32_t* nkept = reinterpret_cast<int32_t*>(take((size_t)B * 4));
     int32_t* ncopy = reinterpret_cast<int32_t*>(take((size_t)B * 4));
     hipLaunchKernelGGL(dg_dense_layout_kernel, dim3((r + 256) / 256), dim3(256), 0, st, roff, nkept, ncopy, row_cloud,
-                       (float*)nullptr, B, N);
+                       (float*)nullptr, B, N, N);
     const Ragged rg{roff, nkept, ncopy, row_cloud, nullptr};
     const float* src = x;
     int ld = C, cpad = C;
     if (C == 3) {
-        hipLaunchKernelGGL(pad_xyz_kernel, dim3((r + 255) / 256), dim3(256), 0, st, x, x0, (int)r);
+        hipLaunchKernelGGL(pad_xyz_kernel, dim3((r + 255) / 256), dim3(256), 0, st, x, x0, B, N, N);
         src = x0; ld = 8; cpad = 8;
     }
     hipLaunchKernelGGL(rownorm_kernel, dim3((r + 63) / 64), dim3(kThreads), 0, st, src, ld, C, xx, rg, B);
@@ -489,7 +496,7 @@ int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, i
 extern "C" int iq_dgcnn_forward(const iq_dgcnn_weights* w, const float* xyz, float* logits, void* workspace,
                                 size_t workspace_bytes, int B, int N, int fixed_graph, iq_stream_t stream) {
     IQ_REQUIRE(w && xyz && logits, "iq_dgcnn_forward: null pointer");
-    IQ_REQUIRE(B >= 0 && N >= 32 && N % 32 == 0 && N <= 32767, "iq_dgcnn_forward: N=%d must be a multiple of 32", N);
+    IQ_REQUIRE(B >= 0 && N >= kK && N <= 32767, "iq_dgcnn_forward: N=%d not in [%d, 32767]", N, kK);
     IQ_REQUIRE(w->k == kK, "iq_dgcnn_forward: k=%d (only 20)", w->k);
     if (B == 0) return IQ_OK;
     const size_t need = carve_d(nullptr, B, N).bytes;
@@ -497,12 +504,13 @@ extern "C" int iq_dgcnn_forward(const iq_dgcnn_weights* w, const float* xyz, flo
         return iq::fail(IQ_EWORKSPACE, "iq_dgcnn_forward: workspace %zu < %zu bytes", workspace_bytes, need);
     WsD s = carve_d(workspace, B, N);
     hipStream_t st = iq::as_stream(stream);
-    const int rows = B * N;
+    const int Np = (N + 31) / 32 * 32;  // rows N..Np-1 of every cloud are dead padding
+    const int rows = B * Np;
     int rc;
     iq::ProfileSpan call_span(iq::kSlotCall, st);
     hipLaunchKernelGGL(dg_dense_layout_kernel, dim3((rows + 256) / 256), dim3(256), 0, st, s.roff, s.nkept, s.ncopy,
-                       s.row_cloud, s.row_w, B, N);
-    hipLaunchKernelGGL(pad_xyz_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, xyz, s.x0, rows);
+                       s.row_cloud, s.row_w, B, N, Np);
+    hipLaunchKernelGGL(pad_xyz_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, xyz, s.x0, B, N, Np);
     if ((rc = iq::check_launch("pad_xyz_kernel"))) return rc;
     return run_network(w, s, logits, B, N, rows, fixed_graph, st);
 }
@@ -513,7 +521,7 @@ extern "C" int iq_dgcnn_coalitions(const iq_dgcnn_weights* w, const float* cloud
                                    iq_stream_t stream) {
     IQ_REQUIRE(B >= 0 && nclouds >= 1, "iq_dgcnn_coalitions: B=%d nclouds=%d", B, nclouds);
     IQ_REQUIRE(w && clouds && centers && region_id && (B == 0 || (keep && logits)), "iq_dgcnn_coalitions: null pointer");
-    IQ_REQUIRE(N >= 32 && N % 32 == 0 && N <= 32767, "iq_dgcnn_coalitions: N=%d must be a multiple of 32", N);
+    IQ_REQUIRE(N >= kK && N <= 32767, "iq_dgcnn_coalitions: N=%d not in [%d, 32767]", N, kK);
     IQ_REQUIRE(cloud_of || nclouds == 1 || nclouds == B, "iq_dgcnn_coalitions: cloud_of required when 1 < nclouds != B");
     IQ_REQUIRE(w->k == kK, "iq_dgcnn_coalitions: k=%d (only 20)", w->k);
     if (B == 0) return IQ_OK;
@@ -529,5 +537,5 @@ extern "C" int iq_dgcnn_coalitions(const iq_dgcnn_weights* w, const float* cloud
     hipLaunchKernelGGL(dg_compact_kernel, dim3(B), dim3(64), 0, st, clouds, centers, region_id, keep, cloud_of, s.roff, s.nkept,
                        s.ncopy, s.x0, s.row_cloud, s.row_w, N, nclouds);
     if ((rc = iq::check_launch("dg_compact_kernel"))) return rc;
-    return run_network(w, s, logits, B, N, B * N, fixed_graph, st);
+    return run_network(w, s, logits, B, N, B * ((N + 31) / 32 * 32), fixed_graph, st);
 }

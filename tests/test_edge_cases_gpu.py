@@ -236,7 +236,7 @@ def test_abi_error_reporting_of_the_coalition_and_enumeration_entry_points():
     eng = dg.to(d).eval().engine()
     args = (ctypes.byref(eng.weights.struct), p(clouds), p(centers), p(rid), p(keep), None, p(logits), p(tiny), tiny.numel())
     assert lib.iq_dgcnn_coalitions(*args, 4, 1, 1024, 0, None) == -3 and b"workspace" in lib.iq_last_error()
-    assert lib.iq_dgcnn_coalitions(*args, 4, 1, 1000, 0, None) == -1 and b"multiple of 32" in lib.iq_last_error()
+    assert lib.iq_dgcnn_coalitions(*args, 4, 1, 10, 0, None) == -1 and b"N=10" in lib.iq_last_error()   # fewer points than k
     assert lib.iq_dgcnn_coalitions(*args, 4, 3, 1024, 0, None) == -1 and b"cloud_of" in lib.iq_last_error()
     assert lib.iq_dgcnn_coalitions(*args, 0, 1, 1024, 0, None) == 0                       # empty batch: nothing to do
     pn = PointNet2ClsMsg(None)
@@ -293,3 +293,28 @@ def test_pointnet_coalitions_on_odd_cloud_sizes(model, oracle_model, n):
     pts, _ = synth.make_cloud(12, num_points=n)
     rng = np.random.default_rng(n)
     check_against_oracle(model, oracle_model, pts, rng.integers(0, 16, size=n), 16, [0, 0xffff, 0x00ff, 0x8001, 0x5a5a])
+
+
+@pytest.mark.parametrize("name", ["dgcnn", "gcnn"])
+def test_graph_models_on_a_cloud_size_that_is_not_a_multiple_of_32(name):
+    """N = 1000: dense forward against the oracle, and the coalition path against the dense forward (clouds are padded to
+    a multiple of 32 with dead rows internally; the reference accepts any N >= k)."""
+    import argparse
+    from oracle import ref_cpu as O
+    from interpret_quality_amd.dgcnn import DGCNN_cls, GCNN_cls
+    sd = synth.to_torch(synth.dgcnn_state_dict(0))
+    m = (DGCNN_cls if name == "dgcnn" else GCNN_cls)(argparse.Namespace(dataset="modelnet10", k=20))
+    m.load_state_dict(sd)
+    m = m.to(dev()).eval()
+    d = dev()
+    pts, _ = synth.make_cloud(13, num_points=1000)
+    x = torch.from_numpy(pts).unsqueeze(0)
+    want = O.DgcnnOracle(sd, k=20, fixed_graph=(name == "gcnn"))(x.permute(0, 2, 1).contiguous()).numpy()
+    got = m(x.permute(0, 2, 1).contiguous().to(d)).cpu().numpy()
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-4
+    rid = torch.from_numpy(np.random.default_rng(0).integers(0, 8, size=(1, 1000)).astype(np.int32)).to(d)
+    keep = [0xff, 0x0f, 0x00, 0x81]
+    cloud, center = x.to(d), x.to(d).mean(dim=1)
+    co = m.coalition_logits(cloud, center, rid, hip_ops.masks_to_tensor(keep, d), None, num_regions=8)
+    dense = m.forward_points(hip_ops.mask_coalitions(cloud[0], rid[0].contiguous(), hip_ops.masks_to_tensor(keep, d), center[0].contiguous()))
+    assert np.abs((co - dense).cpu().numpy()).max() / np.abs(dense.cpu().numpy()).max() < 1e-5
