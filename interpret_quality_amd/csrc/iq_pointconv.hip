@@ -400,11 +400,19 @@ __global__ __launch_bounds__(kThreads) void pc_all_contract_kernel(const float* 
     for (int w = 0; w < 16; ++w) dst[w] = o[w];
 }
 
-__global__ void pc_pad8_kernel(const float* __restrict__ xyz, float* __restrict__ out, int total) {
+// (B,n,3) -> (B,np,8), np >= n a multiple of 32: padding rows sit at 1e18 in every coordinate, so as keys they are further
+// than any real point (|p|^2 = 3e36 stays finite) and are never among the K nearest
+__global__ void pc_pad8_kernel(const float* __restrict__ xyz, float* __restrict__ out, int B, int n, int np) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    reinterpret_cast<f32x4*>(out)[t * 2] = (f32x4){xyz[t * 3], xyz[t * 3 + 1], xyz[t * 3 + 2], 0.f};
-    reinterpret_cast<f32x4*>(out)[t * 2 + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (t >= B * np) return;
+    const int b = t / np, i = t - b * np;
+    f32x4 a = {1e18f, 1e18f, 1e18f, 0.f};
+    if (i < n) {
+        const float* src = xyz + ((size_t)b * n + i) * 3;
+        a = (f32x4){src[0], src[1], src[2], 0.f};
+    }
+    reinterpret_cast<f32x4*>(out)[(size_t)t * 2] = a;
+    reinterpret_cast<f32x4*>(out)[(size_t)t * 2 + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
 struct WsC {
@@ -432,7 +440,7 @@ WsC carve_c(void* base, int B, int N) {
     s.inv1 = (float*)take(b * N * 4); s.inv2 = (float*)take(b * 512 * 4); s.inv3 = (float*)take(b * 128 * 4);
     s.fps1 = (int32_t*)take(b * 512 * 4); s.fps2 = (int32_t*)take(b * 128 * 4);
     s.nx1 = (float*)take(b * 512 * 3 * 4); s.nx2 = (float*)take(b * 128 * 3 * 4);
-    s.k8 = (float*)take(b * N * 8 * 4); s.q8 = (float*)take(b * 512 * 8 * 4);
+    s.k8 = (float*)take(b * ((N + 31) / 32 * 32) * 8 * 4); s.q8 = (float*)take(b * 512 * 8 * 4);
     s.idx1 = (int16_t*)take(b * 512 * 32 * 2); s.idx2 = (int16_t*)take(b * 128 * 64 * 2);
     s.g1 = (float*)take(b * 512 * 2048 * 4); s.l1 = (float*)take(b * 512 * 128 * 4);
     s.u2 = (float*)take(b * 512 * 128 * 4); s.g2 = (float*)take(b * 128 * 4096 * 4); s.l2 = (float*)take(b * 128 * 256 * 4);
@@ -445,10 +453,11 @@ WsC carve_c(void* base, int B, int N) {
 
 template <int K>
 int launch_pc_knn(const float* keys, int nkeys, const float* queries, int S, WsC& s, int16_t* idx, int B, hipStream_t st) {
-    hipLaunchKernelGGL(pc_pad8_kernel, dim3((B * nkeys + 255) / 256), dim3(256), 0, st, keys, s.k8, B * nkeys);
-    hipLaunchKernelGGL(pc_pad8_kernel, dim3((B * S + 255) / 256), dim3(256), 0, st, queries, s.q8, B * S);
+    const int nkp = (nkeys + 31) / 32 * 32;
+    hipLaunchKernelGGL(pc_pad8_kernel, dim3((B * nkp + 255) / 256), dim3(256), 0, st, keys, s.k8, B, nkeys, nkp);
+    hipLaunchKernelGGL(pc_pad8_kernel, dim3((B * S + 255) / 256), dim3(256), 0, st, queries, s.q8, B, S, S);
     const int wpc = (S + 127) / 128;
-    hipLaunchKernelGGL(pc_knn_kernel<K>, dim3((unsigned)((B + 7) / 8 * 8 * wpc)), dim3(kThreads), 0, st, s.k8, s.q8, idx, nkeys, S, B,
+    hipLaunchKernelGGL(pc_knn_kernel<K>, dim3((unsigned)((B + 7) / 8 * 8 * wpc)), dim3(kThreads), 0, st, s.k8, s.q8, idx, nkp, S, B,
                        wpc);
     return iq::check_launch("pc_knn_kernel");
 }
@@ -478,7 +487,7 @@ extern "C" size_t iq_pointconv_workspace_bytes(int B, int N) {
 extern "C" int iq_pointconv_forward(const iq_pointconv_weights* w, const float* xyz, float* logits, void* workspace,
                                     size_t workspace_bytes, int B, int N, iq_stream_t stream) {
     IQ_REQUIRE(w && xyz && logits, "iq_pointconv_forward: null pointer");
-    IQ_REQUIRE(B >= 0 && N >= 512 && N % 32 == 0 && N <= 4096, "iq_pointconv_forward: N=%d", N);
+    IQ_REQUIRE(B >= 0 && N >= 512 && N <= 4096, "iq_pointconv_forward: N=%d not in [512, 4096]", N);
     IQ_REQUIRE(w->sa[0].nsample == 32 && w->sa[1].nsample == 64, "iq_pointconv_forward: nsample must be 32 / 64");
     if (B == 0) return IQ_OK;
     const size_t need = carve_c(nullptr, B, N).bytes;

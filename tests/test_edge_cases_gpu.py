@@ -318,3 +318,23 @@ def test_graph_models_on_a_cloud_size_that_is_not_a_multiple_of_32(name):
     co = m.coalition_logits(cloud, center, rid, hip_ops.masks_to_tensor(keep, d), None, num_regions=8)
     dense = m.forward_points(hip_ops.mask_coalitions(cloud[0], rid[0].contiguous(), hip_ops.masks_to_tensor(keep, d), center[0].contiguous()))
     assert np.abs((co - dense).cpu().numpy()).max() / np.abs(dense.cpu().numpy()).max() < 1e-5
+
+
+@pytest.mark.parametrize("name", ["pointnet2", "pointconv"])
+def test_set_abstraction_models_on_a_cloud_size_that_is_not_a_multiple_of_32(name):
+    from oracle import ref_cpu as O
+    from interpret_quality_amd.pointconv import PointConvDensityClsSsg
+    from interpret_quality_amd.pointnet2 import PointNet2ClsMsg
+    cls, sdf, orc = {"pointnet2": (PointNet2ClsMsg, synth.pointnet2_state_dict, O.PointNet2Oracle),
+                     "pointconv": (PointConvDensityClsSsg, synth.pointconv_state_dict, O.PointConvOracle)}[name]
+    sd = synth.to_torch(sdf(0))
+    m = cls(None)
+    m.load_state_dict(sd)
+    m = m.to(dev()).eval()
+    pts, _ = synth.make_cloud(14, num_points=1000)
+    x = torch.from_numpy(pts).unsqueeze(0).permute(0, 2, 1).contiguous()
+    want = orc(sd)(x)
+    want = (want[0] if isinstance(want, tuple) else want).numpy()
+    got = m(x.to(dev()))
+    got = (got[0] if isinstance(got, tuple) else got).cpu().numpy()
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-4
