@@ -10,13 +10,29 @@ coalitions = 33 000 masked forward passes, reward, per-region float64 accumulati
 (cloud, region ids, permutations) are resident in HBM before the timed region.  With N > 1 every
 rank works on its own cloud (weak scaling; independent objects) and one RCCL all-gather per step
 brings the per-coalition logits to every rank, as the artefact writer on rank 0 needs them
-(SURVEY.md §8e).  Rank 0 prints ONE JSON line.
+(SURVEY.md §8e).  IQ_FORCE_DIST=1 creates the process group (and runs the barrier / all-gather) at
+N = 1 too, so the RCCL path can be exercised on a one-GPU box.  Rank 0 prints ONE JSON line.
+
+The line's `roofline` is what the dominant kernel EXECUTES (FLOP of the 32-row MFMA tiles it issues) over its
+HIP-event launch time, against the dense fp32 MFMA peak; the algorithmic count of the dense reference layers is a
+separate key (the kernel skips duplicate points exactly, so that ratio exceeds 1).  After the timed region (N = 1
+only): the other model families on their BASELINE shapes with a roofline each (`other_models`), the stock
+PyTorch-ROCm eager restatement on the same GPU (`gpu_eager_baseline`), the CPU oracle on the host cores
+(`cpu_baseline`), and the HBM traffic of the dominant kernel from two rocprofv3 counter passes of this script
+(`roofline.traffic`; null when the profiler is unavailable).
 """
 import argparse
+import contextlib
+import csv
 import ctypes
+import glob
+import io
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,7 +43,8 @@ sys.path.insert(0, REPO)
 
 NUM_POINTS, NUM_REGIONS, NUM_PERMS = 1024, 32, 1000
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak (no xf32/TF32 on gfx950)
-SUSTAINED_F32_MFMA_TFLOPS = 138.7  # bare MFMA loop on random operands, this chip: profiles/r01_mfma_shape_microbench.txt
+CHAIN_MAC_PER_ROW = 143360.0  # 64*64 + 64*128 + 128*1024: the MFMA layers of one chain-kernel row
+SLOT_DOMINANT = 5
 
 
 def parse():
@@ -39,8 +56,11 @@ def parse():
     ap.add_argument("--regions", type=int, default=NUM_REGIONS)
     ap.add_argument("--cpu-baseline", type=int, default=1, help="time the CPU oracle on rank 0 at N=1")
     ap.add_argument("--cpu-perms", type=int, default=40, help="permutations of the bounded CPU sample")
-    ap.add_argument("--other-models", type=int, default=1, help="after the timed region (N=1 only): coalitions/s of the other "
-                    "model families on BASELINE configs[2..3] shapes, reported under 'other_models'")
+    ap.add_argument("--eager-baseline", type=int, default=1, help="time the stock PyTorch-ROCm eager restatement (N=1)")
+    ap.add_argument("--other-models", type=int, default=1, help="after the timed region (N=1 only): coalitions/s and the "
+                    "dominant kernel's roofline of the other model families on BASELINE configs[2..3] shapes")
+    ap.add_argument("--traffic", type=int, default=1, help="measure the chain kernel's HBM bytes with two rocprofv3 "
+                    "counter passes of this script (N=1 only; null if rocprofv3 is unavailable)")
     return ap.parse_args()
 
 
@@ -80,18 +100,67 @@ def cpu_baseline(num_regions, perms, bs=10):
                       % (num_regions, perms, bs, bs * (num_regions + 1), n, dt)}
 
 
-def other_models(dev, regions=32):
+def gpu_eager_baseline(num_regions):
+    """SURVEY §8d baseline (ii): the reference's Shapley loop restated with stock PyTorch-ROCm eager ops on this GPU
+    (index-put masking storm, one batched forward, one host sync per permutation; config.py's bs = 50 for PointNet)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("iq_eager_gpu_baseline", os.path.join(REPO, "tests", "eager_gpu_baseline.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.run_eager(perms=100, bs=50, regions=num_regions)
+
+
+def _read_slot(lib, slot):
+    from interpret_quality_amd import _lib
+    ms, n, work = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
+    _lib.check(lib.iq_profile_read_work(slot, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(work)), "iq_profile_read_work")
+    return ms.value, n.value, work.value
+
+
+# SURVEY.md §8d: dense MAC count of each reference network per coalition (the algorithmic figure) and the kernel that
+# dominates its step here
+OTHER_MODELS = {
+    "pointnet2": {"config": "BASELINE configs[2]", "dense_gflop": 7.83, "kernel": "pn2_group_kernel<128,128,256> (sa2, r=0.8)"},
+    "dgcnn": {"config": "BASELINE configs[3]", "dense_gflop": 5.33, "kernel": "pn_gemm_lds_kernel<4,pool> (conv5 + max/mean pool)"},
+    "gcnn": {"config": "BASELINE configs[3] (gcnn)", "dense_gflop": 4.79, "kernel": "pn_gemm_lds_kernel<4,pool> (conv5 + max/mean pool)"},
+    "pointconv": {"config": "Shapley shape of configs[2]", "dense_gflop": 2.4, "kernel": "pc_group_kernel<128,128,256> (sa2)"},
+}
+
+
+def interaction_workload(regions, num_pairs=300, max_ctx=100, seed=1):
+    """The reference's interaction inputs for one cloud (final_gen_pair.py:288-300 and :18-43): 300 random region pairs and,
+    for each of the 13 ratios, up to 100 sampled contexts per pair (all C(R-2, m) when there are fewer).  Returns
+    [(pairs (P,2), contexts (P,C,m))] per ratio; 1032 contexts per pair at R = 32."""
+    from argparse import Namespace
+    from interpret_quality_amd import gen_pair
+    from interpret_quality_amd.interaction import DEFAULT_RATIOS
+    a = Namespace(num_regions=regions, num_pairs_random=num_pairs, num_save_context_max=max_ctx, ratio=DEFAULT_RATIOS)
+    np.random.seed(seed)
+    pairs = gen_pair.gen_pair_random(a)
+    out = []
+    tmp = tempfile.mkdtemp(prefix="iq_bench_ctx_")
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            gen_pair.gen_context(pairs, tmp + "/", a)
+        for ratio in DEFAULT_RATIOS:
+            out.append((pairs, np.load(tmp + "/ratio%d_context_list.npy" % int(ratio * 100))))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def other_models(dev, lib, regions=32):
     """Not the headline: coalitions/s of the other model families through the same C ABI, each on the shape BASELINE.json
-    names for it (PointNet++ / PointConv: Shapley, 100 permutations = 3300 coalitions per step; DGCNN / GCNN: interaction,
-    30 pairs x 100 contexts x 4 = 12 000 coalitions per step).  Every coalition row is a forward pass (no driver-level
-    de-duplication).  Failures are reported, never raised: the headline line must still be printed."""
+    names for it - PointNet++ / PointConv: Shapley, 100 permutations x 33 = 3300 coalitions per step (configs[2]);
+    DGCNN / GCNN: the interaction stage of ONE cloud setting at full size, 300 pairs x 13 ratios (1032 contexts per pair) x 4
+    = 1 238 400 coalitions per step (configs[3]).  Every coalition row is a forward pass (no driver-level de-duplication).
+    A second, profiled pass gives the dominant kernel's HIP-event time and the FLOP its MFMA tiles execute -> `roofline`.
+    Failures are reported, never raised: the headline line must still be printed."""
     import argparse as ap
     from interpret_quality_amd import final_common, hip_ops, interaction, synth
     from interpret_quality_amd.dgcnn import DGCNN_cls, GCNN_cls
     from interpret_quality_amd.pointconv import PointConvDensityClsSsg
     from interpret_quality_amd.pointnet2 import PointNet2ClsMsg
-    import contextlib
-    import io
     saved = final_common.distinct_coalitions
     final_common.distinct_coalitions = lambda k: (np.asarray(k, dtype=np.uint64), np.arange(len(k)))
     out = {}
@@ -101,11 +170,8 @@ def other_models(dev, regions=32):
         lbl = torch.tensor([label], device=dev)
         region_id = hip_ops.region_assign(data[0].contiguous(), hip_ops.fps(data, regions)[0].contiguous()).cpu().numpy()
         orders = synth.make_orders(100, regions, seed=1)
-        rng = np.random.default_rng(0)
-        all_pairs = np.array([[i, j] for i in range(regions) for j in range(regions) if j > i])
-        pairs = all_pairs[rng.choice(len(all_pairs), size=30, replace=False)]
-        ctx = np.stack([np.stack([rng.choice([r for r in range(regions) if r not in pr], 15, replace=False) for _ in range(100)])
-                        for pr in pairs])
+        inter = interaction_workload(regions)
+        n_inter = sum(4 * p.shape[0] * c.shape[1] for p, c in inter)
         specs = (("pointnet2", PointNet2ClsMsg, synth.pointnet2_state_dict, "shapley"),
                  ("dgcnn", DGCNN_cls, synth.dgcnn_state_dict, "interaction"),
                  ("gcnn", GCNN_cls, synth.dgcnn_state_dict, "interaction"),
@@ -118,29 +184,97 @@ def other_models(dev, regions=32):
                 a = ap.Namespace(model=name, softmax_type="modified", num_points=NUM_POINTS, num_regions=regions, num_samples=100,
                                  shapley_batch_size=20, interaction_batch_size=100, verbose=False)
                 if mode == "shapley":
-                    run = lambda: final_common.shap_sampling_all_regions_batch(m, data, lbl, region_id, orders, a)
-                    n = 100 * (regions + 1)
+                    def run(frac=1.0):
+                        final_common.shap_sampling_all_regions_batch(m, data, lbl, region_id, orders, a)
+                        return 100 * (regions + 1)
+                    steps, workload = 5, "Shapley, %d regions x 100 permutations = %d coalitions per step" % (regions, 100 * (regions + 1))
                 else:
-                    def run():
+                    def run(frac=1.0):
+                        n = 0
                         with contextlib.redirect_stdout(io.StringIO()):
-                            return interaction.compute_order_interaction_logits(m, data, region_id, pairs, ctx, a)
-                    n = 30 * 100 * 4
-                run()
+                            for pairs, ctx in inter:
+                                k = max(1, int(round(pairs.shape[0] * frac)))
+                                interaction.compute_order_interaction_logits(m, data, region_id, pairs[:k], ctx[:k], a)
+                                n += 4 * k * ctx.shape[1]
+                        return n
+                    steps, workload = 1, ("interaction, one cloud setting: 300 pairs x 13 ratios (%d contexts per pair) x 4 = %d "
+                                          "coalitions per step" % (n_inter // 1200, n_inter))
+                run(0.1)                                    # warm-up (a tenth of the pairs for the interaction shape)
                 torch.cuda.synchronize()
-                steps = 3
                 t0 = time.perf_counter()
-                for _ in range(steps):
-                    run()
+                n = sum(run() for _ in range(steps))
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
-                out[name] = {"value": n * steps / dt, "unit": "coalitions/s", "steps": steps,
-                             "workload": "%s, %d regions, %d coalitions per step" % (mode, regions, n)}
+                # profiled pass (its syncs for the work counts stay out of the throughput above)
+                lib.iq_profile_enable(1)
+                run(0.1 if mode == "interaction" else 1.0)
+                torch.cuda.synchronize()
+                lib.iq_profile_enable(0)
+                ms, launches, work = _read_slot(lib, SLOT_DOMINANT)
+                for s in range(5):
+                    _read_slot(lib, s)                      # forget the other spans
+                spec = OTHER_MODELS[name]
+                achieved = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                out[name] = {"value": n / dt, "unit": "coalitions/s", "steps": steps, "workload": workload, "config": spec["config"],
+                             "roofline": {"bound": "mfma", "kernel": spec["kernel"], "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                                          "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+                                          "executed_flop_per_launch": work / max(launches, 1),
+                                          "algorithmic_tflops_whole_step": spec["dense_gflop"] * 1e9 * (n / dt) / 1e12,
+                                          "note": "achieved = FLOP of the MFMA tiles the dominant kernel issues / its HIP-event time; "
+                                                  "algorithmic_tflops_whole_step = SURVEY 8d dense FLOP per coalition x coalitions/s "
+                                                  "(exceeds the peak where exact restructurings skip work)"}}
                 del m
             except Exception as e:  # noqa: BLE001
-                out[name] = {"error": repr(e)[:200]}
+                out[name] = {"error": repr(e)[:300]}
     finally:
         final_common.distinct_coalitions = saved
+        lib.iq_profile_enable(0)
     return out
+
+
+def measure_traffic():
+    """HBM bytes per chain-kernel launch, measured NOW: two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE: they do not fit
+    one pass) of this script as child processes, kernel trace only.  Units and the gfx950 correction per
+    MI355X_MICROARCH.md §HBM: the counters are in KB, FETCH_SIZE reports half the bytes of wide coalesced reads.  Returns
+    (bytes per launch averaged over the feature-STN and trunk instantiations, detail dict) or (None, reason)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    per = {}
+    tmp = tempfile.mkdtemp(prefix="iq_bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "IQ_FORCE_DIST"):
+        env.pop(k, None)
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-baseline", "0", "--other-models", "0",
+                   "--eager-baseline", "0", "--traffic", "0"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-200:])
+            for row in csv.DictReader(open(files[0])):
+                name = row["Kernel_Name"]
+                if "pn_chain_kernel" in name and row["Counter_Name"] == counter:
+                    key = "fstn" if "pn_chain_kernel<1" in name else "trunk" if "pn_chain_kernel<2" in name else "prepool"
+                    per.setdefault(key, {}).setdefault(counter, []).append(float(row["Counter_Value"]) * 1024.0)
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+        return None, "traffic pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    detail, tot, n = {}, 0.0, 0
+    for key in ("fstn", "trunk"):
+        if key not in per or "FETCH_SIZE" not in per[key] or "WRITE_SIZE" not in per[key]:
+            return None, "no %s chain launches in the counter output" % key
+        fetch = 2.0 * float(np.mean(per[key]["FETCH_SIZE"]))    # gfx950: FETCH_SIZE counts half of a wide coalesced read
+        write = float(np.mean(per[key]["WRITE_SIZE"]))
+        detail[key] = {"fetch_bytes_corrected_x2": fetch, "write_bytes": write}
+        tot += fetch + write
+        n += 1
+    return tot / n, detail
 
 
 def main():
@@ -157,12 +291,16 @@ def main():
     # IQ_BENCH_REHEARSAL=1: rehearse the N > 1 code path on a one-GPU box (all ranks on cuda:0, gloo
     # collectives).  Never set by the driver; the numbers of a rehearsal mean nothing.
     rehearsal = os.environ.get("IQ_BENCH_REHEARSAL") == "1"
+    force_dist = os.environ.get("IQ_FORCE_DIST") == "1"
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    collectives = world > 1 or force_dist
+    if collectives:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)  # nccl = RCCL on ROCm
 
     from interpret_quality_amd import _lib, final_common, hip_ops, synth
@@ -179,23 +317,26 @@ def main():
     data = torch.from_numpy(pts).unsqueeze(0).to(dev)
     fps_idx = hip_ops.fps(data, R)[0].contiguous()
     region_id = hip_ops.region_assign(data[0].contiguous(), fps_idx).reshape(1, -1)
+    hip_ops.check_index_range(region_id, 0, R, "region_id")   # once, before timing; the timed calls skip the check
     orders_np = synth.make_orders(S, R, seed=1)
     orders = hip_ops.as_i32(orders_np, dev)
-    keep = hip_ops.masks_to_tensor(final_common.prefix_keep_masks(orders_np, R), dev)
+    keep_np = final_common.prefix_keep_masks(orders_np, R)
+    keep = hip_ops.masks_to_tensor(keep_np, dev)
     center = torch.mean(data, dim=1).contiguous()
     n_coal = S * (R + 1)
-    gathered = [torch.empty((n_coal, 10), dtype=torch.float32, device=dev) for _ in range(world)] if world > 1 else None
+    # ONE preallocated receive buffer for the per-step all-gather of the logits (132 KB per rank)
+    gathered = torch.empty((world * n_coal, 10), dtype=torch.float32, device=dev) if collectives else None
 
     def step():
-        logits = model.coalition_logits(data, center, region_id, keep, None, num_regions=R)
+        logits = model.coalition_logits(data, center, region_id, keep, None, num_regions=R, validate=False)
         v = hip_ops.reward(logits, label, True)
         phi_sum, _, _ = hip_ops.shapley_accum(v, orders)
-        if world > 1:
-            dist.all_gather(gathered, logits)
+        if collectives:
+            dist.all_gather_into_tensor(gathered, logits)
         return phi_sum, logits
 
     def fence():
-        if world > 1:
+        if collectives:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -209,20 +350,18 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     lib.iq_profile_enable(0)
-    if world > 1:
+    if collectives:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's chunk of the gather must hold that rank's logits (rank r's own chunk is checkable locally)
+        assert torch.equal(gathered[rank * n_coal:(rank + 1) * n_coal], logits), "all-gather returned a wrong chunk"
 
     # ---- HIP-event durations of the dominant kernel over the timed region ----------------------
-    def slot(i):
-        ms, n = ctypes.c_double(0), ctypes.c_int(0)
-        _lib.check(lib.iq_profile_read(i, ctypes.byref(ms), ctypes.byref(n)), "iq_profile_read")
-        return ms.value, n.value
-    pre_ms, pre_n = slot(0)
-    f_ms, f_n = slot(1)
-    t_ms, t_n = slot(2)
-    call_ms, call_n = slot(3)
+    pre_ms, pre_n, _ = _read_slot(lib, 0)
+    f_ms, f_n, _ = _read_slot(lib, 1)
+    t_ms, t_n, _ = _read_slot(lib, 2)
+    call_ms, call_n, _ = _read_slot(lib, 3)
 
     # sanity: efficiency axiom on the last step (sum phi = v(N) - v(empty) for every permutation)
     v = hip_ops.reward(logits, label, True)
@@ -231,22 +370,21 @@ def main():
 
     if rank == 0:
         total = n_coal * args.steps * world
-        # the chain kernel (feature-STN and trunk instantiations: same shape, 143 360 MAC per point)
-        flop_per_launch = 2.0 * 143360.0 * NUM_POINTS * n_coal
         avg_launch_s = (f_ms + t_ms) / max(f_n + t_n, 1) * 1e-3
-        achieved = flop_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
-        # what the kernel actually executes: each coalition's DISTINCT rows (kept points + the centre), in 32-row MFMA tiles
+        # what the chain kernel (feature-STN and trunk instantiations: same shape) executes per launch: each coalition's
+        # DISTINCT rows (kept points + the centre), in 32-row MFMA tiles, 143 360 MAC per row
         sizes = np.bincount(region_id.cpu().numpy().reshape(-1), minlength=R).astype(np.int64)
-        bits = ((final_common.prefix_keep_masks(orders_np, R)[:, None] >> np.arange(R, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.int64)
+        bits = ((keep_np[:, None] >> np.arange(R, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.int64)
         kept = bits @ sizes
         rows = kept + (kept < NUM_POINTS)
         rows32 = (rows + 31) // 32 * 32
-        executed = 2.0 * 143360.0 * float(rows32.sum()) / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        executed_flop = 2.0 * CHAIN_MAC_PER_ROW * float(rows32.sum())
+        algorithmic_flop = 2.0 * CHAIN_MAC_PER_ROW * NUM_POINTS * n_coal          # the dense reference layers: all 1024 rows
+        achieved = executed_flop / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         step_flops = lib.iq_pointnet_flops_per_coalition(NUM_POINTS) * n_coal
+        traffic, traffic_detail = (None, "not measured (N > 1 or --traffic 0)")
+        if world == 1 and args.traffic and not force_dist:
+            traffic, traffic_detail = measure_traffic()
         out = {
             "metric": "coalitions/sec (masked forward passes/sec), PointNet 1024-pt ModelNet10",
             "value": total / elapsed, "unit": "coalitions/s", "n_gpus": world, "steps": args.steps,
@@ -255,26 +393,36 @@ def main():
             "config": {"workload": "PointNet ModelNet10-style Shapley, %d regions x %d permutations per cloud "
                                    "(%d coalitions per step per GPU), BASELINE configs[1]" % (R, S, n_coal),
                        "num_points": NUM_POINTS, "num_regions": R, "permutations": S,
-                       "parallelism": "clouds sharded over %d GPU(s), all-gather of logits" % world},
+                       "parallelism": "clouds sharded over %d GPU(s), one all_gather_into_tensor of the logits per step%s"
+                                      % (world, " (forced single-rank RCCL group)" if force_dist and world == 1 else "")},
             "roofline": {"bound": "mfma", "kernel": "pn_chain_kernel<fstn|trunk>", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": traffic, "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n + t_n,
-                         "algorithmic_flop_per_launch": flop_per_launch,
-                         "executed": executed, "executed_frac_of_peak": executed / PEAK_F32_MFMA_TFLOPS,
-                         "sustained_mfma_random_operands": SUSTAINED_F32_MFMA_TFLOPS,
-                         "executed_frac_of_sustained": executed / SUSTAINED_F32_MFMA_TFLOPS,
-                         "note": "achieved/frac: algorithmic FLOP of the dense reference layers this kernel implements; the "
-                                 "kernel evaluates each coalition's distinct points only (exact), so frac can exceed 1. "
-                                 "executed: FLOP of the 32-row MFMA tiles it really issues",
+                         "traffic": traffic, "traffic_detail": traffic_detail,
+                         "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n + t_n,
+                         "executed_flop_per_launch": executed_flop,
+                         "algorithmic_flop_per_launch": algorithmic_flop,
+                         "algorithmic_tflops": algorithmic_flop / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0,
+                         "algorithmic_vs_executed": algorithmic_flop / executed_flop,
+                         "note": "achieved/frac: FLOP of the 32-row fp32 MFMA tiles the kernel issues / HIP-event launch time / dense "
+                                 "fp32 MFMA peak.  algorithmic_*: the dense reference layers this kernel implements (every coalition, all "
+                                 "1024 rows); the kernel evaluates each coalition's distinct points only (exact, DESIGN.md 3), so the "
+                                 "algorithmic rate exceeds the peak.  traffic: HBM bytes per launch from rocprofv3 FETCH_SIZE x2 + "
+                                 "WRITE_SIZE of this same script, measured now",
                          "step_tflops_algorithmic": step_flops / (elapsed / args.steps) / 1e12,
                          "prepool_ms_per_launch": pre_ms / max(pre_n, 1), "call_ms": call_ms / max(call_n, 1)},
         }
         if world == 1 and args.other_models:
-            out["other_models"] = other_models(dev, R)
+            out["other_models"] = other_models(dev, lib, R)
+        if world == 1 and args.eager_baseline:
+            try:
+                out["gpu_eager_baseline"] = gpu_eager_baseline(R)
+            except Exception as e:  # noqa: BLE001
+                out["gpu_eager_baseline"] = {"error": repr(e)[:300]}
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(R, args.cpu_perms)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if collectives:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -72,6 +72,15 @@ int iq_mask_coalitions(const float* cloud /*N,3*/, const int32_t* region_id /*N*
                        const uint64_t* keep /*B*/, const float* center /*3*/, float* out,
                        int N, int B, int channel_first, iq_stream_t stream);
 
+/* Validation of index inputs (region ids in [0,R), permutation / pair entries in [0,R), FPS indices in [0,N)):
+ * returns IQ_EINVAL and names the first offending position if any idx[i] lies outside [lo, hi).  The ONE entry point
+ * that synchronises `stream` (it reads a 4-byte verdict back); `scratch` = 4 bytes of device memory.  The launch
+ * functions themselves never fault on an out-of-range id - such a point is treated as belonging to no region (always
+ * masked), an out-of-range order entry is ignored - but their results are then meaningless; callers that take ids from
+ * files (region_id.npy, all_orders.npy: tools/final_common.py:120-121) validate once per cloud with this call. */
+int iq_check_index_range(const int32_t* idx, size_t count, int lo, int hi, uint32_t* scratch /*4 B, device*/,
+                         iq_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Reward and reductions
  * ------------------------------------------------------------------------------------------- */
@@ -337,6 +346,11 @@ int iq_pointconv_forward(const iq_pointconv_weights* w /*host struct of device p
  * duration and count, and forgets them.  Slots: 0 = input-STN pre-pool chain, 1 = feature-STN
  * chain, 2 = trunk chain, 3 = whole iq_pointnet_coalitions call. */
 int iq_profile_enable(int on);
+/* As iq_profile_read, plus the summed `work` (executed FLOP of the MFMA tiles issued) the library attached to the spans
+ * of that slot.  Slot 5 = the dominant kernel of a model's step: PointNet++ pn2_group_kernel<128,128,256> (sa2, third
+ * scale), DGCNN / GCNN conv5 + pooling GEMM, PointConv pc_group_kernel<128,128,256> (sa2).  Profiler state and the
+ * iq_set_tuning knobs belong to the calling thread (like iq_last_error). */
+int iq_profile_read_work(int slot, double* total_ms, int* launches, double* total_work);
 /* Experiment knob: selects between co-compiled kernel variants so that they can be timed
  * interleaved in ONE process.  key 0 = L3 weight-streaming variant of the chain kernel; 1 = extra dynamic LDS
  * of the chain kernel (occupancy experiment); 2 = 1: no LPT launch order; 3 = 1: dense layers never use the

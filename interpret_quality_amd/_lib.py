@@ -78,6 +78,7 @@ SIGNATURES = {
     "iq_mask_shapley": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "iq_mask_interaction": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "iq_mask_coalitions": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "iq_check_index_range": (_I, [_P, _SZ, _I, _I, _P, _P]),
     "iq_reward": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "iq_shapley_accum": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P]),
     "iq_interaction_reduce": (_I, [_P, _P, _I, _P]),
@@ -108,6 +109,7 @@ SIGNATURES = {
     "iq_set_tuning": (_I, [_I, _I]),
     "iq_debug_chain_occupancy": (_I, []),
     "iq_debug_stamps": (_I, [_I, ctypes.POINTER(ctypes.c_ulonglong)]),
+    "iq_profile_read_work": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
     "iq_profile_read": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
 }
 

@@ -32,6 +32,12 @@ inline hipStream_t as_stream(iq_stream_t s) { return reinterpret_cast<hipStream_
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Bit `rid` of a coalition's keep mask; a region id outside [0, 64) (which iq_check_index_range rejects) is never kept,
+// so an unvalidated id gives a defined result instead of an undefined shift.
+__host__ __device__ inline bool keep_bit(unsigned long long keep, int rid) {
+    return (unsigned)rid < 64u && ((keep >> rid) & 1ull);
+}
+
 }  // namespace iq
 
 #define IQ_REQUIRE(cond, ...) \

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64) void dg_count_kernel(const int32_t* __restrict_
     const uint64_t k = keep[b];
     const int32_t* rid = region_id + (size_t)c * N;
     int n = 0;
-    for (int i = lane; i < N; i += 64) n += (int)((k >> rid[i]) & 1ull);
+    for (int i = lane; i < N; i += 64) n += (int)iq::keep_bit(k, rid[i]);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
     if (lane == 0) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void dg_compact_kernel(const float* __restrict_
     int pos = 0;
     for (int i0 = 0; i0 < N; i0 += 64) {
         const int i = i0 + lane;
-        const bool kept = i < N && ((k >> rid[i]) & 1ull);
+        const bool kept = i < N && iq::keep_bit(k, rid[i]);
         const unsigned long long m = __ballot(kept);
         if (kept) {
             const int row = base + pos + __popcll(m & ((1ull << lane) - 1ull));
@@ -481,6 +481,13 @@ int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, i
         iq::ProfileSpan span(iq::kSlotTrunk, st);
         // conv5 + LeakyReLU with the pooling folded into the GEMM epilogue (s.h holds the per-tile partials)
         IQ_REQUIRE(w->conv5.cout == 1024 && w->conv5.cin == 512, "iq_dgcnn: conv5 must be 512 -> 1024");
+        double work = 0.0;
+        if (iq::profile_enabled()) {  // profiling only: the live row count (one sync); the GEMM issues whole 128-row tiles
+            int32_t n = 0;
+            if (hipMemcpyAsync(&n, live, sizeof(n), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+                work = 2.0 * 512.0 * 1024.0 * (double)((n + 127) / 128 * 128);
+        }
+        iq::ProfileSpan dom(iq::kSlotDominant, st, work);
         if ((rc = iq::launch_linear_pool(s.xc, 512, w->conv5, s.h, rows, 2, s.row_w, st, live))) return rc;
         hipLaunchKernelGGL(pool_reduce_kernel, dim3(1024 / kThreads, B), dim3(kThreads), 0, st, s.h, s.g, rg, N, 1024);
         if ((rc = iq::check_launch("pool_reduce_kernel"))) return rc;

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void region_assign_kernel(const float* __restr
                                                             int32_t* __restrict__ region_id, int N, int R) {
     __shared__ float cs[IQ_MAX_REGIONS * 4];
     if (threadIdx.x < R) {
-        const int c = fps_idx[threadIdx.x];
+        const int c = min(max(fps_idx[threadIdx.x], 0), N - 1);  // out-of-range indices: iq_check_index_range
         const float x = cloud[c * 3], y = cloud[c * 3 + 1], z = cloud[c * 3 + 2];
         cs[threadIdx.x * 4 + 0] = x;
         cs[threadIdx.x * 4 + 1] = y;
@@ -134,6 +134,10 @@ int iq::launch_fps(const float* xyz, int32_t* idx, int32_t* n_unique, int B, int
     if (B == 0) return IQ_OK;
     IQ_REQUIRE(xyz && idx, "iq_fps: null pointer");
     const size_t lds = (size_t)N * 4 * sizeof(float);
+    if (lds > 48 * 1024) {  // above the default dynamic-LDS limit (N > 3072): opt in, up to 128 KB at N = 8192
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return iq::fail(IQ_ELAUNCH, "iq_fps: cannot reserve %zu bytes of LDS for N=%d", lds, N);
+    }
     hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(kFpsThreads), lds, st, xyz, idx, n_unique, N, S);
     return iq::check_launch("fps_kernel");
 }

@@ -4,6 +4,8 @@
 // cloud (12 KB), region ids and centre are re-read from L2 by every workgroup - algorithmic traffic
 // is the 12 288 B written per coalition.  Each lane stores 16 B (float4), consecutive lanes store
 // consecutive addresses.
+#include <algorithm>
+
 #include "iq_common.h"
 
 namespace {
@@ -31,13 +33,13 @@ __device__ inline uint64_t row_keep(const MaskArgs& a, int g) {
         // row i of order o keeps orders[o][0..i-1]  (tools/final_common.py:56-60)
         const int o = g / (a.R + 1), i = g % (a.R + 1);
         uint64_t m = 0;
-        for (int j = 0; j < i; ++j) m |= 1ull << a.orders[o * a.R + j];
+        for (int j = 0; j < i; ++j) m |= 1ull << (a.orders[o * a.R + j] & 63);
         return m;
     }
     // interaction: rows 4k..4k+3 = S+{i,j}, S+{i}, S+{j}, S
     const int k = g >> 2, which = g & 3;
     uint64_t m = a.ctx[k];
-    const uint64_t bi = 1ull << a.pairs[2 * k], bj = 1ull << a.pairs[2 * k + 1];
+    const uint64_t bi = 1ull << (a.pairs[2 * k] & 63), bj = 1ull << (a.pairs[2 * k + 1] & 63);
     if (which == 0) m |= bi | bj;
     if (which == 1) m |= bi;
     if (which == 2) m |= bj;
@@ -73,13 +75,24 @@ __global__ __launch_bounds__(kThreads) void mask_rows_kernel(MaskArgs a) {
             if (g >= a.rows) break;
             const uint64_t m = keep_s[r];
             float4 o;
-            o.x = ((m >> rid[0]) & 1) ? x[0] : c[0];
-            o.y = ((m >> rid[1]) & 1) ? x[1] : c[1];
-            o.z = ((m >> rid[2]) & 1) ? x[2] : c[2];
-            o.w = ((m >> rid[3]) & 1) ? x[3] : c[3];
+            o.x = iq::keep_bit(m, rid[0]) ? x[0] : c[0];
+            o.y = iq::keep_bit(m, rid[1]) ? x[1] : c[1];
+            o.z = iq::keep_bit(m, rid[2]) ? x[2] : c[2];
+            o.w = iq::keep_bit(m, rid[3]) ? x[3] : c[3];
             reinterpret_cast<float4*>(a.out + (size_t)g * cloud_floats)[e4] = o;
         }
     }
+}
+
+// first position whose value lies outside [lo, hi), or 0xffffffff
+__global__ __launch_bounds__(256) void index_range_kernel(const int32_t* __restrict__ idx, size_t count, int lo, int hi,
+                                                          uint32_t* __restrict__ first_bad) {
+    uint32_t bad = 0xffffffffu;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = idx[i];
+        if (v < lo || v >= hi) { bad = (uint32_t)min(i, (size_t)0xfffffffeu); break; }
+    }
+    if (bad != 0xffffffffu) atomicMin(first_bad, bad);
 }
 
 int launch(MaskArgs a, iq_stream_t stream) {
@@ -122,4 +135,21 @@ extern "C" int iq_mask_coalitions(const float* cloud, const int32_t* region_id, 
     MaskArgs a{cloud, region_id, center, out, keep, nullptr, nullptr, nullptr,
                N, IQ_MAX_REGIONS, B, channel_first, kExplicit};
     return launch(a, stream);
+}
+
+extern "C" int iq_check_index_range(const int32_t* idx, size_t count, int lo, int hi, uint32_t* scratch, iq_stream_t stream) {
+    IQ_REQUIRE(scratch && (idx || count == 0), "iq_check_index_range: null pointer");
+    if (count == 0) return IQ_OK;
+    hipStream_t st = iq::as_stream(stream);
+    uint32_t bad = 0xffffffffu;
+    if (hipMemcpyAsync(scratch, &bad, sizeof(bad), hipMemcpyHostToDevice, st) != hipSuccess)
+        return iq::fail(IQ_ELAUNCH, "iq_check_index_range: copy failed");
+    const int grid = (int)std::min<size_t>((count + 255) / 256, 1024);
+    hipLaunchKernelGGL(index_range_kernel, dim3(grid), dim3(256), 0, st, idx, count, lo, hi, scratch);
+    int rc = iq::check_launch("index_range_kernel");
+    if (rc) return rc;
+    if (hipMemcpyAsync(&bad, scratch, sizeof(bad), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return iq::fail(IQ_ELAUNCH, "iq_check_index_range: read-back failed");
+    if (bad != 0xffffffffu) return iq::fail(IQ_EINVAL, "index at position %u is outside [%d, %d)", bad, lo, hi);
+    return IQ_OK;
 }

@@ -472,7 +472,11 @@ int launch_pc_group(const iq_pointconv_sa& sa, PcGroupArgs a, int B, hipStream_t
     dim3 grid((unsigned)((B + 7) / 8 * 8 * a.wgs_per_cloud));
     const int c1 = sa.l2.cin, c2 = sa.l2.cout, c3 = sa.l3.cout;
     if (c1 == 64 && c2 == 64 && c3 == 128) hipLaunchKernelGGL((pc_group_kernel<64, 64, 128>), grid, dim3(kThreads), 0, st, a);
-    else if (c1 == 128 && c2 == 128 && c3 == 256) hipLaunchKernelGGL((pc_group_kernel<128, 128, 256>), grid, dim3(kThreads), 0, st, a);
+    else if (c1 == 128 && c2 == 128 && c3 == 256) {
+        // every group runs all its K members (sums, not maxima: nothing is skipped); MFMA work = the two dense layers
+        iq::ProfileSpan dom(iq::kSlotDominant, st, 2.0 * (double)B * a.S * a.K * ((double)c1 * c2 + (double)c2 * c3));
+        hipLaunchKernelGGL((pc_group_kernel<128, 128, 256>), grid, dim3(kThreads), 0, st, a);
+    }
     else return iq::fail(IQ_EUNSUPPORTED, "pointconv stage %d-%d-%d has no kernel instantiation", c1, c2, c3);
     return iq::check_launch("pc_group_kernel");
 }

@@ -342,7 +342,12 @@ __global__ __launch_bounds__(kThreads) void pn_prepare_kernel(const int32_t* __r
     __shared__ int cnt[IQ_MAX_REGIONS + 1];
     const int cloud = blockIdx.x;
     if (threadIdx.x <= IQ_MAX_REGIONS) cnt[threadIdx.x] = 0;
-    for (int p = threadIdx.x; p < N; p += kThreads) rid[p] = (int16_t)region_id[(size_t)cloud * N + p];
+    for (int p = threadIdx.x; p < N; p += kThreads) {
+        // an id outside [0,R) (rejected by iq_check_index_range; never produced by iq_region_assign) goes to bucket R,
+        // which no coalition keeps: the point counts as masked instead of indexing LDS / the workspace out of bounds
+        const int r = region_id[(size_t)cloud * N + p];
+        rid[p] = (int16_t)((unsigned)r < (unsigned)R ? r : R);
+    }
     __syncthreads();
     for (int p = threadIdx.x; p < N; p += kThreads) atomicAdd(&cnt[rid[p]], 1);
     __syncthreads();
@@ -354,6 +359,7 @@ __global__ __launch_bounds__(kThreads) void pn_prepare_kernel(const int32_t* __r
     if (threadIdx.x <= R) roff[(size_t)cloud * (R + 1) + threadIdx.x] = cnt[threadIdx.x];
     for (int p = threadIdx.x; p < N; p += kThreads) {
         const int r = rid[p];
+        if (r >= R) continue;
         int k = 0;
         for (int q = 0; q < p; ++q) k += (rid[q] == r);   // rank inside the region: ascending point index
         sorted_pts[(size_t)cloud * N + cnt[r] + k] = (uint16_t)p;

@@ -18,6 +18,9 @@
 // Grouped kernel: 64-row chunks -> LDS act1 -> MFMA C1->C2 -> LDS act2 -> MFMA C2->C3 -> group max in
 // registers.  Index-valued steps (ball query) use explicitly rounded arithmetic in the reference's
 // evaluation order.
+#include <algorithm>
+#include <vector>
+
 #include "iq_common.h"
 #include "iq_mfma.h"
 #include "iq_profile.h"
@@ -416,7 +419,24 @@ int launch_group_t(GroupArgs a, int B, hipStream_t st) {
     return iq::check_launch("pn2_group_kernel");
 }
 
-int launch_group(const iq_pn2_scale& sc, GroupArgs a, const int32_t* n_unique, int B, hipStream_t st) {
+// FLOP the MFMA tiles of pn2_group_kernel execute for the block table just built (profiling only: reads the per-cloud block
+// counts back, one sync).  A workgroup owns blocks_per_wg 16-row blocks = chunks of 4; a chunk issues 1 or 2 32-row tiles.
+double group_work(const GroupArgs& a, int B, int c1, int c2, int c3, hipStream_t st) {
+    std::vector<int32_t> nb((size_t)B);
+    if (hipMemcpy2DAsync(nb.data(), sizeof(int32_t), a.block_start + a.S, (size_t)(a.S + 1) * sizeof(int32_t), sizeof(int32_t), (size_t)B,
+                         hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return 0.0;
+    double rows = 0.0;
+    for (int b = 0; b < B; ++b) {
+        for (int j0 = 0; j0 < nb[b]; j0 += a.blocks_per_wg) {
+            const int jend = std::min(nb[b], j0 + a.blocks_per_wg);
+            for (int j = j0; j < jend; j += 4) rows += (jend - j) > 2 ? 64.0 : 32.0;
+        }
+    }
+    return rows * 2.0 * ((double)c1 * c2 + (double)c2 * c3);
+}
+
+int launch_group(const iq_pn2_scale& sc, GroupArgs a, const int32_t* n_unique, int B, hipStream_t st, bool dominant = false) {
     a.w1x = sc.w1x;
     a.w2 = sc.l2.w; a.b2 = sc.l2.b;
     a.w3 = sc.l3.w; a.b3 = sc.l3.b;
@@ -435,7 +455,10 @@ int launch_group(const iq_pn2_scale& sc, GroupArgs a, const int32_t* n_unique, i
     if (c1 == 32 && c2 == 32 && c3 == 64) return launch_group_t<32, 32, 64>(a, B, st);
     if (c1 == 64 && c2 == 64 && c3 == 128) return launch_group_t<64, 64, 128>(a, B, st);
     if (c1 == 64 && c2 == 96 && c3 == 128) return launch_group_t<64, 96, 128>(a, B, st);
-    if (c1 == 128 && c2 == 128 && c3 == 256) return launch_group_t<128, 128, 256>(a, B, st);
+    if (c1 == 128 && c2 == 128 && c3 == 256) {
+        iq::ProfileSpan span(iq::kSlotDominant, st, dominant && iq::profile_enabled() ? group_work(a, B, c1, c2, c3, st) : 0.0);
+        return launch_group_t<128, 128, 256>(a, B, st);
+    }
     return iq::fail(IQ_EUNSUPPORTED, "pointnet2 scale %d-%d-%d has no kernel instantiation", c1, c2, c3);
 }
 
@@ -488,7 +511,7 @@ __global__ void pn2_mask_kernel(const float* __restrict__ clouds, const float* _
     if (t >= B * N) return;
     const int b = t / N, i = t - b * N;
     const int c = cloud_of ? cloud_of[b] : (nclouds == 1 ? 0 : b);
-    const bool kept = (keep[b] >> region_id[(size_t)c * N + i]) & 1ull;
+    const bool kept = iq::keep_bit(keep[b], region_id[(size_t)c * N + i]);
     const float* src = kept ? clouds + ((size_t)c * N + i) * 3 : centers + (size_t)c * 3;
     out[(size_t)t * 3] = src[0]; out[(size_t)t * 3 + 1] = src[1]; out[(size_t)t * 3 + 2] = src[2];
 }
@@ -618,7 +641,7 @@ __global__ __launch_bounds__(kThreads) void pt_gather_kernel(GatherArgs a) {
     const uint64_t k = a.keep[b];
     const int32_t* rid = a.region_id + (size_t)c * a.N;
     const int pi = a.fps[(size_t)b * a.S + s];
-    const int p = ((k >> rid[pi]) & 1ull) ? pi : a.N;
+    const int p = iq::keep_bit(k, rid[pi]) ? pi : a.N;
     const int32_t* mrow = a.map + ((size_t)c * (a.N + 1) + p) * (a.N + 1);
     const int16_t* mem = a.idx + ((size_t)b * a.S + s) * a.K;
     const int n = a.cnt[(size_t)b * a.S + s];
@@ -627,7 +650,7 @@ __global__ __launch_bounds__(kThreads) void pt_gather_kernel(GatherArgs a) {
     bool centre_done = false;
     for (int j = 0; j < n; ++j) {
         const int qi = mem[j];
-        const bool kept = (k >> rid[qi]) & 1ull;
+        const bool kept = iq::keep_bit(k, rid[qi]);
         if (!kept) {
             if (centre_done) continue;              // all masked members are the same point
             centre_done = true;
@@ -768,7 +791,7 @@ int run_pn2(const iq_pointnet2_weights* w, const float* xyz, float* logits, cons
         a.U = s.U + ucol; a.ldu = F1;
         a.out = s.a3 + 3 + col; a.ldo = LD3; a.N = S1; a.S = S2;
         iq::ProfileSpan span(iq::kSlotFstn, st);
-        if ((rc = launch_group(w->sa2[q], a, s.nu2, B, st))) return rc;
+        if ((rc = launch_group(w->sa2[q], a, s.nu2, B, st, true))) return rc;
         col += w->sa2[q].l3.cout;
         ucol += w->sa2[q].l2.cin;
     }

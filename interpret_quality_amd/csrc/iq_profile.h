@@ -5,7 +5,9 @@
 
 namespace iq {
 
-enum ProfileSlot { kSlotPrepool = 0, kSlotFstn = 1, kSlotTrunk = 2, kSlotCall = 3, kSlotMask = 4 };
+// kSlotDominant: the ONE kernel that dominates a model's step (bench.py's per-model roofline), with the FLOP its MFMA tiles
+// execute attached as `work`
+enum ProfileSlot { kSlotPrepool = 0, kSlotFstn = 1, kSlotTrunk = 2, kSlotCall = 3, kSlotMask = 4, kSlotDominant = 5 };
 
 bool profile_enabled();
 
@@ -15,7 +17,7 @@ int tuning(int key);
 
 class ProfileSpan {
   public:
-    ProfileSpan(int which, hipStream_t st);
+    ProfileSpan(int which, hipStream_t st, double work = 0.0);
     ~ProfileSpan();
     ProfileSpan(const ProfileSpan&) = delete;
     ProfileSpan& operator=(const ProfileSpan&) = delete;
@@ -24,6 +26,7 @@ class ProfileSpan {
     int which_;
     hipStream_t st_;
     bool on_;
+    double work_;
     hipEvent_t start_{}, stop_{};
 };
 

@@ -33,7 +33,8 @@ __global__ void shapley_scatter_kernel(const float* __restrict__ v, const int32_
     const int o = t / R, j = t - o * R;
     const float* vo = v + (size_t)o * (R + 1);
     const float dv = vo[j + 1] - vo[j];
-    sv_rows[(size_t)o * R + orders[t]] = (double)dv;
+    const int r = orders[t];
+    if ((unsigned)r < (unsigned)R) sv_rows[(size_t)o * R + r] = (double)dv;  // entries outside [0,R): iq_check_index_range
 }
 
 // Sum over permutations in permutation order, one lane per region: the same sequence of float64

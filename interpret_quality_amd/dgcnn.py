@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, hip_ops
 from .pointnet import BN_EPS, _np
 
 CONVS = [(6, 64), (128, 64), (128, 128), (256, 256)]  # models/dgcnn.py:66-77
@@ -162,8 +162,10 @@ class _GraphCnn(nn.Module):
         """x (B,3,N) as in the reference -> logits (B,10)."""
         return self.forward_points(x.permute(0, 2, 1).contiguous())
 
-    def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None, num_regions=None):
+    def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None, num_regions=None, validate=True):
         """Same call as PointNetCls.coalition_logits: logits of B coalitions given as region bit masks."""
+        if validate:
+            hip_ops.check_index_range(region_id, 0, int(num_regions) if num_regions else 64, "region_id")
         eng = self.engine()
         step = self.max_clouds_per_call
         nc, b = clouds.shape[0], keep.shape[0]

@@ -32,9 +32,22 @@ def init_from_env(device_type="cuda"):
     rehearsal = os.environ.get("IQ_REHEARSAL") == "1"
     if rehearsal:
         lr = 0
-    if w > 1 and not dist.is_initialized():
+    # IQ_FORCE_DIST=1: create the process group even for a single rank, so that the RCCL communicator, the barrier and
+    # the all-gather of the N > 1 path are exercised on a one-GPU box (a world of 1 is otherwise collective-free).
+    if (w > 1 or force_dist()) and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl" if device_type == "cuda" and not rehearsal else "gloo", rank=r, world_size=w)
     return r, w, lr
+
+
+def force_dist():
+    return os.environ.get("IQ_FORCE_DIST") == "1"
+
+
+def collectives_on():
+    """True when results travel through the collectives: more than one rank, or a forced single-rank group."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_dist())
 
 
 def shard_range(n, r=None, w=None):
@@ -56,15 +69,37 @@ def all_gather_rows(t, n_total):
     """Each rank holds rows shard_range(n_total) of a (n_total, ...) tensor; returns the full tensor
     on every rank.  Pads to equal chunks for a single all_gather."""
     w = world()
-    if w == 1:
+    if not collectives_on():
         return t
     counts = shard_counts(n_total, w)
     cap = max(counts)
-    pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    pad[:t.shape[0]] = t
-    out = [torch.empty_like(pad) for _ in range(w)]
-    dist.all_gather(out, pad)
-    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+    tail = tuple(t.shape[1:])
+    if t.shape[0] == cap:
+        pad = t.contiguous()
+    else:
+        pad = torch.zeros((cap,) + tail, dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
+    # ONE preallocated (w * cap, ...) receive buffer: all_gather_into_tensor writes every rank's chunk in place (the
+    # list form of all_gather costs an extra copy per rank on RCCL, and these payloads are latency-bound)
+    out = torch.empty((w * cap,) + tail, dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, pad)
+    if all(c == cap for c in counts):
+        return out
+    return torch.cat([out[r * cap:r * cap + c] for r, c in enumerate(counts)], dim=0)
+
+
+def num_classes_of(model, default=10):
+    """Class count of a model's logits (the trailing dimension an empty shard must still agree on)."""
+    for obj in (model, getattr(model, "weights", None)):
+        n = getattr(obj, "num_classes", None) or getattr(obj, "output_channels", None)
+        if n:
+            return int(n)
+    sd = getattr(model, "state_dict", None)
+    if sd is not None:
+        last = [v for k, v in sd().items() if k.endswith("weight") and v.dim() == 2]
+        if last:
+            return int(last[-1].shape[0])
+    return default
 
 
 def sharded_rows(n_total, compute_fn):
@@ -75,5 +110,32 @@ def sharded_rows(n_total, compute_fn):
 
 
 def barrier():
-    if world() > 1:
+    if collectives_on():
         dist.barrier()
+
+
+def record(fn):
+    """Decorator for the stage scripts' main(): under a multi-rank launch a failing rank's exception (with its traceback)
+    goes to torchrun's error file and to stderr BEFORE the launcher tears the other ranks down, so the cause of a child
+    death is on record (torch.distributed.elastic's ``record``; a plain call otherwise)."""
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return fn
+    try:
+        from torch.distributed.elastic.multiprocessing.errors import record as _record
+    except ImportError:
+        return fn
+    import functools
+    import sys
+    import traceback
+
+    recorded = _record(fn)
+
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        try:
+            return recorded(*a, **k)
+        except BaseException:
+            sys.stderr.write("[rank %s] stage failed:\n%s\n" % (os.environ.get("RANK", "?"), traceback.format_exc()))
+            sys.stderr.flush()
+            raise
+    return wrapper

@@ -38,7 +38,8 @@ def mask_data_batch(masked_data, center, orders, region_id, args):
     R*bs index assignments."""
     dev = masked_data.device
     cloud = masked_data[-1].clone()  # the last row of a block is never masked
-    out = hip_ops.mask_shapley(cloud, hip_ops.as_i32(region_id, dev), hip_ops.as_i32(np.asarray(orders), dev),
+    hip_ops.check_host_indices(np.asarray(orders), 0, args.num_regions, "orders")
+    out = hip_ops.mask_shapley(cloud, hip_ops.region_ids(region_id, dev, args.num_regions), hip_ops.as_i32(np.asarray(orders), dev),
                                center.contiguous(), channel_first=False)
     masked_data.copy_(out)
     return masked_data
@@ -46,6 +47,7 @@ def mask_data_batch(masked_data, center, orders, region_id, args):
 
 def prefix_keep_masks(orders, num_regions):
     """(S,R) permutations -> (S*(R+1),) uint64 keep masks: row i of order o keeps orders[o][:i]."""
+    hip_ops.check_host_indices(orders, 0, num_regions, "orders")
     orders = np.asarray(orders, dtype=np.uint64)
     bits = np.left_shift(np.uint64(1), orders)                       # (S,R)
     pref = np.concatenate([np.zeros((orders.shape[0], 1), dtype=np.uint64),
@@ -72,13 +74,13 @@ def shapley_logits(model, data, lbl, region_id, orders, args, center=None):
     r = args.num_regions
     if center is None:
         center = torch.mean(data, dim=1)  # (1,3), tools/final_common.py:80
-    rid = hip_ops.as_i32(region_id, dev)
+    rid = hip_ops.region_ids(region_id, dev, r)   # validated here: the model calls below skip their own check
     uniq, inv = distinct_coalitions(prefix_keep_masks(orders, r))
     inv_t = torch.from_numpy(inv.astype(np.int64)).to(dev)
     keep = hip_ops.masks_to_tensor(uniq, dev)
     if hasattr(model, "coalition_logits"):
         logits = model.coalition_logits(data.contiguous(), center.reshape(1, 3).contiguous(), rid.reshape(1, -1),
-                                        keep, None, num_regions=r)
+                                        keep, None, num_regions=r, validate=False)
         return logits.index_select(0, inv_t)
     # config.py's knob is a floor: rows are independent in eval mode, so larger launches give the same logits
     # (stage 1 sets no batch size: the reference evaluates one permutation per forward there, final_shapley_value.py:138-144)

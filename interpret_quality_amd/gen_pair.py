@@ -169,6 +169,7 @@ def save_pred_label(args, disturb_fn, folder_name_list):
                 gen_pred_label(model, data, lbl, disturb_fn, region_folder + "min_pose/", args)
 
 
+@iqdist.record
 def main(argv=None):
     """final_gen_pair.py:323-374, same flags and stage order."""
     p = argparse.ArgumentParser(description="Point Cloud Recognition")

@@ -34,6 +34,37 @@ def as_i32(x, device):
     return x.to(device=device, dtype=torch.int32).contiguous()
 
 
+def check_index_range(t, lo, hi, what):
+    """Raise IqError unless every entry of the int32 device tensor ``t`` lies in [lo, hi) (iq_check_index_range; the one
+    call that synchronises the stream).  The kernels never fault on a bad id, but their results are then meaningless."""
+    lib = _lib.load()
+    if t.numel() == 0:
+        return
+    scratch = torch.empty((1,), dtype=torch.int32, device=t.device)
+    rc = lib.iq_check_index_range(_dev(t, torch.int32, what), t.numel(), int(lo), int(hi), _p(scratch), _stream())
+    if rc != 0:
+        msg = lib.iq_last_error()
+        raise _lib.IqError("%s: %s" % (what, msg.decode() if msg else "index out of range"))
+
+
+def check_host_indices(arr, lo, hi, what):
+    """The same check for indices that are still on the host (region_id.npy, all_orders.npy, pair lists): free."""
+    a = np.asarray(arr)
+    if a.size and (a.min() < lo or a.max() >= hi):
+        bad = int(np.flatnonzero((a.reshape(-1) < lo) | (a.reshape(-1) >= hi))[0])
+        raise _lib.IqError("%s: index at position %d is outside [%d, %d)" % (what, bad, lo, hi))
+
+
+def region_ids(region_id, device, num_regions):
+    """Region ids of one cloud (ndarray from region_id.npy, or a tensor) -> validated int32 device tensor."""
+    if isinstance(region_id, np.ndarray):
+        check_host_indices(region_id, 0, num_regions, "region_id")
+        return as_i32(region_id, device)
+    t = as_i32(region_id, device)
+    check_index_range(t, 0, num_regions, "region_id")
+    return t
+
+
 def region_bitmask(regions):
     """Iterable of region ids -> python int bit mask."""
     m = 0

@@ -25,13 +25,15 @@ from .shapley_stage import data_loader, finish_args
 DEFAULT_RATIOS = [0., 0.04, 0.07, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.]  # :153
 
 
-def context_keep_masks(region_pair_list, context_list):
+def context_keep_masks(region_pair_list, context_list, num_regions=64):
     """(P,2) pairs and (P,C,m) contexts -> (P*C*4,) uint64 keep masks in the reference's row order
     4k: S+{i,j}, 4k+1: S+{i}, 4k+2: S+{j}, 4k+3: S (final_point_binary_interaction_logits.py:48-52).
     m = 0 gives the empty context (np.in1d(region_id, []) is all False)."""
     pairs = np.asarray(region_pair_list, dtype=np.int64).reshape(-1, 2)
     ctx = np.asarray(context_list, dtype=np.int64)
     p, c = ctx.shape[0], ctx.shape[1]
+    hip_ops.check_host_indices(pairs, 0, num_regions, "region_pair_list")
+    hip_ops.check_host_indices(ctx, 0, num_regions, "context_list")
     one = np.uint64(1)
     if ctx.shape[2] > 0:
         s = np.bitwise_or.reduce(np.left_shift(one, ctx.astype(np.uint64)), axis=2)  # (P,C)
@@ -56,15 +58,15 @@ def compute_order_interaction_logits(model, data_disturb, region_id, region_pair
     num_context = ctx.shape[1] if ctx.ndim >= 2 else 0
     lo, hi = iqdist.shard_range(num_pairs)
     center = torch.mean(data_disturb, dim=1)  # (1,3), :32
-    rid = hip_ops.as_i32(region_id, dev)
+    rid = hip_ops.region_ids(region_id, dev, r)
     with torch.no_grad():
         if hi > lo:
             # equal sets are equal clouds (few-region contexts repeat a lot): evaluate the distinct ones once
-            keep_np, inv = final_common.distinct_coalitions(context_keep_masks(pairs[lo:hi], ctx[lo:hi]))
+            keep_np, inv = final_common.distinct_coalitions(context_keep_masks(pairs[lo:hi], ctx[lo:hi], r))
             inv_t = torch.from_numpy(inv.astype(np.int64)).to(dev)
             if hasattr(model, "coalition_logits"):
                 logits = model.coalition_logits(data_disturb.contiguous(), center.contiguous(), rid.reshape(1, -1),
-                                                hip_ops.masks_to_tensor(keep_np, dev), None, num_regions=r)
+                                                hip_ops.masks_to_tensor(keep_np, dev), None, num_regions=r, validate=False)
             else:
                 # config.py's knob is a floor: rows are independent in eval mode, larger launches give the same logits
                 bs = max(4 * args.interaction_batch_size, getattr(model, "preferred_clouds_per_call", 0))
@@ -78,7 +80,7 @@ def compute_order_interaction_logits(model, data_disturb, region_id, region_pair
                 logits = torch.cat(chunks, dim=0)
             logits = logits.index_select(0, inv_t).reshape(hi - lo, 4 * num_context, -1)
         else:
-            logits = torch.zeros((0, 4 * num_context, 10), dtype=torch.float32, device=dev)
+            logits = torch.zeros((0, 4 * num_context, iqdist.num_classes_of(model)), dtype=torch.float32, device=dev)
         all_logits = iqdist.all_gather_rows(logits, num_pairs)
     print("shape of all_logits: ", all_logits.size())
     print("done time: ", time.time() - t0)
@@ -204,6 +206,7 @@ def build_parser(with_cal_flags):
     return p
 
 
+@iqdist.record
 def main_logits(argv=None):
     args = build_parser(False).parse_args(argv)
     args.softmax_type = "modified"
@@ -212,6 +215,7 @@ def main_logits(argv=None):
     save_logits(args, disturb_fn=translate_pc if args.mode == "trans" else rotate_xyz)
 
 
+@iqdist.record
 def main_cal(argv=None):
     args = build_parser(True).parse_args(argv)
     finish_args(args)

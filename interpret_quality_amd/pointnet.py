@@ -15,7 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, hip_ops
 
 BN_EPS = 1e-5
 
@@ -214,5 +214,9 @@ class PointNetCls(nn.Module):
         logits, trans_feat = self.engine().forward(x)
         return logits, trans_feat, None
 
-    def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None, num_regions=None):
+    def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None, num_regions=None, validate=True):
+        """``validate``: check region_id against [0, num_regions) first (one stream sync); the drivers validate the ids
+        once per cloud on the host and pass False."""
+        if validate:
+            hip_ops.check_index_range(region_id, 0, int(num_regions), "region_id")
         return self.engine().coalition_logits(clouds, centers, region_id, keep, cloud_of, num_regions=num_regions)

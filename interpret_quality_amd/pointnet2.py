@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, hip_ops
 from .pointnet import BN_EPS, _np
 
 SA1 = dict(npoint=512, radius=[0.1, 0.2, 0.4], nsample=[16, 32, 128], in_channel=0,
@@ -198,9 +198,11 @@ class PointNet2ClsMsg(nn.Module):
         """xyz (B,3,N) as in the reference -> logits (B,10)."""
         return self.forward_points(xyz.permute(0, 2, 1).contiguous())
 
-    def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None, num_regions=None):
+    def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None, num_regions=None, validate=True):
         """Same call as PointNetCls.coalition_logits: logits of B coalitions given as region bit masks (sa1 from the
         per-cloud pair tables, csrc/iq_pointnet2.hip)."""
+        if validate:
+            hip_ops.check_index_range(region_id, 0, int(num_regions) if num_regions else 64, "region_id")
         eng = self.engine()
         step = self.max_clouds_per_call
         nc, b = clouds.shape[0], keep.shape[0]

@@ -117,7 +117,7 @@ def shapley_over_poses(model, poses, lbl, region_id, orders, args, pose_batch=8)
         raise final_common.IqError("shapley_batch_size=%d does not divide num_samples=%d" % (args.shapley_batch_size, s))
     orders = np.asarray(orders[:s])
     orders_dev = hip_ops.as_i32(orders, dev)
-    rid = hip_ops.as_i32(region_id, dev)
+    rid = hip_ops.region_ids(region_id, dev, r)
     p = poses.shape[0]
     per = s * (r + 1)
     phis, all_logits = [], []
@@ -136,7 +136,7 @@ def shapley_over_poses(model, poses, lbl, region_id, orders, args, pose_batch=8)
             keep = hip_ops.masks_to_tensor(np.tile(uniq, nb), dev)
             cloud_of = torch.arange(nb, dtype=torch.int32, device=dev).repeat_interleave(nu).contiguous()
             logits = model.coalition_logits(clouds, centers, rid.reshape(1, -1).expand(nb, -1).contiguous(), keep,
-                                            cloud_of, num_regions=r)
+                                            cloud_of, num_regions=r, validate=False)
             logits = logits.reshape(nb, nu, -1).index_select(1, inv_t).reshape(nb * per, -1)
             v = final_common.get_reward(logits, lbl, args)
             for k in range(nb):
@@ -150,9 +150,24 @@ def shapley_over_poses(model, poses, lbl, region_id, orders, args, pose_batch=8)
             phi_sum, _, _ = hip_ops.shapley_accum(v, orders_dev)
             phis.append(phi_sum / s)
             all_logits.append(logits.unsqueeze(0))
-    if p == 0:
-        return torch.zeros((0, r), dtype=torch.float64, device=dev), torch.zeros((0, per, 10), device=dev)
+    if p == 0:  # an empty shard still has to agree with the others on the trailing shape of the gather
+        return (torch.zeros((0, r), dtype=torch.float64, device=dev),
+                torch.zeros((0, per, iqdist.num_classes_of(model)), dtype=torch.float32, device=dev))
     return torch.stack(phis, dim=0), torch.cat(all_logits, dim=0)
+
+
+def sharded_shapley(model, data, poses, lbl, region_id, orders, args):
+    """Region Shapley values of the original cloud ``data`` (1,N,3) and of its perturbed copies ``poses`` (P,N,3), the
+    P + 1 clouds sharded over the ranks (the original pose travels as pose 0 of the batch, so no rank repeats it) and
+    gathered once.  Returns (orig (R,) float64 ndarray, phi (P,R) float64 tensor, logits (P, S*(R+1), C)), the same on
+    every rank.  A cloud's values do not depend on the batch or shard it travels in (tested bitwise)."""
+    allp = torch.cat([data.reshape(1, -1, 3), poses.reshape(-1, data.shape[1], 3)], dim=0)
+    n = allp.shape[0]
+    lo, hi = iqdist.shard_range(n)
+    phi, logits = shapley_over_poses(model, allp[lo:hi].contiguous(), lbl, region_id, orders, args)
+    phi = iqdist.all_gather_rows(phi, n)          # one gather per cloud
+    logits = iqdist.all_gather_rows(logits, n)
+    return phi[0].cpu().numpy(), phi[1:], logits[1:]
 
 
 def test(args, get_transform_params_fn, disturb_fn, print_info_fn, save_info_fn):
@@ -175,15 +190,10 @@ def test(args, get_transform_params_fn, disturb_fn, print_info_fn, save_info_fn)
 
         t_start = time.time()
         with torch.no_grad():
-            orig, _ = final_common.shap_sampling_all_regions_batch(model, data, lbl, region_id, load_order_list, args)
             all_params = get_transform_params_fn(args, data.device)
             n_pose = all_params.size()[0]
-            lo, hi = iqdist.shard_range(n_pose)
-            mine = [disturb_fn(data, all_params[i]) for i in range(lo, hi)]
-            poses = torch.cat(mine, dim=0) if mine else torch.zeros((0,) + tuple(data.shape[1:]), device=data.device)
-            phi, logits = shapley_over_poses(model, poses, lbl, region_id, load_order_list, args)
-            phi = iqdist.all_gather_rows(phi, n_pose)          # one gather per cloud
-            logits = iqdist.all_gather_rows(logits, n_pose)
+            poses = torch.cat([disturb_fn(data, all_params[i]) for i in range(n_pose)], dim=0)
+            orig, phi, logits = sharded_shapley(model, data, poses, lbl, region_id, load_order_list, args)
         if write:
             io.cprint("origin region shapley: %s" % str(orig))
             np.save(mode_folder + "orig_shapley_value.npy", orig)
@@ -197,6 +207,7 @@ def test(args, get_transform_params_fn, disturb_fn, print_info_fn, save_info_fn)
             io.close()
 
 
+@iqdist.record
 def _main(mode, argv=None):
     default_model = {"trans": "gcnn_adv", "rotate": "pointconv", "scale": "pointconv"}[mode]
     args = build_parser(default_model).parse_args(argv)

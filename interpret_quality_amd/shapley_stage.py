@@ -172,8 +172,17 @@ def finish_args(args):
     args.exp_folder = exp_folder(args)
     _, world, local_rank = iqdist.init_from_env("cuda")
     if world == 1:
-        os.environ.setdefault("HIP_VISIBLE_DEVICES", str(args.device_id))  # CUDA_VISIBLE_DEVICES of the reference
-        local_rank = 0
+        # CUDA_VISIBLE_DEVICES = device_id in the reference (final_shapley_value.py:192-193).  When the launcher has
+        # already restricted the visible devices, or device_id names a GPU this box does not have (the reference's
+        # final_cal_interactions.py defaults to 1), device_id is mapped onto the visible devices instead of hiding every GPU.
+        n_dev = torch.cuda.device_count()  # does not initialise the GPU
+        if "HIP_VISIBLE_DEVICES" in os.environ or "CUDA_VISIBLE_DEVICES" in os.environ or args.device_id >= n_dev:
+            local_rank = args.device_id % max(n_dev, 1)
+            if local_rank != args.device_id:
+                print("warning: --device_id %d is not among the %d visible device(s); using device %d" % (args.device_id, n_dev, local_rank))
+        else:
+            os.environ["HIP_VISIBLE_DEVICES"] = str(args.device_id)
+            local_rank = 0
     if args.no_cuda or not torch.cuda.is_available():
         raise SystemExit("this build has no CPU path: a GPU is required (the reference's --no_cuda is not supported)")
     torch.cuda.set_device(local_rank)
@@ -187,6 +196,7 @@ def finish_args(args):
     return args
 
 
+@iqdist.record
 def main(argv=None):
     parser = build_parser()
     parser.add_argument("--num_samples_save", type=int, default=NUM_SAMPLES_SAVE)  # additive

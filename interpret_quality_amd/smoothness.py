@@ -28,7 +28,7 @@ import torch
 from . import dist as iqdist
 from . import final_common, hip_ops
 from .final_util import NUM_SAMPLES, IOStream, get_folder_name_list, load_model, mkdir, set_shapley_batch_size
-from .pose_sweep import shapley_over_poses
+from .pose_sweep import sharded_shapley
 from .shapley_stage import build_parser, data_loader, finish_args
 
 STEP = 1e-3            # final_smoothness_center_enum_all.py:13-19
@@ -44,7 +44,7 @@ def enumerate_smoothness(data, region_id, args, objective):
     """The epoch loop of test_all_region (:303-335) without its Shapley calls.  data (1,N,3) GPU tensor ->
     (poses (P,N,3) f32 GPU tensor, smoothness (P,R) f64 ndarray, raw kernel outputs)."""
     dev = data.device
-    res = hip_ops.smoothness_enum(data[0].contiguous(), hip_ops.as_i32(region_id, dev), args.num_regions, args.mode, objective,
+    res = hip_ops.smoothness_enum(data[0].contiguous(), hip_ops.region_ids(region_id, dev, args.num_regions), args.num_regions, args.mode, objective,
                                   step=args.step, enum_step=args.enum_step, var_threshold=args.var_threshold,
                                   dist_threshold=args.dist_threshold, stop_ratio=args.stop_ratio, epochs=args.epoch,
                                   max_iteration=args.max_iteration)
@@ -87,13 +87,9 @@ def test_all_region(model, data, lbl, load_order_list, region_id, mode_folder, a
         io = IOStream(result_path + "log.txt")
         io.cprint(str(args))
     with torch.no_grad():
-        orig_shap_value, _ = final_common.shap_sampling_all_regions_batch(model, data, lbl, region_id, load_order_list, args)
         poses, smoothness_list, res = enumerate_smoothness(data, region_id, args, objective)
         n_pose = poses.shape[0]
-        lo, hi = iqdist.shard_range(n_pose)
-        phi, logits = shapley_over_poses(model, poses[lo:hi].contiguous(), lbl, region_id, load_order_list, args)
-        phi = iqdist.all_gather_rows(phi, n_pose)
-        logits = iqdist.all_gather_rows(logits, n_pose)
+        orig_shap_value, phi, logits = sharded_shapley(model, data, poses, lbl, region_id, load_order_list, args)
     if write:
         io.cprint("origin shapley of this region: %s" % str(orig_shap_value))
         np.save(result_path + "orig_shapley_value.npy", orig_shap_value)
@@ -123,6 +119,7 @@ def test_smoothness(args):
         test_all_region(model, data, lbl, load_order_list, region_id, mode_folder, args, objective="dec")
 
 
+@iqdist.record
 def main(argv=None):
     args = build_parser("pointnet").parse_args(argv)
     args.num_samples = NUM_SAMPLES

@@ -338,3 +338,62 @@ def test_set_abstraction_models_on_a_cloud_size_that_is_not_a_multiple_of_32(nam
     got = m(x.to(dev()))
     got = (got[0] if isinstance(got, tuple) else got).cpu().numpy()
     assert np.abs(got - want).max() / np.abs(want).max() < 1e-4
+
+
+def test_out_of_range_region_ids_and_orders_are_rejected_and_never_fault(model):
+    """an id >= R or < 0 (a stale region_id.npy, a wrong num_regions) used to index LDS / the workspace out of
+    bounds.  Now (a) iq_check_index_range names the first bad position, (b) every Python entry point that takes ids runs it
+    (or its host twin), (c) the kernels themselves treat such a point as belonging to no region: no fault, finite output."""
+    lib = _lib.load()
+    d = dev()
+    pts, _ = synth.make_cloud(2)
+    data = torch.from_numpy(pts).unsqueeze(0).to(d)
+    center = torch.mean(data, dim=1)
+    rid = hip_ops.region_assign(data[0].contiguous(), hip_ops.fps(data, 8)[0].contiguous())
+    hip_ops.check_index_range(rid, 0, 8, "region_id")                      # valid
+    bad = rid.clone()
+    bad[517] = 8
+    bad[900] = -3
+    with pytest.raises(_lib.IqError, match="position 517"):
+        hip_ops.check_index_range(bad, 0, 8, "region_id")
+    keep = hip_ops.masks_to_tensor([0, 0x0f, 0xff], d)
+    for m_name in ("pointnet",):
+        with pytest.raises(_lib.IqError, match="position 517"):
+            model.coalition_logits(data, center, bad.reshape(1, -1), keep, None, num_regions=8)
+    # the raw ABI with the same ids: no fault; the two bad points count as masked in every coalition
+    got = model.coalition_logits(data, center, bad.reshape(1, -1), keep, None, num_regions=8, validate=False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    pts2 = pts.copy()
+    pts2[[517, 900]] = center[0].cpu().numpy()                              # = those two points moved onto the centre
+    ok_rid = rid.clone()
+    want = model.coalition_logits(torch.from_numpy(pts2).unsqueeze(0).to(d), center, ok_rid.reshape(1, -1), keep[:2].contiguous(),
+                                  None, num_regions=8)
+    assert torch.allclose(got[:2], want, rtol=1e-4, atol=1e-5)              # coalitions that mask something: same clouds
+    # host-side twins used by the drivers for ids read from files
+    with pytest.raises(_lib.IqError, match="region_id"):
+        hip_ops.region_ids(bad.cpu().numpy().astype(np.int64), d, 8)
+    from interpret_quality_amd import final_common, interaction
+    with pytest.raises(_lib.IqError, match="orders"):
+        final_common.prefix_keep_masks(np.array([[0, 1, 9]]), 8)
+    with pytest.raises(_lib.IqError, match="region_pair_list"):
+        interaction.context_keep_masks(np.array([[0, 8]]), np.zeros((1, 1, 0), dtype=np.int64), 8)
+    # mask kernels and the accumulation with bad entries: defined, in-bounds
+    orders = torch.tensor([[0, 1, 2, 3, 4, 5, 6, 77]], dtype=torch.int32, device=d)
+    out = hip_ops.mask_shapley(data[0].contiguous(), bad, orders, center.reshape(3).contiguous())
+    v = torch.arange(9, dtype=torch.float32, device=d)
+    phi, rows, _ = hip_ops.shapley_accum(v, orders)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and float(phi.sum().item()) == 7.0    # the 8th difference has nowhere to go
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_fps_at_the_advertised_maximum_cloud_size(n):
+    """iq_fps accepts N <= 8192 (16 N bytes of dynamic LDS: 64 KB at 4096, 128 KB at 8192 - above the default limit, so the
+    launch opts in).  Checked against the oracle on a 2-cloud batch."""
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((2, n, 3)).astype(np.float32)
+    got = hip_ops.fps(torch.from_numpy(x).to(dev()), 64).cpu().numpy()
+    want = O.farthest_point_sample(torch.from_numpy(x), 64).numpy()
+    assert np.array_equal(got, want)
