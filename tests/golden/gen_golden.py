@@ -20,10 +20,11 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
-sys.path.insert(0, REPO)
-sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
+import _refenv  # noqa: E402
 
-from interpret_quality_amd import synth  # noqa: E402
+synth = _refenv.setup()   # the reference first on sys.path, the repository root (its `tools/` shims) off it
+
 
 # ---- the reference, imported as-is --------------------------------------------------------
 from tools import final_common as ref_common  # noqa: E402

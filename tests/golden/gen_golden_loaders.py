@@ -13,10 +13,11 @@ import tempfile
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-sys.path.insert(0, "/root/reference")
+sys.path.insert(0, HERE)
+import _refenv  # noqa: E402
 
-from interpret_quality_amd import synth  # noqa: E402
+synth = _refenv.setup()   # the reference first on sys.path, the repository root (its `tools/` shims) off it
+
 import final_data_shapley as ref_data  # noqa: E402
 from tools import final_util as ref_util  # noqa: E402
 

@@ -12,10 +12,11 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-sys.path.insert(0, "/root/reference")
+sys.path.insert(0, HERE)
+import _refenv  # noqa: E402
 
-from interpret_quality_amd import synth  # noqa: E402
+synth = _refenv.setup()   # the reference first on sys.path, the repository root (its `tools/` shims) off it
+
 from models import pointconv as ref_pc  # noqa: E402
 from tools import final_common as ref_common  # noqa: E402
 import final_shapley_value as ref_stage1  # noqa: E402

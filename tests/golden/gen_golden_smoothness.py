@@ -16,13 +16,14 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-sys.path.insert(0, "/root/reference")
+sys.path.insert(0, HERE)
+import _refenv  # noqa: E402
+
+synth = _refenv.setup()   # the reference first on sys.path, the repository root (its `tools/` shims) off it
 
 # torch 2.x keeps the name only as a stub that raises "removed"
 torch.symeig = lambda a, eigenvectors=True: torch.linalg.eigh(a)  # noqa: E731
 
-from interpret_quality_amd import synth  # noqa: E402
 import final_smoothness_center_enum_all as ref  # noqa: E402
 import final_shapley_value as ref_stage1  # noqa: E402
 import final_save_fps as ref_fps  # noqa: E402

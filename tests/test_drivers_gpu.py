@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import assert_close_elementwise, load_golden
 from interpret_quality_amd import final_common, hip_ops, interaction, pose_sweep, shapley_stage, synth
 from interpret_quality_amd.pointnet import PointNetCls
 
@@ -55,6 +55,7 @@ def test_shap_sampling_all_regions_batch_matches_reference(model, num_regions):
         phi, logits = final_common.shap_sampling_all_regions_batch(model, data, lbl, g[p + "region_id"], g[p + "orders"], args)
         assert isinstance(phi, np.ndarray) and phi.dtype == np.float64 and phi.shape == (num_regions,)
         assert rel_err(logits.cpu().numpy(), g[p + "logits"]) < RTOL
+        assert_close_elementwise(logits.cpu().numpy(), g[p + "logits"])   # and element-wise, with an absolute floor (conftest.py)
         assert np.abs(phi - g[p + "phi"]).max() < RTOL * np.abs(g[p + "phi"]).max()
     bad = ns(num_regions=num_regions, num_samples=8, shapley_batch_size=3)
     with pytest.raises(Exception):
@@ -76,6 +77,7 @@ def test_mask_data_batch_inplace_and_cal_reward(model, oracle):
     assert torch.equal(m1.cpu(), want[:33])
     v, logits = final_common.cal_reward(model, masked, torch.tensor([label], device=dev()), ns())
     assert rel_err(v.cpu().numpy(), g["c0_v_batch0"]) < RTOL
+    assert_close_elementwise(v.cpu().numpy(), g["c0_v_batch0"])   # and element-wise, with an absolute floor (conftest.py)
 
 
 def test_shapley_over_poses_matches_oracle(model, oracle, pointnet_sd):
@@ -94,6 +96,7 @@ def test_shapley_over_poses_matches_oracle(model, oracle, pointnet_sd):
     for k, pose in enumerate(poses):
         o_phi, o_logits = oracle.shap_sampling_all_regions_batch(om, pose, lbl, region_id, orders, s, 2, num_regions)
         assert rel_err(logits[k].cpu().numpy(), o_logits.numpy()) < RTOL
+        assert_close_elementwise(logits[k].cpu().numpy(), o_logits.numpy())   # and element-wise, with an absolute floor (conftest.py)
         assert np.abs(phi[k].cpu().numpy() - o_phi).max() < RTOL * np.abs(o_phi).max()
     # device-side perturbations agree with the oracle's
     assert rel_err(pose_sweep.rotate_xyz(data.to(dev()), torch.tensor([0.3, -0.2, 0.6], device=dev())).cpu().numpy(),
@@ -110,6 +113,7 @@ def test_interaction_functions_match_reference(model):
         logits = interaction.compute_order_interaction_logits(model, data, g["region_id"], g["pairs"], g[tag + "_contexts"], args)
         assert logits.shape == g[tag + "_logits"].shape
         assert rel_err(logits.cpu().numpy(), g[tag + "_logits"]) < RTOL
+        assert_close_elementwise(logits.cpu().numpy(), g[tag + "_logits"])   # and element-wise, with an absolute floor (conftest.py)
         inter = interaction.compute_order_interaction(torch.from_numpy(g[tag + "_logits"]).to(dev()), lbl, args)
         assert inter.dtype == np.float64
         np.testing.assert_allclose(inter, g[tag + "_interaction"], rtol=0, atol=2e-6)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import assert_close_elementwise, load_golden
 from interpret_quality_amd import hip_ops, synth
 from interpret_quality_amd.pointnet import PointNetCls
 
@@ -199,9 +199,12 @@ def test_pointnet_dense_forward(model, oracle, pointnet_sd):
     x = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in range(4)]).permute(0, 2, 1).contiguous()
     logits, trans_feat, _ = model(x.to(dev()))
     assert rel_err(logits.cpu().numpy(), g["logits"]) < RTOL
+    assert_close_elementwise(logits.cpu().numpy(), g["logits"])   # and element-wise, with an absolute floor (conftest.py)
     o_logits, o_tf, _ = oracle.PointNetOracle(pointnet_sd)(x)
     assert rel_err(trans_feat.cpu().numpy(), o_tf.numpy()) < RTOL
+    assert_close_elementwise(trans_feat.cpu().numpy(), o_tf.numpy())   # and element-wise, with an absolute floor (conftest.py)
     assert rel_err(logits.cpu().numpy(), o_logits.numpy()) < RTOL
+    assert_close_elementwise(logits.cpu().numpy(), o_logits.numpy())   # and element-wise, with an absolute floor (conftest.py)
 
 
 @pytest.mark.parametrize("num_regions", [8, 32])
@@ -223,6 +226,7 @@ def test_pointnet_coalitions_vs_golden_and_oracle(model, oracle, num_regions):
         logits = model.coalition_logits(data.to(d), center.to(d), hip_ops.as_i32(g[p + "region_id"], d).reshape(1, -1),
                                         hip_ops.masks_to_tensor(keep, d), None, num_regions=num_regions)
         assert rel_err(logits.cpu().numpy(), g[p + "logits"]) < RTOL
+        assert_close_elementwise(logits.cpu().numpy(), g[p + "logits"])   # and element-wise, with an absolute floor (conftest.py)
         v = hip_ops.reward(logits, label, True)
         phi, _, _ = hip_ops.shapley_accum(v, hip_ops.as_i32(orders, d))
         phi = phi.cpu().numpy() / ns
@@ -264,6 +268,7 @@ def test_pointnet_interaction_vs_golden(model):
                                         num_regions=32)
         want = g[tag + "_logits"].reshape(-1, 10)
         assert rel_err(logits.cpu().numpy(), want) < RTOL
+        assert_close_elementwise(logits.cpu().numpy(), want)   # and element-wise, with an absolute floor (conftest.py)
 
 
 def test_pointnet_multi_cloud_batch(model, oracle):

@@ -230,3 +230,31 @@ def test_reference_import_paths_resolve_to_this_build():
     assert np.allclose(d, ((x[:, None] - x[None]) ** 2).sum(-1)) and fu.ball_query(x, 10.0).all()
     t = torch.from_numpy(x).float().unsqueeze(0)
     assert torch.allclose(fu.square_distance(t, t)[0], torch.from_numpy(d).float(), atol=1e-5)
+
+
+def test_save_pair_single_region_matches_the_reference(tmp_path, monkeypatch):
+    """final_gen_pair.py:145-218 is host NumPy: range ranks, max / min poses, ball-query neighbour pairs and the folder names,
+    on the inputs the reference was run on (tests/golden/gen_pair.npz; the device half is checked in -m gpu)."""
+    import argparse
+    import torch
+    from interpret_quality_amd import gen_pair
+    g = load_golden("gen_pair.npz")
+    name, r = "synthetic_03", 32
+    exp = str(tmp_path) + "/exp/"
+    base = exp + name + "/"
+    os.makedirs(base + "rotate_all")
+    np.save(base + "region_id.npy", g["region_id"].astype(np.int64))
+    np.save(base + "rotate_all/angle_tuple.npy", g["angle_tuple"])
+    np.save(base + "rotate_all/region_shapley_value.npy", g["region_shapley_value"])
+    pts, label = synth.make_cloud(int(g["cloud_id"]))
+    monkeypatch.setattr(gen_pair, "data_loader", lambda a: [(torch.from_numpy(pts).unsqueeze(0), torch.tensor([label]))])
+    args = argparse.Namespace(model="pointnet", dataset="modelnet10", mode="rotate", seed=1, num_points=1024, num_regions=r, exp_folder=exp)
+    gen_pair.save_pair_single_region(args, [name])
+    single = base + "interaction_seed1/rotate_adv_single_region/"
+    assert sorted(os.listdir(single)) == sorted("range_rank%02d_region%02d" % (g["range_rank"][k], k) for k in range(r))
+    off = np.concatenate([[0], np.cumsum(g["single_pair_counts"])])
+    for k in range(r):
+        f = single + "range_rank%02d_region%02d/" % (g["range_rank"][k], k)
+        assert np.array_equal(np.load(f + "region_pair_list.npy").reshape(-1, 2), g["single_pairs"][off[k]:off[k + 1]].reshape(-1, 2))
+        assert int(np.load(f + "max_pose/pose_idx.npy")) == g["max_pose_idx"][k] and int(np.load(f + "min_pose/pose_idx.npy")) == g["min_pose_idx"][k]
+        assert np.array_equal(np.load(f + "min_pose/transform_params.npy"), g["angle_tuple"][g["min_pose_idx"][k]])

@@ -217,3 +217,46 @@ def test_smoothness_enumeration_matches_reference(mode):
         assert np.array_equal(s, g[key + "_smoothness"])
         assert np.array_equal(d[0, 0], g[key + "_after1_data"]) and np.array_equal(d[1, 0], g[key + "_after2_data"])
         assert np.array_equal(d[-1, 0], g[key + "_full_data"])
+
+
+def test_oracle_on_config0_at_spec_subset(model):
+    """BASELINE configs[0] fixture (30 clouds x 8 regions x 64 permutations, bs 8, tests/golden/gen_golden_config0.py): the
+    oracle on three of its clouds incl. the continuing permutation stream (the GPU test covers all 30)."""
+    g = load_golden("pointnet_config0.npz")
+    r, s, bs = int(g["num_regions"]), int(g["num_samples"]), int(g["bs"])
+    np.random.seed(1)
+    for ci in range(30):
+        orders = O.generate_all_orders(s, r)                 # the stream runs on from cloud to cloud
+        assert np.array_equal(orders, g["orders"][ci])
+        if ci not in (0, 1, 29):
+            continue
+        pts, label = synth.make_cloud(ci)
+        data = torch.from_numpy(pts).unsqueeze(0)
+        lbl = torch.tensor([label])
+        fps = O.farthest_point_sample(data, r)[0]
+        assert np.array_equal(fps.numpy(), g["fps_index"][ci])
+        region_id = O.cal_region_id(data, fps)
+        assert np.array_equal(region_id, g["region_id"][ci])
+        phi, logits = O.shap_sampling_all_regions_batch(model, data, lbl, region_id, orders, s, bs, r)
+        np.testing.assert_allclose(phi, g["phi"][ci], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(O.get_reward(logits, lbl).numpy(), g["v"][ci], rtol=1e-5, atol=1e-5)
+        if ci < 2:
+            np.testing.assert_allclose(logits.numpy(), g["logits_first2"][ci], rtol=1e-6, atol=1e-6)
+
+
+def test_oracle_dgcnn_on_a_slice_of_the_scale_fixture():
+    """dgcnn_scale.npz (2016 coalitions from the reference): the oracle's DGCNN on one pair per ratio."""
+    g = load_golden("dgcnn_scale.npz")
+    sd = synth.to_torch(synth.dgcnn_state_dict(0))
+    pts, _ = synth.make_cloud(int(g["cloud_id"]))
+    data = torch.from_numpy(pts).unsqueeze(0)
+    model = lambda x: O.dgcnn_forward(sd, x, 20, False)  # noqa: E731
+    n = 0
+    for k, ratio in enumerate(g["ratios"]):
+        tag = "ratio%d" % int(ratio * 100)
+        p = 5 * k
+        got = O.compute_order_interaction_logits(model, data, g["region_id"].astype(np.int64), g["pairs"][p:p + 1].astype(np.int64),
+                                                 g[tag + "_contexts"][p:p + 1].astype(np.int64), 6, is_pointnet=False)
+        np.testing.assert_allclose(got.numpy(), g[tag + "_logits"][p:p + 1], rtol=1e-5, atol=1e-5)
+        n += got.shape[1]
+    assert n == 96 and sum(g["ratio%d_logits" % int(r * 100)].shape[0] * g["ratio%d_logits" % int(r * 100)].shape[1] for r in g["ratios"]) == 2016

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import assert_close_elementwise, load_golden
 from interpret_quality_amd import final_common, synth
 from interpret_quality_amd.pointconv import PointConvDensityClsSsg
 
@@ -55,6 +55,7 @@ def test_pointconv_shapley_matches_reference(model):
                               shapley_batch_size=2, verbose=False)
     phi, logits = final_common.shap_sampling_all_regions_batch(model, data, lbl, g["region_id"], g["orders"], args)
     assert rel_err(logits.cpu().numpy(), g["shap_logits"]) < RTOL
+    assert_close_elementwise(logits.cpu().numpy(), g["shap_logits"])   # and element-wise, with an absolute floor (conftest.py)
     assert np.abs(phi - g["phi"]).max() < RTOL * np.abs(g["phi"]).max()
 
 
@@ -64,3 +65,4 @@ def test_pointconv_raw_clouds_vs_oracle(model):
     want = O.PointConvOracle(synth.to_torch(synth.pointconv_state_dict(0)))(x)
     got = model(x.to(dev()))
     assert rel_err(got.cpu().numpy(), want.numpy()) < RTOL
+    assert_close_elementwise(got.cpu().numpy(), want.numpy())   # and element-wise, with an absolute floor (conftest.py)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import assert_close_elementwise, load_golden
 from interpret_quality_amd import final_common, hip_ops, synth
 from interpret_quality_amd.pointnet2 import PointNet2ClsMsg
 
@@ -89,6 +89,7 @@ def test_pointnet2_forward_matches_reference(model, masked):
     g = load_golden("pointnet2.npz")
     logits = model(masked.permute(0, 2, 1).contiguous().to(dev()))
     assert rel_err(logits.cpu().numpy(), g["logits"]) < RTOL
+    assert_close_elementwise(logits.cpu().numpy(), g["logits"])   # and element-wise, with an absolute floor (conftest.py)
     # channel-last entry point, split into several calls
     model.max_clouds_per_call = 7
     l2 = model.forward_points(masked.to(dev()))
@@ -105,6 +106,7 @@ def test_pointnet2_shapley_matches_reference(model):
                               shapley_batch_size=2, verbose=False)
     phi, logits = final_common.shap_sampling_all_regions_batch(model, data, lbl, g["region_id"], g["orders"], args)
     assert rel_err(logits.cpu().numpy(), g["shap_logits"]) < RTOL
+    assert_close_elementwise(logits.cpu().numpy(), g["shap_logits"])   # and element-wise, with an absolute floor (conftest.py)
     assert np.abs(phi - g["phi"]).max() < RTOL * np.abs(g["phi"]).max()
 
 
@@ -113,6 +115,7 @@ def test_pointnet2_raw_clouds_vs_oracle(model, oracle):
     want = oracle.PointNet2Oracle(synth.to_torch(synth.pointnet2_state_dict(0)))(x)
     got = model(x.to(dev()))
     assert rel_err(got.cpu().numpy(), want.numpy()) < RTOL
+    assert_close_elementwise(got.cpu().numpy(), want.numpy())   # and element-wise, with an absolute floor (conftest.py)
 
 
 def test_coalitions_with_pair_tables_equal_the_forward_on_masked_clouds(model):
