@@ -37,7 +37,8 @@ __global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __rest
     if (split) out += (size_t)blockIdx.z * M * ldo;
 
     const float* ap[MT];
-    const float* bp[NT];
+    int bs[NT];                                   // scalar byte offset of n-tile j's fragment kb0 in the weight image
+    const WBuf wb = wbuf_make(wp, lane);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int row = min(m0 + i * 32 + (lane & 31), M - 1);
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int nt = min(nt0 + j, ntiles - 1);
-        bp[j] = wp + (((size_t)nt * KBT + kb0) * 64 + lane) * 4;
+        bs[j] = uniform((nt * KBT + kb0) * kFragBytes);
     }
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -58,14 +59,14 @@ __global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < MT; ++i) av[i] = *reinterpret_cast<const f32x4*>(ap[i]);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(bp[j]);
+    for (int j = 0; j < NT; ++j) bv[j] = wbuf_load(wb, bs[j]);
     for (int kb = 0; kb < KB; ++kb) {
         f32x4 an[MT], bn[NT];
         const int kn = min(kb + 1, KB - 1);
 #pragma unroll
         for (int i = 0; i < MT; ++i) an[i] = *reinterpret_cast<const f32x4*>(ap[i] + 8 * kn);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bn[j] = *reinterpret_cast<const f32x4*>(bp[j] + (size_t)kn * 256);
+        for (int j = 0; j < NT; ++j) bn[j] = wbuf_load(wb, bs[j] + kn * kFragBytes);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -125,36 +126,40 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
     const int ntiles = (Nout + 31) >> 5;
     const int nt0 = (blockIdx.y * 2 + wn) * NT;
 
-    // chunk copy: 128 rows x 8 float4; thread t owns (row, c4) = (e >> 3, e & 7) for e = t + 256 i
-    const float* arow[4];
+    // chunk copy: 128 rows x 8 float4; thread t owns (row, c4) = (e >> 3, e & 7) for e = t + 256 i.  Buffer loads on a
+    // resource based at this workgroup's first row: loop-invariant per-lane offsets, the K position is a scalar offset.
+    const WBuf ab = wbuf_make(A + (size_t)m0 * lda, lane);
+    int aoffb[4];
     int soff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int e = tid + kThreads * i, row = e >> 3, c4 = e & 7;
-        arow[i] = A + (size_t)min(m0 + row, M - 1) * lda + c4 * 4;
+        aoffb[i] = (min(row, M - 1 - m0) * lda + c4 * 4) * 4;
         soff[i] = row * LDA + c4 * 4;
     }
     f32x4 stage[4];
     auto load_chunk = [&](int kc) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stage[i] = *reinterpret_cast<const f32x4*>(arow[i] + kc * KC);
+        for (int i = 0; i < 4; ++i)
+            stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ab.rsrc, aoffb[i], kc * KC * 4, 0));
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&As[buf][soff[i]]) = stage[i];
     };
 
-    const float* bp[NT];
+    const WBuf wb = wbuf_make(wp, lane);
+    int bs[NT];                                   // scalar byte offset of n-tile j's first fragment
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bp[j] = wp + ((size_t)min(nt0 + j, ntiles - 1) * KB * 64 + lane) * 4;
+    for (int j = 0; j < NT; ++j) bs[j] = uniform(min(nt0 + j, ntiles - 1) * KB * kFragBytes);
     // B fragments in a 2-deep register ring (k-blocks kb, kb + 1); the slot just consumed is refilled with kb + 2, i.e.
     // 2 x 8 NT MFMAs (>= 4096 cycles) ahead of its use.  sched_group_barrier pins that order: left alone, the
     // scheduler sinks the loads next to their uses and the MFMAs wait on L2.
     f32x4 ring[2][NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        ring[0][j] = *reinterpret_cast<const f32x4*>(bp[j]);
-        ring[1][j] = *reinterpret_cast<const f32x4*>(bp[j] + (size_t)min(1, KB - 1) * 256);
+        ring[0][j] = wbuf_load(wb, bs[j]);
+        ring[1][j] = wbuf_load(wb, bs[j] + min(1, KB - 1) * kFragBytes);
     }
     f32x16 acc[2][NT];
 #pragma unroll
@@ -178,13 +183,13 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
                 a0n = *reinterpret_cast<const f32x4*>(as + 8 * (k4 + 1));
                 a1n = *reinterpret_cast<const f32x4*>(as + 32 * LDA + 8 * (k4 + 1));
             }
-            const size_t kn = (size_t)min(kb + 2, KB - 1) * 256;
+            const int kn = min(kb + 2, KB - 1) * kFragBytes;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const f32x4 bk = ring[k4 & 1][j];
                 acc[0][j] = mfma4(a0, bk, acc[0][j]);
                 acc[1][j] = mfma4(a1, bk, acc[1][j]);
-                ring[k4 & 1][j] = *reinterpret_cast<const f32x4*>(bp[j] + kn);
+                ring[k4 & 1][j] = wbuf_load(wb, bs[j] + kn);
             }
             if (k4 < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll

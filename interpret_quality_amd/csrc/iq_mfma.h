@@ -16,10 +16,35 @@ __device__ __forceinline__ f32x4 lds_frag(const float* abase, int mt, int kb) {
     return *reinterpret_cast<const f32x4*>(abase + mt * 32 * LD + 8 * kb);
 }
 
-// B fragment from the packed weight image (iq_pack_weight): ((nt*KB + kb)*64 + lane)*4.
-__device__ __forceinline__ f32x4 glb_b(const float* wp, int lane) {
-    return *reinterpret_cast<const f32x4*>(wp + lane * 4);
+// B fragments come from the packed weight image (iq_pack_weight): fragment (nt, kb) = 1 KiB at ((nt*KB + kb)*64 + lane)*4
+// floats.  They are fetched with RAW BUFFER LOADS: an SGPR resource on the image, ONE loop-invariant VGPR offset (lane * 16 B)
+// and a scalar byte offset per fragment.  With flat `global_load_dwordx4` on per-lane 64-bit pointers every fragment cost a
+// VMEM issue with two address VGPRs plus VALU pointer arithmetic between the MFMAs: measured 8 % of the chain kernel's L3
+// loop (24.2 -> 22.6 ms, against 22.2 ms with the loads removed altogether; profiles/r02_chain_l3_ab.txt).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct WBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;   // lane * 16 bytes
+};
+
+// `base` must be wave-uniform.  Raw buffer (stride 0): offsets are plain byte offsets, reads past num_records return 0.
+__device__ __forceinline__ WBuf wbuf_make(const float* base, int lane) {
+    WBuf w;
+    w.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+    w.voff = lane * 16;
+    return w;
 }
+
+// fragment at scalar byte offset `soff` (wave-uniform) of the image
+__device__ __forceinline__ f32x4 wbuf_load(const WBuf& w, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rsrc, w.voff, soff, 0));
+}
+
+// wave-uniform copy of a value the compiler cannot prove uniform (e.g. threadIdx.x >> 6)
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+constexpr int kFragBytes = 1024;   // one (n-tile, k-block) fragment
 
 __device__ __forceinline__ f32x16 mfma4(f32x4 a, f32x4 b, f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
@@ -49,13 +74,14 @@ struct WRing {
     f32x4 r[4];
 };
 
-__device__ __forceinline__ void wring_prime(WRing& w, const float* wq, int lane) {
+// scur / snext: scalar byte offsets of the current / next n-tile's first fragment in the weight image
+__device__ __forceinline__ void wring_prime(WRing& w, const WBuf& wb, int scur) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w.r[i] = glb_b(wq + i * 256, lane);
+    for (int i = 0; i < 4; ++i) w.r[i] = wbuf_load(wb, scur + i * kFragBytes);
 }
 
 template <int LD, int KB, int MTS>
-__device__ __forceinline__ void mfma_ntile(const float* abase, const float* wcur, const float* wnext, int lane,
+__device__ __forceinline__ void mfma_ntile(const float* abase, const WBuf& wb, int scur, int snext,
                                            WRing& ring, f32x16& acc0, f32x16& acc1) {
     static_assert(KB % 4 == 0, "KB must be a multiple of 4");
     f32x4 a0n = lds_frag<LD>(abase, 0, 0), a1n = a0n;
@@ -70,7 +96,7 @@ __device__ __forceinline__ void mfma_ntile(const float* abase, const float* wcur
         const f32x4 bk = ring.r[kb & 3];
         acc0 = mfma4(a0, bk, acc0);
         if (MTS == 2) acc1 = mfma4(a1, bk, acc1);
-        ring.r[kb & 3] = glb_b(kb + 4 < KB ? wcur + (kb + 4) * 256 : wnext + (kb + 4 - KB) * 256, lane);
+        ring.r[kb & 3] = wbuf_load(wb, kb + 4 < KB ? scur + (kb + 4) * kFragBytes : snext + (kb + 4 - KB) * kFragBytes);
         if (kb + 1 < KB) __builtin_amdgcn_sched_group_barrier(0x100, MTS, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * MTS, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);

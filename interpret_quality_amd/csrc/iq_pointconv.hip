@@ -249,17 +249,19 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_kernel(PcGroupArgs a) {
         }
     }
     WRing ring2, ring3;
-    if (NT2 >= 4) wring_prime(ring2, a.w2 + (size_t)wave * KB1 * 256, lane);
+    const int wave_s = uniform(wave);
+    const WBuf w2b = wbuf_make(a.w2, lane), w3b = wbuf_make(a.w3, lane);
+    if (NT2 >= 4) wring_prime(ring2, w2b, wave_s * KB1 * kFragBytes);
     __syncthreads();
     // ---- layer 2 -------------------------------------------------------------------------------------------------
     if (NT2 >= 4) {
 #pragma unroll
         for (int q = 0; q < NT2 / 4; ++q) {
-            const int nt = q * 4 + wave;
+            const int nt = q * 4 + wave, nts = q * 4 + wave_s;
             f32x16 acc0 = {0}, acc1 = {0};
-            const float* wq = a.w2 + (size_t)nt * KB1 * 256;
-            const float* wn = a.w2 + (size_t)(q + 1 < NT2 / 4 ? nt + 4 : nt) * KB1 * 256;
-            mfma_ntile<LD1, KB1, 2>(a1base, wq, wn, lane, ring2, acc0, acc1);
+            const int wq = nts * KB1 * kFragBytes;
+            const int wn = (q + 1 < NT2 / 4 ? nts + 4 : nts) * KB1 * kFragBytes;
+            mfma_ntile<LD1, KB1, 2>(a1base, w2b, wq, wn, ring2, acc0, acc1);
             const float bias = a.b2[nt * 32 + fl];
             float* dst = c2base + nt * 32;
 #pragma unroll
@@ -272,26 +274,26 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_kernel(PcGroupArgs a) {
         for (int t = wave; t < 2 * NT2; t += 4) {
             const int mt = t / NT2, nt = t - mt * NT2;
             f32x16 acc = {0};
-            const float* wq = a.w2 + (size_t)nt * KB1 * 256;
+            const int wq = uniform(nt) * KB1 * kFragBytes;
 #pragma unroll 4
             for (int kb = 0; kb < KB1; ++kb)
-                acc = mfma4(lds_frag<LD1>(a1base + mt * 32 * LD1, 0, kb), glb_b(wq + kb * 256, lane), acc);
+                acc = mfma4(lds_frag<LD1>(a1base + mt * 32 * LD1, 0, kb), wbuf_load(w2b, wq + kb * kFragBytes), acc);
             const float bias = a.b2[nt * 32 + fl];
             float* dst = c2base + mt * 32 * LD2 + nt * 32;
 #pragma unroll
             for (int i = 0; i < 16; ++i) dst[c_row_i(i) * LD2] = fmaxf(acc[i] + bias, 0.f);
         }
     }
-    wring_prime(ring3, a.w3 + (size_t)wave * KB2 * 256, lane);
+    wring_prime(ring3, w3b, wave_s * KB2 * kFragBytes);
     __syncthreads();
     // ---- layer 3 + contraction over the members -------------------------------------------------------------------
 #pragma unroll
     for (int q = 0; q < NT3 / 4; ++q) {
-        const int nt = q * 4 + wave;
+        const int nt = q * 4 + wave, nts = q * 4 + wave_s;
         f32x16 acc0 = {0}, acc1 = {0};
-        const float* wq = a.w3 + (size_t)nt * KB2 * 256;
-        const float* wn = a.w3 + (size_t)(q + 1 < NT3 / 4 ? nt + 4 : nt) * KB2 * 256;
-        mfma_ntile<LD2, KB2, 2>(a2base, wq, wn, lane, ring3, acc0, acc1);
+        const int wq = nts * KB2 * kFragBytes;
+        const int wn = (q + 1 < NT3 / 4 ? nts + 4 : nts) * KB2 * kFragBytes;
+        mfma_ntile<LD2, KB2, 2>(a2base, w3b, wq, wn, ring3, acc0, acc1);
         const float bias = a.b3[nt * 32 + fl];
         float o0[16], o1[16];   // per m-tile: sum over its 16 rows (this half-wave) of h[row][c] * sw[row][w]
 #pragma unroll

@@ -62,18 +62,17 @@ struct ChainArgs {
 // ---- L3: 128 -> 1024 for one 64-row chunk; wave `wave` owns the n-tiles q*4 + wave ------------
 // Variant 0: B fragments two K-blocks ahead in a small register ring, compiler-scheduled.
 template <int MTS>
-__device__ __forceinline__ void l3_pass_v0(const float* __restrict__ w3, const float* abase, int wave, int lane,
-                                           float (&runmax)[8]) {
-    const float* wq = w3 + (size_t)wave * 16 * 256;
-    f32x4 b0 = glb_b(wq, lane);
-    f32x4 b1 = glb_b(wq + 256, lane);
+__device__ __forceinline__ void l3_pass_v0(const WBuf& w3, const float* abase, int wave_s, float (&runmax)[8]) {
+    int wq = wave_s * 16 * kFragBytes;
+    f32x4 b0 = wbuf_load(w3, wq);
+    f32x4 b1 = wbuf_load(w3, wq + kFragBytes);
 #pragma unroll 1
     for (int q = 0; q < 8; ++q) {
-        const float* wnext = w3 + (size_t)(min(q + 1, 7) * 4 + wave) * 16 * 256;
+        const int wnext = (min(q + 1, 7) * 4 + wave_s) * 16 * kFragBytes;
         f32x16 acc0 = {0}, acc1 = {0};
 #pragma unroll 4
         for (int kb = 0; kb < 16; ++kb) {
-            const f32x4 bn = (kb + 2 < 16) ? glb_b(wq + (kb + 2) * 256, lane) : glb_b(wnext + (kb + 2 - 16) * 256, lane);
+            const f32x4 bn = wbuf_load(w3, (kb + 2 < 16) ? wq + (kb + 2) * kFragBytes : wnext + (kb + 2 - 16) * kFragBytes);
             acc0 = mfma4(lds_frag<kLd2>(abase, 0, kb), b0, acc0);
             if (MTS == 2) acc1 = mfma4(lds_frag<kLd2>(abase, 1, kb), b0, acc1);
             b0 = b1;
@@ -96,20 +95,19 @@ struct BRing {
     f32x4 r[8];
 };
 
-__device__ __forceinline__ void bring_init(BRing& ring, const float* __restrict__ w3, int wave, int lane) {
-    const float* wq = w3 + (size_t)wave * 16 * 256 + lane * 4;
+__device__ __forceinline__ void bring_init(BRing& ring, const WBuf& w3, int wave_s) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ring.r[i] = *reinterpret_cast<const f32x4*>(wq + i * 256);
+    for (int i = 0; i < 8; ++i) ring.r[i] = wbuf_load(w3, (wave_s * 16 + i) * kFragBytes);
 }
 
+// wave_s: the wave index as a scalar; the fragment offsets are then scalar too (iq_mfma.h: WBuf)
 template <int MTS>
-__device__ __forceinline__ void l3_pass_v2(const float* __restrict__ w3, const float* abase, int wave, int lane,
-                                           float (&runmax)[8], BRing& ring) {
-    const float* w0 = w3 + (size_t)wave * 16 * 256 + lane * 4;
-    const float* wq = w0;
+__device__ __forceinline__ void l3_pass_v2(const WBuf& w3, const float* abase, int wave_s, float (&runmax)[8], BRing& ring) {
+    const int w0 = wave_s * 16 * kFragBytes;
+    int wq = w0;
 #pragma unroll 1
     for (int q = 0; q < 8; ++q) {
-        const float* wn = (q < 7) ? wq + 4 * 16 * 256 : w0;
+        const int wn = (q < 7) ? wq + 4 * 16 * kFragBytes : w0;
         f32x16 acc0 = {0}, acc1 = {0};
         f32x4 a0n = lds_frag<kLd2>(abase, 0, 0), a1n = a0n;
         if (MTS == 2) a1n = lds_frag<kLd2>(abase, 1, 0);
@@ -123,7 +121,7 @@ __device__ __forceinline__ void l3_pass_v2(const float* __restrict__ w3, const f
             const f32x4 bk = ring.r[kb & 7];
             acc0 = mfma4(a0, bk, acc0);
             if (MTS == 2) acc1 = mfma4(a1, bk, acc1);
-            ring.r[kb & 7] = *reinterpret_cast<const f32x4*>((kb < 8 ? wq + (kb + 8) * 256 : wn + (kb - 8) * 256));
+            ring.r[kb & 7] = wbuf_load(w3, kb < 8 ? wq + (kb + 8) * kFragBytes : wn + (kb - 8) * kFragBytes);
             if (kb + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, MTS, 0);  // DS reads of K-block kb+1
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * MTS, 0);               // MFMAs of K-block kb
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // ring refill
@@ -177,7 +175,10 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
 
     const int c0 = tid & 63, rg = tid >> 6;
     const f32x4 win = *reinterpret_cast<const f32x4*>(a.w_in + c0 * 4);
-    const float* w1 = (MODE == kTrunk) ? a.w1 + (size_t)item * 4096 : a.w1;
+    const int wave_s = uniform(wave);
+    // weight images as buffer resources (kTrunk: layer 1 is this item's packed 64x64 transform)
+    const WBuf w1b = wbuf_make((MODE == kTrunk) ? a.w1 + (size_t)item * 4096 : a.w1, lane);
+    const WBuf w2b = wbuf_make(a.w2, lane), w3b = wbuf_make(a.w3, lane);
     // per-lane bases: A-fragment reads and C-tile writes are base + immediate everywhere below
     const int frag_lane = (lane & 31), frag_h = lane >> 5;
     const float* a1base_A = bufA + frag_lane * kLd1 + 4 * frag_h;   // act0 in bufA
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
     }
 
     BRing ring;
-    if (L3V == 2) bring_init(ring, a.w3, wave, lane);
+    if (L3V == 2) bring_init(ring, w3b, wave_s);
     unsigned tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? stamp_now() : 0ull;
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -251,10 +252,10 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
         // ---- L1: 64 -> 64 ------------------------------------------------------------------
         if (MODE != kPrepool) {
             const int mt = wave & 1, nt = wave >> 1;
-            const float* wq = w1 + (size_t)nt * 8 * 256;
+            const int wq = (wave_s >> 1) * 8 * kFragBytes;
             f32x4 bw[8];  // weight fragments are requested before the barrier, consumed after it
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) bw[kb] = glb_b(wq + kb * 256, lane);
+            for (int kb = 0; kb < 8; ++kb) bw[kb] = wbuf_load(w1b, wq + kb * kFragBytes);
             IQ_STAMP(2);
             __syncthreads();
             IQ_STAMP(3);
@@ -279,10 +280,10 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
         //      are requested while the first pass computes ------------------------------------
         {
             const int mt = wave & 1, nt0 = wave >> 1;
-            const float* wq0 = a.w2 + (size_t)nt0 * 8 * 256;
+            const int wq0 = (wave_s >> 1) * 8 * kFragBytes;
             f32x4 bw[8];
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) bw[kb] = glb_b(wq0 + kb * 256, lane);
+            for (int kb = 0; kb < 8; ++kb) bw[kb] = wbuf_load(w2b, wq0 + kb * kFragBytes);
             IQ_STAMP(4);
             __syncthreads();
             IQ_STAMP(3);
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
 #pragma unroll
                     for (int kb = 0; kb < 8; ++kb) {
                         acc = mfma4(lds_frag<kLd1>(arow, 0, kb), bw[kb], acc);
-                        if (pass == 0) bw[kb] = glb_b(wq0 + (2 * 8 + kb) * 256, lane);
+                        if (pass == 0) bw[kb] = wbuf_load(w2b, wq0 + (2 * 8 + kb) * kFragBytes);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     const float bias = a.b2[nt0 * 32 + pass * 64 + frag_lane];
@@ -309,11 +310,11 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
         IQ_STAMP(3);
         // ---- L3: 128 -> 1024, running column max -------------------------------------------
         if (L3V == 0) {
-            if (mts == 2) l3_pass_v0<2>(a.w3, a2base, wave, lane, runmax);
-            else          l3_pass_v0<1>(a.w3, a2base, wave, lane, runmax);
+            if (mts == 2) l3_pass_v0<2>(w3b, a2base, wave_s, runmax);
+            else          l3_pass_v0<1>(w3b, a2base, wave_s, runmax);
         } else {
-            if (mts == 2) l3_pass_v2<2>(a.w3, a2base, wave, lane, runmax, ring);
-            else          l3_pass_v2<1>(a.w3, a2base, wave, lane, runmax, ring);
+            if (mts == 2) l3_pass_v2<2>(w3b, a2base, wave_s, runmax, ring);
+            else          l3_pass_v2<1>(w3b, a2base, wave_s, runmax, ring);
         }
         IQ_STAMP(6);
     }

@@ -299,11 +299,13 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
         }
     };
     WRing ring2, ring3;
+    const int wave_s = uniform(wave);
+    const WBuf w2b = wbuf_make(a.w2, lane), w3b = wbuf_make(a.w3, lane);
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1, nxt = cur ^ 1;
         const int mts = (jend - (j0 + ch * (kMC / kBlk))) > 2 ? 2 : 1;  // second m-tile holds live blocks?
         const int ga = blk_group[cur * 4], gb = blk_group[cur * 4 + 1], gc = blk_group[cur * 4 + 2], gd = blk_group[cur * 4 + 3];
-        if (NT2 >= 4) wring_prime(ring2, a.w2 + (size_t)wave * KB1 * 256, lane);  // in flight across stage 0b
+        if (NT2 >= 4) wring_prime(ring2, w2b, wave_s * KB1 * kFragBytes);  // in flight across stage 0b
         // ---- stage 0b: layer 1 -> act1 -------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -317,12 +319,12 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
         if (NT2 >= 4) {
 #pragma unroll
             for (int q = 0; q < NT2 / 4; ++q) {
-                const int nt = q * 4 + wave;
+                const int nt = q * 4 + wave, nts = q * 4 + wave_s;
                 f32x16 acc0 = {0}, acc1 = {0};
-                const float* wq = a.w2 + (size_t)nt * KB1 * 256;
-                const float* wn = a.w2 + (size_t)(q + 1 < NT2 / 4 ? nt + 4 : nt) * KB1 * 256;
-                if (mts == 2) mfma_ntile<LD1, KB1, 2>(a1base, wq, wn, lane, ring2, acc0, acc1);
-                else          mfma_ntile<LD1, KB1, 1>(a1base, wq, wn, lane, ring2, acc0, acc1);
+                const int wq = nts * KB1 * kFragBytes;
+                const int wn = (q + 1 < NT2 / 4 ? nts + 4 : nts) * KB1 * kFragBytes;
+                if (mts == 2) mfma_ntile<LD1, KB1, 2>(a1base, w2b, wq, wn, ring2, acc0, acc1);
+                else          mfma_ntile<LD1, KB1, 1>(a1base, w2b, wq, wn, ring2, acc0, acc1);
                 const float bias = a.b2[nt * 32 + fl];
                 float* dst = c2base + nt * 32;
 #pragma unroll
@@ -335,17 +337,17 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
             for (int t = wave; t < mts * NT2; t += 4) {
                 const int mt = t / NT2, nt = t - mt * NT2;
                 f32x16 acc = {0};
-                const float* wq = a.w2 + (size_t)nt * KB1 * 256;
+                const int wq = uniform(nt) * KB1 * kFragBytes;
 #pragma unroll 4
                 for (int kb = 0; kb < KB1; ++kb)
-                    acc = mfma4(lds_frag<LD1>(a1base + mt * 32 * LD1, 0, kb), glb_b(wq + kb * 256, lane), acc);
+                    acc = mfma4(lds_frag<LD1>(a1base + mt * 32 * LD1, 0, kb), wbuf_load(w2b, wq + kb * kFragBytes), acc);
                 const float bias = a.b2[nt * 32 + fl];
                 float* dst = c2base + mt * 32 * LD2 + nt * 32;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) dst[c_row_i(i) * LD2] = fmaxf(acc[i] + bias, 0.f);
             }
         }
-        if (NT3 >= 4) wring_prime(ring3, a.w3 + (size_t)wave * KB2 * 256, lane);  // in flight across the barrier
+        if (NT3 >= 4) wring_prime(ring3, w3b, wave_s * KB2 * kFragBytes);  // in flight across the barrier
         if (ch + 1 < nchunks) stage0a(ch + 1, nxt);
         __syncthreads();  // act2 complete; rel[nxt] visible
         if (ch + 1 < nchunks) gather_u(nxt);  // consumed after L3
@@ -353,12 +355,12 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
         if (NT3 >= 4) {
 #pragma unroll
             for (int q = 0; q < NT3 / 4; ++q) {
-                const int nt = q * 4 + wave;
+                const int nt = q * 4 + wave, nts = q * 4 + wave_s;
                 f32x16 acc0 = {0}, acc1 = {0};
-                const float* wq = a.w3 + (size_t)nt * KB2 * 256;
-                const float* wn = a.w3 + (size_t)(q + 1 < NT3 / 4 ? nt + 4 : nt) * KB2 * 256;
-                if (mts == 2) mfma_ntile<LD2, KB2, 2>(a2base, wq, wn, lane, ring3, acc0, acc1);
-                else          mfma_ntile<LD2, KB2, 1>(a2base, wq, wn, lane, ring3, acc0, acc1);
+                const int wq = nts * KB2 * kFragBytes;
+                const int wn = (q + 1 < NT3 / 4 ? nts + 4 : nts) * KB2 * kFragBytes;
+                if (mts == 2) mfma_ntile<LD2, KB2, 2>(a2base, w3b, wq, wn, ring3, acc0, acc1);
+                else          mfma_ntile<LD2, KB2, 1>(a2base, w3b, wq, wn, ring3, acc0, acc1);
                 const float bias = a.b3[nt * 32 + fl];
                 const TileMax m0 = reduce_tile(acc0, bias);
                 feed(q, ga, m0.lo);
@@ -373,10 +375,10 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
             for (int t = wave; t < mts * NT3; t += 4) {
                 const int mt = t / NT3, nt = t - mt * NT3;
                 f32x16 acc = {0};
-                const float* wq = a.w3 + (size_t)nt * KB2 * 256;
+                const int wq = uniform(nt) * KB2 * kFragBytes;
 #pragma unroll 4
                 for (int kb = 0; kb < KB2; ++kb)
-                    acc = mfma4(lds_frag<LD2>(a2base + mt * 32 * LD2, 0, kb), glb_b(wq + kb * 256, lane), acc);
+                    acc = mfma4(lds_frag<LD2>(a2base + mt * 32 * LD2, 0, kb), wbuf_load(w3b, wq + kb * kFragBytes), acc);
                 const float bias = a.b3[nt * 32 + fl];
                 float* orow = a.out + (size_t)b * a.S * a.ldo + nt * 32 + fl;
                 emit_tile(acc, bias, mt == 0 ? ga : gc, mt == 0 ? gb : gd, orow, a.ldo, fh);

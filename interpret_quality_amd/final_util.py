@@ -132,12 +132,19 @@ def _batch_key(model):
     return "gcnn" if model == "gcnn_adv" else model  # tools/final_util.py:214,228
 
 
+def strict_batch_cap():
+    """config.py's additive "strict_batch_cap" key or IQ_STRICT_BATCH=1: the batch-size knobs cap every launch (reference
+    semantics, config.py:2-17) instead of being a floor."""
+    return bool(_config().get("strict_batch_cap", False)) or os.environ.get("IQ_STRICT_BATCH") == "1"
+
+
 def set_shapley_batch_size(args):
     """tools/final_util.py:207-219."""
     table = _config()["shapley_batch_size"]
     if _batch_key(args.model) not in table:
         raise Exception("Not implemented")
     args.shapley_batch_size = table[_batch_key(args.model)]
+    args.strict_batch_cap = strict_batch_cap()
 
 
 def set_interaction_batch_size(args):
@@ -146,6 +153,7 @@ def set_interaction_batch_size(args):
     if _batch_key(args.model) not in table:
         raise Exception("Not implemented")
     args.interaction_batch_size = table[_batch_key(args.model)]
+    args.strict_batch_cap = strict_batch_cap()
 
 
 def load_model(args):

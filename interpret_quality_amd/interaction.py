@@ -64,12 +64,16 @@ def compute_order_interaction_logits(model, data_disturb, region_id, region_pair
             # equal sets are equal clouds (few-region contexts repeat a lot): evaluate the distinct ones once
             keep_np, inv = final_common.distinct_coalitions(context_keep_masks(pairs[lo:hi], ctx[lo:hi], r))
             inv_t = torch.from_numpy(inv.astype(np.int64)).to(dev)
+            strict = getattr(args, "strict_batch_cap", False)
             if hasattr(model, "coalition_logits"):
-                logits = model.coalition_logits(data_disturb.contiguous(), center.contiguous(), rid.reshape(1, -1),
-                                                hip_ops.masks_to_tensor(keep_np, dev), None, num_regions=r, validate=False)
+                logits = final_common.coalition_logits_capped(model, data_disturb.contiguous(), center.contiguous(), rid.reshape(1, -1),
+                                                              hip_ops.masks_to_tensor(keep_np, dev), r,
+                                                              4 * args.interaction_batch_size if strict else None)
             else:
-                # config.py's knob is a floor: rows are independent in eval mode, larger launches give the same logits
-                bs = max(4 * args.interaction_batch_size, getattr(model, "preferred_clouds_per_call", 0))
+                # config.py's knob is a floor (a cap with strict_batch_cap): rows are independent in eval mode, larger
+                # launches give the same logits
+                bs = 4 * args.interaction_batch_size if strict else max(4 * args.interaction_batch_size,
+                                                                       getattr(model, "preferred_clouds_per_call", 0))
                 keep = hip_ops.masks_to_tensor(keep_np, dev)
                 chunks = []
                 points_api = hasattr(model, "forward_points")  # consumes (B,N,3) directly: no transpose

@@ -121,7 +121,7 @@ def shapley_over_poses(model, poses, lbl, region_id, orders, args, pose_batch=8)
     p = poses.shape[0]
     per = s * (r + 1)
     phis, all_logits = [], []
-    if hasattr(model, "coalition_logits"):
+    if hasattr(model, "coalition_logits") and not getattr(args, "strict_batch_cap", False):
         # every pose uses the same permutations, hence the same sets: evaluate the distinct ones (final_common.distinct_coalitions)
         uniq, inv = final_common.distinct_coalitions(final_common.prefix_keep_masks(orders, r))
         nu = len(uniq)

@@ -4,7 +4,7 @@ float32 path.  DGCNN rebuilds its kNN graph in feature space at every layer, so 
 flip a neighbour under any rounding change; this fixture is what the rate of such coalitions is measured on
 (tests/test_dgcnn_gpu.py::test_dgcnn_parity_rate_at_scale).
 
-    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/gen_golden_dgcnn_scale.py     (about 3 minutes, 8 cores)
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/gen_golden_dgcnn_scale.py     (about 10 minutes, 8 cores)
 
 Output tests/golden/dgcnn_scale.npz (data only)."""
 import argparse
@@ -46,6 +46,11 @@ def main():
     pairs = ref_pair.gen_pair_random(args)
     out = {"cloud_id": cloud_id, "label": label, "region_id": region_id.astype(np.int8), "pairs": pairs.astype(np.int8),
            "ratios": np.array(ratios)}
+    # the reference itself in float64 on the same inputs: how far ITS float32 result is from exact arithmetic shows which
+    # coalitions sit on a kNN near-tie (their graphs flip under any change of rounding), i.e. the reference's own conditioning
+    m64 = ref_dg.DGCNN_cls(argparse.Namespace(dataset="modelnet10", k=20)).double()
+    m64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in synth.to_torch(synth.dgcnn_state_dict(0)).items()})
+    m64.eval()
     n = 0
     with tempfile.TemporaryDirectory() as td, torch.no_grad():
         ref_pair.gen_context(pairs, td + "/", args)
@@ -55,6 +60,8 @@ def main():
             logits = ref_inter.compute_order_interaction_logits(model, data, region_id, pairs, ctx, args)
             out[tag + "_contexts"] = ctx.astype(np.int8)
             out[tag + "_logits"] = logits.numpy()
+            l64 = ref_inter.compute_order_interaction_logits(m64, data.double(), region_id, pairs, ctx, args)
+            out[tag + "_logits_fp64"] = l64.numpy().astype(np.float32)      # its deviation from the float32 run is >= 1e-5 where it matters
             n += logits.shape[0] * logits.shape[1]
             print(tag, ctx.shape, tuple(logits.shape), flush=True)
     print("coalitions:", n)

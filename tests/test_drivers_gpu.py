@@ -386,3 +386,41 @@ def test_stage1_on_a_real_format_dataset_tree_without_the_synthetic_flag(tmp_pat
         nf = float(np.load(root + name + "/norm_factor.npy"))
         assert sv.shape == (20, 8) and np.abs(sv.sum(1) - nf).max() < 2e-4 * max(1.0, abs(nf))
         assert np.load(root + name + "/region_id.npy").shape == (1024,)
+
+
+@pytest.mark.parametrize("model_name", ["pointnet", "dgcnn", "pointconv"])
+def test_strict_batch_cap_bounds_every_launch_and_changes_no_result(model_name, monkeypatch):
+    """config.py's knobs as a CAP (CONFIG['strict_batch_cap'] / IQ_STRICT_BATCH=1, the reference's meaning of config.py:2-17)
+    against the default floor semantics: no launch exceeds knob x (R+1) (x 4) coalitions, logits bitwise identical."""
+    from interpret_quality_amd import final_util
+    a = ns(model=model_name, dataset="modelnet10", device=dev(), synthetic=True, model_path="checkpoints/none.t7", k=20,
+           num_regions=8, num_samples=8, shapley_batch_size=2, interaction_batch_size=3)
+    m = final_util.load_model(a)
+    pts, label = synth.make_cloud(4)
+    data = torch.from_numpy(pts).unsqueeze(0).to(dev())
+    lbl = torch.tensor([label], device=dev())
+    rid = hip_ops.region_assign(data[0].contiguous(), hip_ops.fps(data, 8)[0].contiguous()).cpu().numpy().astype(np.int64)
+    orders = synth.make_orders(8, 8, seed=3)
+    pairs = np.array([[0, 5], [2, 3]])
+    ctx = np.array([[[1, 4], [6, 7], [1, 7], [4, 6], [2, 6]], [[0, 1], [5, 6], [4, 7], [0, 7], [1, 5]]])
+    sizes = []
+    target = m
+    for name in ("coalition_logits", "forward_points"):
+        if hasattr(target, name):
+            orig = getattr(target, name)
+
+            def spy(*args, _orig=orig, _name=name, **kw):
+                sizes.append(args[3].shape[0] if _name == "coalition_logits" else args[0].shape[0])
+                return _orig(*args, **kw)
+            monkeypatch.setattr(target, name, spy)
+    out = {}
+    for strict in (False, True):
+        a.strict_batch_cap = strict
+        sizes.clear()
+        phi, logits = final_common.shap_sampling_all_regions_batch(m, data, lbl, rid, orders, a)
+        il = interaction.compute_order_interaction_logits(m, data, rid, pairs, ctx, a)
+        out[strict] = (phi, logits, il)
+        if strict:
+            assert sizes and max(sizes) <= max(2 * 9, 4 * 3), sizes
+    assert np.array_equal(out[False][0], out[True][0])
+    assert torch.equal(out[False][1], out[True][1]) and torch.equal(out[False][2], out[True][2])
