@@ -204,6 +204,7 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
                                                  int16_t* __restrict__ idx, Ragged rg, int B, int tiles_per_cloud, int dbg) {
     constexpr int KB = C / 8;
     __shared__ double queue[16 * 64];
+    __shared__ __attribute__((aligned(16))) float kxs[2 * 64];   // |key|^2 of two pairs of key tiles (double-buffered)
     const int lane = threadIdx.x;
     // workgroups go round-robin over the 8 XCDs: give each XCD whole clouds, so that the ~17 waves which stream the same
     // keys share one L2 (and often one L1) instead of pulling the cloud into all eight
@@ -228,12 +229,25 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
     QueuedTopK<kK, 16> top;
     top.init(queue);
     const int ntiles = N / 32;
-    const float* kp = xb + (size_t)fl * ldx + 4 * fh;   // A fragment of key row (32 t + fl), k-block kb: kp + 32 t ldx + 8 kb
-    const float* kxp = xxb + 4 * fh;                     // |key|^2 of rows 32 t + 8 j + 4 fh + (0..3): kxp + 32 t + 8 j
-    f32x4 an = *reinterpret_cast<const f32x4*>(kp);
-    f32x4 kxn[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) kxn[j] = *reinterpret_cast<const f32x4*>(kxp + 8 * j);
+    // Key fragments by raw buffer loads (iq_mfma.h: WBuf): resource on this cloud's rows, ONE loop-invariant per-lane offset
+    // (row fl of the tile, k offset 4 fh), the tile / k-block position is a scalar offset.  |key|^2 of two tiles (64 floats)
+    // comes with ONE coalesced load per pair of tiles and goes through a wave-private LDS strip, from which each lane reads
+    // the 16 values of its accumulator rows (4 ds_read_b128) - instead of 4 more vector-memory instructions per tile.  VMEM
+    // instructions per tile: C/8 + 1/2 (was C/8 + 4); each costs the SIMD tens of issue cycles next to the MFMAs.
+    const WBuf kb_buf = wbuf_make(xb, lane);
+    const int kvoff = (fl * ldx + 4 * fh) * 4;                   // bytes
+    const int row_bytes = ldx * 4;
+    const WBuf kx_buf = wbuf_make(xxb, lane);
+    auto key_frag = [&](int t, int kb) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kb_buf.rsrc, kvoff, (32 * t * row_bytes + 32 * kb), 0));
+    };
+    auto kx_pair = [&](int tp) {                                   // |key|^2 of tiles 2 tp, 2 tp + 1 (clamped to the cloud's rows)
+        const int row = min(64 * tp + lane, N - 1);
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(kx_buf.rsrc, row * 4, 0, 0));
+    };
+    f32x4 an = key_frag(0, 0);
+    kxs[lane] = kx_pair(0);                                        // wave-private: no barrier (one wave per workgroup)
+    float kx_next = kx_pair(1 < (ntiles + 1) / 2 ? 1 : 0);
     // ONE loop (a small state machine) instead of rounds nested in the tile loop: the 20-entry list is then carried
     // by a single loop and stays in 40 registers; nested, the allocator kept copies per loop level (300 registers).
     float d[16];
@@ -250,17 +264,21 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
         if (last) break;
         if (half == 2) {  // distances of key tile t
             f32x4 kx[4];
+            const float* ks = kxs + 64 * ((t >> 1) & 1) + 32 * (t & 1) + 4 * fh;   // rows 8 j + 4 fh + (0..3) of this tile
 #pragma unroll
-            for (int j = 0; j < 4; ++j) kx[j] = kxn[j];
+            for (int j = 0; j < 4; ++j) kx[j] = *reinterpret_cast<const f32x4*>(ks + 8 * j);
             const int tn = min(t + 1, ntiles - 1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) kxn[j] = *reinterpret_cast<const f32x4*>(kxp + 32 * tn + 8 * j);
             f32x16 acc = {0};
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const f32x4 a = an;
-                an = *reinterpret_cast<const f32x4*>(kb + 1 < KB ? kp + (size_t)32 * t * ldx + 8 * (kb + 1) : kp + (size_t)32 * tn * ldx);
+                an = kb + 1 < KB ? key_frag(t, kb + 1) : key_frag(tn, 0);
                 acc = mfma4(a, qf[kb], acc);
+            }
+            if (t & 1) {   // both tiles of the pair are used up: publish the next pair's strip, request the one after it
+                const int tp = (t >> 1) + 1;
+                kxs[64 * (tp & 1) + lane] = kx_next;
+                kx_next = kx_pair(min(tp + 1, (ntiles - 1) >> 1));
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -308,15 +326,31 @@ __global__ __launch_bounds__(kThreads) void gather_max_kernel(const float* __res
     const int pt = t / per, c4 = t - pt * per;
     if (pt >= rg.roff[B]) return;
     const int base = rg.roff[rg.row_cloud[pt]];
-    const int16_t* nb = idx + (size_t)pt * kK;
-    const f32x4* P = reinterpret_cast<const f32x4*>(pq);
-    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll 4
-    for (int j = 0; j < kK; ++j) {
-        const f32x4 v = P[((size_t)base + nb[j]) * (2 * per) + c4];
-        m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+    // the 20 neighbour indices of the point: 40 contiguous bytes, read as five 8-byte words
+    const uint2* nbw = reinterpret_cast<const uint2*>(idx + (size_t)pt * kK);
+    int nb[kK];
+#pragma unroll
+    for (int w = 0; w < kK / 4; ++w) {
+        const uint2 v = nbw[w];
+        nb[4 * w] = (int)(v.x & 0xffffu); nb[4 * w + 1] = (int)(v.x >> 16);
+        nb[4 * w + 2] = (int)(v.y & 0xffffu); nb[4 * w + 3] = (int)(v.y >> 16);
     }
-    const f32x4 q = P[(size_t)pt * (2 * per) + per + c4];
+    // Latency-bound gather (rows are L2 / MALL resident): all 20 row loads of a thread are in flight together, as raw
+    // buffer loads with 32-bit offsets (one multiply-add of address arithmetic per load instead of a 64-bit chain).
+    // The resource is based at this workgroup's first cloud row block so that offsets stay far below 4 GB.
+    const int wg_base = rg.roff[rg.row_cloud[min((int)(blockIdx.x * kThreads) / per, rg.roff[B] - 1)]];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pq) + (size_t)wg_base * (2 * Co), 0, 0x7fffffff, 0x00020000);
+    const int row_bytes = 2 * Co * 4;
+    f32x4 v[kK];
+#pragma unroll
+    for (int j = 0; j < kK; ++j)
+        v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (base - wg_base + nb[j]) * row_bytes + c4 * 16, 0, 0));
+    const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (pt - wg_base) * row_bytes + (per + c4) * 16, 0, 0));
+    f32x4 m = v[0];
+#pragma unroll
+    for (int j = 1; j < kK; ++j) {
+        m[0] = fmaxf(m[0], v[j][0]); m[1] = fmaxf(m[1], v[j][1]); m[2] = fmaxf(m[2], v[j][2]); m[3] = fmaxf(m[3], v[j][3]);
+    }
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {

@@ -167,176 +167,215 @@ __device__ __forceinline__ void weight_net(const float* __restrict__ p, float dx
     }
 }
 
+// ---- per-member pre-pass: relative coordinates and density scale x WeightNet ------------------------------------------
+// One thread per member (b, s, k): rel = x_p - c (+ the member index), sw[16] = DensityNet(rho_p / max rho in the group) x
+// WeightNet(rel).  ~450 flops per member on ALL lanes; inside the grouped kernel this ran on 64 of 256 threads in front
+// of every chunk's first MFMA.  80 bytes per member through HBM (1.3 MB per coalition for sa1) buys a grouped kernel
+// whose prologue is two coalesced loads.
+template <int K>
+__global__ __launch_bounds__(kThreads) void pc_member_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                             const int16_t* __restrict__ idx, const float* __restrict__ inv_density,
+                                                             TinyNets nets, float* __restrict__ mrel /*(B,S,K,4)*/,
+                                                             float* __restrict__ msw /*(B,S,K,16)*/, int N, int S, size_t total) {
+    const size_t t = (size_t)blockIdx.x * kThreads + threadIdx.x;       // member index; K divides 64: groups never straddle waves
+    const bool live = t < total;
+    const size_t tt = live ? t : total - 1;
+    const size_t g = tt / K;                                             // b * S + s
+    const int bb = (int)(g / S);
+    const int p = idx[tt];
+    const float* x = xyz + ((size_t)bb * N + p) * 3;
+    const float* c = new_xyz + g * 3;
+    const float dx = x[0] - c[0], dy = x[1] - c[1], dz = x[2] - c[2];
+    const float rho = inv_density[(size_t)bb * N + p];
+    float mx = rho;
+#pragma unroll
+    for (int o = 1; o < K; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));   // max over the K members of the group
+    const float sc = density_net(nets.dn, rho / mx);
+    float wt[16];
+    weight_net(nets.wn, dx, dy, dz, wt);
+    if (!live) return;
+    *reinterpret_cast<f32x4*>(mrel + t * 4) = (f32x4){dx, dy, dz, __int_as_float(p)};
+#pragma unroll
+    for (int w4 = 0; w4 < 4; ++w4)
+        *reinterpret_cast<f32x4*>(msw + t * 16 + w4 * 4) = (f32x4){sc * wt[w4 * 4], sc * wt[w4 * 4 + 1], sc * wt[w4 * 4 + 2], sc * wt[w4 * 4 + 3]};
+}
+
 // ---- grouped MLP + density scale + WeightNet contraction ------------------------------------------------------
 struct PcGroupArgs {
-    const float* xyz;          // (B,N,3) member coordinates
-    const float* new_xyz;      // (B,S,3) centroids
-    const int16_t* idx;        // (B,S,K)
-    const float* inv_density;  // (B,N)
+    const float* mrel;         // (B,S,K,4) relative coordinates + member index (pc_member_kernel)
+    const float* msw;          // (B,S,K,16) density scale x WeightNet output
     const float* U;            // (B,N,ldu) per-point part of layer 1 (bias included) or null
     int ldu;
     const float* w1x;          // [C1][4] = (wx0, wx1, wx2, bias)
     const float* w2; const float* b2;
     const float* w3; const float* b3;
-    TinyNets nets;
     float* out;                // (B,S,C3*16): [c][w]
-    int N, S, K;    int B, wgs_per_cloud;
+    int N, S, K;    int B, wgs_per_cloud, chunks_per_wg;
 };
 
+// One workgroup = `chunks_per_wg` consecutive 64-member chunks of one cloud (K = 32: two groups per chunk, K = 64: one).
+//   stage 0a  members' rel / sw rows -> LDS (sw transposed: swT[w][member], row 16 = zeros)      [coalesced, one chunk ahead]
+//   stage 0b  layer 1 (VALU, 4 channels per thread) + U[p] rows by 16-byte buffer loads -> act1
+//   L2, L3    fp32 MFMA as in pn2_group_kernel
+//   contraction out[c][w] = sum_k h[k][c] sw[k][w] ON THE MFMA: accumulator register i of an L3 tile, after bias + ReLU, IS
+//             the A operand (lane (c, kk) holds h[member c_row_i(i) + 4 kk][c]) of one 32x32x2 MFMA whose B operand is
+//             sw[member][w] for w < 16 and 0 for the other 16 columns - 16 MFMAs per tile at half utilisation (+17 % / +33 %
+//             matrix work for sa2 / sa1) instead of 256 FMAs + 64 LDS reads per lane and tile on the VALU while the matrix
+//             pipe of that wave sits idle, and 32 fewer live registers, which is what lets the next chunk's gather travel
+//             behind the L3 MFMAs.
 template <int C1, int C2, int C3>
 __global__ __launch_bounds__(kThreads, 2) void pc_group_kernel(PcGroupArgs a) {
-    constexpr int LD1 = C1 + 4, LD2 = C2 + 4;
+    constexpr int LD1 = C1 + 4, LD2 = C2 + 4, LDS_SW = kMC + 4;
     constexpr int KB1 = C1 / 8, KB2 = C2 / 8, NT2 = C2 / 32, NT3 = C3 / 32;
     static_assert(NT3 >= 4, "C3 >= 128");
-    constexpr int NR = kMC * C1 / kThreads;
+    constexpr int Q1 = C1 / 4, NR = kMC * Q1 / kThreads;
     __shared__ __attribute__((aligned(16))) float act1[kMC * LD1];
     __shared__ __attribute__((aligned(16))) float act2[kMC * LD2];
-    __shared__ __attribute__((aligned(16))) float rel[kMC * 4];   // dx,dy,dz, member index (bits)
-    __shared__ __attribute__((aligned(16))) float sw[kMC * 16];   // density scale x WeightNet output per member
-    __shared__ float rho[kMC];
+    __shared__ __attribute__((aligned(16))) float rel[2 * kMC * 4];          // dx,dy,dz, member index (bits); double-buffered
+    __shared__ __attribute__((aligned(16))) float swT[2 * 17 * LDS_SW];      // [buf][w | zero row][member]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 1-D grid; workgroups go round-robin over the 8 XCDs: keep all workgroups of a cloud on one XCD (one L2 holds its
-    // U rows, coordinates, densities and indices)
+    // U rows and member records)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int b = (slot / a.wgs_per_cloud) * 8 + xcd;
     if (b >= a.B) return;
-    const int K = a.K;                       // 32 (two groups per chunk) or 64 (one group per chunk)
-    const int gpc = kMC / K;                 // groups per chunk
-    const int g_first = (slot % a.wgs_per_cloud) * gpc;    // one chunk per workgroup
-    if (g_first >= a.S) return;
+    const int K = a.K;                                   // 32 or 64
+    const int chunks_total = a.S * K / kMC;
+    const int ch0 = (slot % a.wgs_per_cloud) * a.chunks_per_wg;
+    if (ch0 >= chunks_total) return;
+    const int nchunks = min(a.chunks_per_wg, chunks_total - ch0);
     const int fl = lane & 31, fh = lane >> 5;
     const float* a1base = act1 + fl * LD1 + 4 * fh;
     const float* a2base = act2 + fl * LD2 + 4 * fh;
     float* c2base = act2 + (4 * fh) * LD2 + fl;
-
-    // ---- stage 0a: members, relative coordinates, inverse densities ------------------------------------
-    if (tid < kMC) {
-        const int g = min(g_first + tid / K, a.S - 1), k = tid % K;
-        const int p = a.idx[((size_t)b * a.S + g) * K + k];
-        const float* x = a.xyz + ((size_t)b * a.N + p) * 3;
-        const float* c = a.new_xyz + ((size_t)b * a.S + g) * 3;
-        f32x4 v;
-        v[0] = x[0] - c[0]; v[1] = x[1] - c[1]; v[2] = x[2] - c[2];
-        v[3] = __int_as_float(p);
-        *reinterpret_cast<f32x4*>(rel + tid * 4) = v;
-        rho[tid] = a.inv_density[(size_t)b * a.N + p];
-    }
-    __syncthreads();
-    // ---- stage 0b: DensityNet(rho / group max) x WeightNet(dx) -> sw; layer 1 -> act1 ----------------------
-    if (tid < kMC) {
-        const int g0 = (tid / K) * K;
-        float mx = rho[g0];
-        for (int k = 1; k < K; ++k) mx = fmaxf(mx, rho[g0 + k]);
-        const float s = density_net(a.nets.dn, rho[tid] / mx);
-        float wt[16];
-        weight_net(a.nets.wn, rel[tid * 4], rel[tid * 4 + 1], rel[tid * 4 + 2], wt);
-#pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4)
-            *reinterpret_cast<f32x4*>(sw + tid * 16 + w4 * 4) =
-                (f32x4){s * wt[w4 * 4], s * wt[w4 * 4 + 1], s * wt[w4 * 4 + 2], s * wt[w4 * 4 + 3]};
-    }
-    {
-        const int chn = tid % C1, rsub = tid / C1;
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.w1x + chn * 4);
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int r = rsub + i * (kThreads / C1);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(rel + r * 4);
-            float h = fmaf(w1[2], v[2], fmaf(w1[1], v[1], w1[0] * v[0])) + w1[3];
-            if (a.U) h += a.U[((size_t)b * a.N + __float_as_int(v[3])) * a.ldu + chn];
-            act1[r * LD1 + chn] = fmaxf(h, 0.f);
-        }
-    }
-    WRing ring2, ring3;
     const int wave_s = uniform(wave);
     const WBuf w2b = wbuf_make(a.w2, lane), w3b = wbuf_make(a.w3, lane);
-    if (NT2 >= 4) wring_prime(ring2, w2b, wave_s * KB1 * kFragBytes);
+    const size_t member0 = (size_t)b * a.S * K;          // first member record of this cloud
+
+    if (tid < 2 * LDS_SW) swT[(tid / LDS_SW) * 17 * LDS_SW + 16 * LDS_SW + tid % LDS_SW] = 0.f;   // the zero rows
+    // B operand rows of the contraction: lanes with w = lane & 31 < 16 read their own row of swT, the others the zero row
+    const float* swlane = swT + (fl < 16 ? fl : 16) * LDS_SW + 4 * fh;
+
+    const int c4 = tid % Q1, rsub = tid / Q1;
+    f32x4 w1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w1[e] = *reinterpret_cast<const f32x4*>(a.w1x + (c4 * 4 + e) * 4);
+    const __amdgpu_buffer_rsrc_t ursrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.U ? a.U + (size_t)b * a.N * a.ldu : a.w1x), 0, 0x7fffffff, 0x00020000);
+    f32x4 ureg[NR];
+    auto stage0a = [&](int ch, int buf) {
+        const size_t m = member0 + (size_t)(ch0 + ch) * kMC;
+        if (tid < kMC) *reinterpret_cast<f32x4*>(rel + (buf * kMC + tid) * 4) = *reinterpret_cast<const f32x4*>(a.mrel + (m + tid) * 4);
+        const int mem = tid >> 2, q4 = tid & 3;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.msw + (m + mem) * 16 + q4 * 4);
+        float* dst = swT + buf * 17 * LDS_SW + (q4 * 4) * LDS_SW + mem;
+        dst[0] = v[0]; dst[LDS_SW] = v[1]; dst[2 * LDS_SW] = v[2]; dst[3 * LDS_SW] = v[3];
+    };
+    auto gather_u = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = rsub + i * (kThreads / Q1);
+            const int p = __float_as_int(rel[(buf * kMC + r) * 4 + 3]);
+            if (a.U) ureg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (p * a.ldu + c4 * 4) * 4, 0, 0));
+            else ureg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    stage0a(0, 0);
     __syncthreads();
-    // ---- layer 2 -------------------------------------------------------------------------------------------------
-    if (NT2 >= 4) {
+    gather_u(0);
+
+    WRing ring2, ring3;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cur = ch & 1, nxt = cur ^ 1;
+        if (NT2 >= 4) wring_prime(ring2, w2b, wave_s * KB1 * kFragBytes);   // in flight across stage 0b
+        // ---- stage 0b: layer 1 -> act1 ----------------------------------------------------------------------------
 #pragma unroll
-        for (int q = 0; q < NT2 / 4; ++q) {
-            const int nt = q * 4 + wave, nts = q * 4 + wave_s;
-            f32x16 acc0 = {0}, acc1 = {0};
-            const int wq = nts * KB1 * kFragBytes;
-            const int wn = (q + 1 < NT2 / 4 ? nts + 4 : nts) * KB1 * kFragBytes;
-            mfma_ntile<LD1, KB1, 2>(a1base, w2b, wq, wn, ring2, acc0, acc1);
-            const float bias = a.b2[nt * 32 + fl];
-            float* dst = c2base + nt * 32;
+        for (int i = 0; i < NR; ++i) {
+            const int r = rsub + i * (kThreads / Q1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rel + (cur * kMC + r) * 4);
+            f32x4 h;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                dst[c_row_i(i) * LD2] = fmaxf(acc0[i] + bias, 0.f);
-                dst[(32 + c_row_i(i)) * LD2] = fmaxf(acc1[i] + bias, 0.f);
+            for (int e = 0; e < 4; ++e) {
+                float t = fmaf(w1[e][2], v[2], fmaf(w1[e][1], v[1], w1[e][0] * v[0])) + w1[e][3];
+                if (a.U) t += ureg[i][e];
+                h[e] = fmaxf(t, 0.f);
             }
+            *reinterpret_cast<f32x4*>(act1 + r * LD1 + c4 * 4) = h;
         }
-    } else {
-        for (int t = wave; t < 2 * NT2; t += 4) {
-            const int mt = t / NT2, nt = t - mt * NT2;
-            f32x16 acc = {0};
-            const int wq = uniform(nt) * KB1 * kFragBytes;
-#pragma unroll 4
-            for (int kb = 0; kb < KB1; ++kb)
-                acc = mfma4(lds_frag<LD1>(a1base + mt * 32 * LD1, 0, kb), wbuf_load(w2b, wq + kb * kFragBytes), acc);
-            const float bias = a.b2[nt * 32 + fl];
-            float* dst = c2base + mt * 32 * LD2 + nt * 32;
+        __syncthreads();  // act1 complete; every wave has finished L3 of the previous chunk (act2, swT[nxt], rel[nxt] are free)
+        // ---- layer 2 -------------------------------------------------------------------------------------------------
+        if (NT2 >= 4) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) dst[c_row_i(i) * LD2] = fmaxf(acc[i] + bias, 0.f);
-        }
-    }
-    wring_prime(ring3, w3b, wave_s * KB2 * kFragBytes);
-    __syncthreads();
-    // ---- layer 3 + contraction over the members -------------------------------------------------------------------
+            for (int q = 0; q < NT2 / 4; ++q) {
+                const int nt = q * 4 + wave, nts = q * 4 + wave_s;
+                f32x16 acc0 = {0}, acc1 = {0};
+                const int wq = nts * KB1 * kFragBytes;
+                const int wn = (q + 1 < NT2 / 4 ? nts + 4 : nts) * KB1 * kFragBytes;
+                mfma_ntile<LD1, KB1, 2>(a1base, w2b, wq, wn, ring2, acc0, acc1);
+                const float bias = a.b2[nt * 32 + fl];
+                float* dst = c2base + nt * 32;
 #pragma unroll
-    for (int q = 0; q < NT3 / 4; ++q) {
-        const int nt = q * 4 + wave, nts = q * 4 + wave_s;
-        f32x16 acc0 = {0}, acc1 = {0};
-        const int wq = nts * KB2 * kFragBytes;
-        const int wn = (q + 1 < NT3 / 4 ? nts + 4 : nts) * KB2 * kFragBytes;
-        mfma_ntile<LD2, KB2, 2>(a2base, w3b, wq, wn, ring3, acc0, acc1);
-        const float bias = a.b3[nt * 32 + fl];
-        float o0[16], o1[16];   // per m-tile: sum over its 16 rows (this half-wave) of h[row][c] * sw[row][w]
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { o0[w] = 0.f; o1[w] = 0.f; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float h0 = fmaxf(acc0[r] + bias, 0.f), h1 = fmaxf(acc1[r] + bias, 0.f);
-            const float* s0 = sw + (c_row_i(r) + 4 * fh) * 16;
-            const float* s1 = s0 + 32 * 16;
-#pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) {
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(s0 + w4 * 4);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(s1 + w4 * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o0[w4 * 4 + e] = fmaf(h0, x0[e], o0[w4 * 4 + e]);
-                    o1[w4 * 4 + e] = fmaf(h1, x1[e], o1[w4 * 4 + e]);
+                for (int i = 0; i < 16; ++i) {
+                    dst[c_row_i(i) * LD2] = fmaxf(acc0[i] + bias, 0.f);
+                    dst[(32 + c_row_i(i)) * LD2] = fmaxf(acc1[i] + bias, 0.f);
                 }
             }
-        }
-        const int c = nt * 32 + fl;
+        } else {
+            for (int t = wave; t < 2 * NT2; t += 4) {
+                const int mt = t / NT2, nt = t - mt * NT2;
+                f32x16 acc = {0};
+                const int wq = uniform(nt) * KB1 * kFragBytes;
+#pragma unroll 4
+                for (int kb = 0; kb < KB1; ++kb)
+                    acc = mfma4(lds_frag<LD1>(a1base + mt * 32 * LD1, 0, kb), wbuf_load(w2b, wq + kb * kFragBytes), acc);
+                const float bias = a.b2[nt * 32 + fl];
+                float* dst = c2base + mt * 32 * LD2 + nt * 32;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            o0[w] += __shfl_xor(o0[w], 32);
-            o1[w] += __shfl_xor(o1[w], 32);
-        }
-        if (K == 64) {          // one group: both m-tiles
-            if (fh == 0) {
-                float* dst = a.out + ((size_t)b * a.S + g_first) * (C3 * 16) + c * 16;
-#pragma unroll
-                for (int w4 = 0; w4 < 4; ++w4)
-                    *reinterpret_cast<f32x4*>(dst + w4 * 4) = (f32x4){o0[w4 * 4] + o1[w4 * 4], o0[w4 * 4 + 1] + o1[w4 * 4 + 1],
-                                                                      o0[w4 * 4 + 2] + o1[w4 * 4 + 2], o0[w4 * 4 + 3] + o1[w4 * 4 + 3]};
+                for (int i = 0; i < 16; ++i) dst[c_row_i(i) * LD2] = fmaxf(acc[i] + bias, 0.f);
             }
-        } else {                // K == 32: m-tile 0 = group g_first, m-tile 1 = g_first + 1; half-waves split the stores
-            const int g = g_first + fh;
-            if (g < a.S) {
-                float* dst = a.out + ((size_t)b * a.S + g) * (C3 * 16) + c * 16;
+        }
+        wring_prime(ring3, w3b, wave_s * KB2 * kFragBytes);                 // in flight across the barrier
+        if (ch + 1 < nchunks) stage0a(ch + 1, nxt);
+        __syncthreads();  // act2 complete; rel[nxt] / swT[nxt] visible
+        if (ch + 1 < nchunks) gather_u(nxt);                                // consumed after L3
+        // ---- layer 3 + contraction over the members (MFMA) -------------------------------------------------------------
+        const float* swc = swlane + cur * 17 * LDS_SW;
+        const int g_first = (ch0 + ch) * (kMC / K);                         // first group of this chunk
 #pragma unroll
-                for (int w4 = 0; w4 < 4; ++w4)
-                    *reinterpret_cast<f32x4*>(dst + w4 * 4) = fh == 0
-                        ? (f32x4){o0[w4 * 4], o0[w4 * 4 + 1], o0[w4 * 4 + 2], o0[w4 * 4 + 3]}
-                        : (f32x4){o1[w4 * 4], o1[w4 * 4 + 1], o1[w4 * 4 + 2], o1[w4 * 4 + 3]};
+        for (int q = 0; q < NT3 / 4; ++q) {
+            const int nt = q * 4 + wave, nts = q * 4 + wave_s;
+            f32x16 acc0 = {0}, acc1 = {0};
+            const int wq = nts * KB2 * kFragBytes;
+            const int wn = (q + 1 < NT3 / 4 ? nts + 4 : nts) * KB2 * kFragBytes;
+            mfma_ntile<LD2, KB2, 2>(a2base, w3b, wq, wn, ring3, acc0, acc1);
+            const float bias = a.b3[nt * 32 + fl];
+            f32x16 d0 = {0}, d1 = {0};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {   // members 8 jj + 4 fh + (0..3) of each m-tile: accumulator registers 4 jj .. 4 jj + 3
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(swc + 8 * jj);
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(swc + 32 + 8 * jj);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * jj + e;
+                    d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(acc0[i] + bias, 0.f), s0[e], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(acc1[i] + bias, 0.f), s1[e], d1, 0, 0, 0);
+                }
+            }
+            // D tile: lane (w = fl, kk = fh), register j <-> channel nt*32 + c_row_i(j) + 4 fh; only w < 16 is real
+            if (fl < 16) {
+                if (K == 64) {        // one group: both m-tiles
+                    float* dst = a.out + ((size_t)b * a.S + g_first) * (C3 * 16) + (size_t)(nt * 32 + 4 * fh) * 16 + fl;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) dst[c_row_i(j) * 16] = d0[j] + d1[j];
+                } else {              // K == 32: m-tile 0 = group g_first, m-tile 1 = g_first + 1
+                    float* dst = a.out + ((size_t)b * a.S + g_first) * (C3 * 16) + (size_t)(nt * 32 + 4 * fh) * 16 + fl;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        dst[c_row_i(j) * 16] = d0[j];
+                        dst[C3 * 16 + c_row_i(j) * 16] = d1[j];
+                    }
+                }
             }
         }
     }
@@ -427,6 +466,7 @@ struct WsC {
     float *u2, *g2, *l2;       // (B,512,128), (B,128,4096), (B,128,256)
     float *u3, *h1, *h2, *h3, *sw3, *g3, *l3;
     float *f1, *f2;
+    float *mrel, *msw;         // member records of the stage being processed: (B,16384,4), (B,16384,16)
     size_t bytes;
 };
 
@@ -449,6 +489,7 @@ WsC carve_c(void* base, int B, int N) {
     s.u3 = (float*)take(b * 128 * 256 * 4); s.h1 = (float*)take(b * 128 * 256 * 4); s.h2 = (float*)take(b * 128 * 512 * 4);
     s.h3 = (float*)take(b * 128 * 1024 * 4); s.sw3 = (float*)take(b * 128 * 16 * 4); s.g3 = (float*)take(b * 16384 * 4);
     s.l3 = (float*)take(b * 1024 * 4); s.f1 = (float*)take(b * 512 * 4); s.f2 = (float*)take(b * 256 * 4);
+    s.mrel = (float*)take(b * 16384 * 4 * 4); s.msw = (float*)take(b * 16384 * 16 * 4);
     s.bytes = off;
     return s;
 }
@@ -464,19 +505,33 @@ int launch_pc_knn(const float* keys, int nkeys, const float* queries, int S, WsC
     return iq::check_launch("pc_knn_kernel");
 }
 
-int launch_pc_group(const iq_pointconv_sa& sa, PcGroupArgs a, int B, hipStream_t st) {
+// members -> (rel, sw) records, then the grouped kernel.  xyz (B,N,3) member coordinates, new_xyz (B,S,3) centroids,
+// idx (B,S,K), inv_density (B,N), U (B,N,ldu) or null.
+int launch_pc_group(const iq_pointconv_sa& sa, const float* xyz, const float* new_xyz, const int16_t* idx, const float* inv_density,
+                    const float* U, int ldu, float* out, WsC& s, int N, int S, int K, int B, hipStream_t st) {
+    IQ_REQUIRE((size_t)S * K <= 16384 && (S * K) % kMC == 0 && (K == 32 || K == 64), "pointconv group: S=%d K=%d", S, K);
+    const size_t total = (size_t)B * S * K;
+    const TinyNets nets{sa.densitynet, sa.weightnet};
+    const unsigned mgrid = (unsigned)((total + kThreads - 1) / kThreads);
+    if (K == 32) hipLaunchKernelGGL(pc_member_kernel<32>, dim3(mgrid), dim3(kThreads), 0, st, xyz, new_xyz, idx, inv_density, nets, s.mrel, s.msw, N, S, total);
+    else         hipLaunchKernelGGL(pc_member_kernel<64>, dim3(mgrid), dim3(kThreads), 0, st, xyz, new_xyz, idx, inv_density, nets, s.mrel, s.msw, N, S, total);
+    int rc = iq::check_launch("pc_member_kernel");
+    if (rc) return rc;
+    PcGroupArgs a{};
+    a.mrel = s.mrel; a.msw = s.msw; a.U = U; a.ldu = ldu;
     a.w1x = sa.w1x;
     a.w2 = sa.l2.w; a.b2 = sa.l2.b; a.w3 = sa.l3.w; a.b3 = sa.l3.b;
-    a.nets.dn = sa.densitynet; a.nets.wn = sa.weightnet;
-    const int gpc = kMC / a.K;
-    a.B = B;
-    a.wgs_per_cloud = (a.S + gpc - 1) / gpc;
+    a.out = out; a.N = N; a.S = S; a.K = K; a.B = B;
+    a.chunks_per_wg = 4;                                   // 256 members per workgroup: the prologue is amortised, the tail stays even
+    const int chunks = S * K / kMC;
+    a.wgs_per_cloud = (chunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
     dim3 grid((unsigned)((B + 7) / 8 * 8 * a.wgs_per_cloud));
     const int c1 = sa.l2.cin, c2 = sa.l2.cout, c3 = sa.l3.cout;
     if (c1 == 64 && c2 == 64 && c3 == 128) hipLaunchKernelGGL((pc_group_kernel<64, 64, 128>), grid, dim3(kThreads), 0, st, a);
     else if (c1 == 128 && c2 == 128 && c3 == 256) {
-        // every group runs all its K members (sums, not maxima: nothing is skipped); MFMA work = the two dense layers
-        iq::ProfileSpan dom(iq::kSlotDominant, st, 2.0 * (double)B * a.S * a.K * ((double)c1 * c2 + (double)c2 * c3));
+        // every group runs all its K members (sums, not maxima: nothing is skipped); MFMA work = the two dense layers + the
+        // contraction's 32x32x2 tiles (16 of their 32 columns carry weights)
+        iq::ProfileSpan dom(iq::kSlotDominant, st, 2.0 * (double)B * S * K * ((double)c1 * c2 + (double)c2 * c3 + 32.0 * c3));
         hipLaunchKernelGGL((pc_group_kernel<128, 128, 256>), grid, dim3(kThreads), 0, st, a);
     }
     else return iq::fail(IQ_EUNSUPPORTED, "pointconv stage %d-%d-%d has no kernel instantiation", c1, c2, c3);
@@ -513,10 +568,7 @@ extern "C" int iq_pointconv_forward(const iq_pointconv_weights* w, const float* 
         if ((rc = iq::launch_fps(xyz, s.fps1, nullptr, B, N, S1, st))) return rc;
         hipLaunchKernelGGL(pc_gather_xyz_kernel, dim3((B * S1 + 255) / 256), dim3(256), 0, st, xyz, 3, s.fps1, s.nx1, N, S1, B * S1);
         if ((rc = launch_pc_knn<32>(xyz, N, s.nx1, S1, s, s.idx1, B, st))) return rc;
-        PcGroupArgs a{};
-        a.xyz = xyz; a.new_xyz = s.nx1; a.idx = s.idx1; a.inv_density = s.inv1; a.U = nullptr; a.ldu = 0;
-        a.out = s.g1; a.N = N; a.S = S1; a.K = 32;
-        if ((rc = launch_pc_group(w->sa[0], a, B, st))) return rc;
+        if ((rc = launch_pc_group(w->sa[0], xyz, s.nx1, s.idx1, s.inv1, nullptr, 0, s.g1, s, N, S1, 32, B, st))) return rc;
         if ((rc = iq::launch_linear(s.g1, 2048, w->sa[0].linear, s.l1, 128, B * S1, 1, st))) return rc;
     }
     // ---- sa2: 512 -> 128 points, K = 64, 131 -> 128 -> 128 -> 256 --------------------------------------------------
@@ -528,10 +580,7 @@ extern "C" int iq_pointconv_forward(const iq_pointconv_weights* w, const float* 
         hipLaunchKernelGGL(pc_gather_xyz_kernel, dim3((B * S2 + 255) / 256), dim3(256), 0, st, s.nx1, 3, s.fps2, s.nx2, S1, S2, B * S2);
         if ((rc = launch_pc_knn<64>(s.nx1, S1, s.nx2, S2, s, s.idx2, B, st))) return rc;
         if ((rc = iq::launch_linear(s.l1, 128, w->sa[1].u, s.u2, 128, B * S1, 0, st))) return rc;
-        PcGroupArgs a{};
-        a.xyz = s.nx1; a.new_xyz = s.nx2; a.idx = s.idx2; a.inv_density = s.inv2; a.U = s.u2; a.ldu = 128;
-        a.out = s.g2; a.N = S1; a.S = S2; a.K = 64;
-        if ((rc = launch_pc_group(w->sa[1], a, B, st))) return rc;
+        if ((rc = launch_pc_group(w->sa[1], s.nx1, s.nx2, s.idx2, s.inv2, s.u2, 128, s.g2, s, S1, S2, 64, B, st))) return rc;
         if ((rc = iq::launch_linear(s.g2, 4096, w->sa[1].linear, s.l2, 256, B * S2, 1, st))) return rc;
     }
     // ---- sa3: group all 128 points, 259 -> 256 -> 512 -> 1024 ------------------------------------------------------

@@ -32,7 +32,6 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMC = 64;
 
 // ---- gather: out[b][s][:] = xyz[b][idx[b][s]][:] ------------------------------------------------
 __global__ void gather_xyz_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ idx,
@@ -205,8 +204,13 @@ __device__ __forceinline__ void emit_tile(f32x16 acc, float bias, int g_lo, int 
     merge_tile(reduce_tile(acc, bias), g_lo, g_hi, orow, ldo, fh);
 }
 
-template <int C1, int C2, int C3>
-__global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
+// MC = rows per chunk: 64 (two 32-row MFMA tiles per weight fragment) or 32 (one tile: half the LDS and far fewer
+// registers, so twice the workgroups per CU hide each other's barriers and stage-0 phases; each weight fragment then
+// feeds 4 MFMAs instead of 8).
+template <int C1, int C2, int C3, int MC, int WPS = (MC == 64 ? 2 : 4)>
+__global__ __launch_bounds__(kThreads, WPS) void pn2_group_kernel(GroupArgs a) {
+    constexpr int kMC = MC;
+    static_assert(MC == 64 || MC == 32, "chunk rows");
     constexpr int LD1 = C1 + 4, LD2 = C2 + 4;
     constexpr int KB1 = C1 / 8, KB2 = C2 / 8, NT2 = C2 / 32, NT3 = C3 / 32;
     __shared__ __attribute__((aligned(16))) float act1[kMC * LD1];
@@ -237,10 +241,18 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
     // Stage 0a (member -> relative coordinates) of chunk c+1 runs before the barrier that precedes L3
     // of chunk c, and the per-point layer-1 rows U[p] of chunk c+1 are requested right after that
     // barrier, so the gather latency hides behind the L3 MFMAs.  rel / blk_group are double-buffered.
-    constexpr int NR = kMC * C1 / kThreads;  // rows per thread in stage 0b
-    const int chn = tid % C1, rsub = tid / C1;
-    const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.w1x + chn * 4);
-    float ureg[NR];
+    // stage 0b: a thread owns 4 consecutive channels (c4) of NR rows; the per-point layer-1 rows U[p] arrive as 16-byte raw
+    // buffer loads (resource on this cloud's U rows, 32-bit per-lane offsets): 4x fewer vector-memory instructions and
+    // no 64-bit address arithmetic next to the MFMAs
+    constexpr int Q1 = C1 / 4;                   // channel quads per row
+    constexpr int NR = kMC * Q1 / kThreads;      // rows per thread in stage 0b
+    const int c4 = tid % Q1, rsub = tid / Q1;
+    f32x4 w1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w1[e] = *reinterpret_cast<const f32x4*>(a.w1x + (c4 * 4 + e) * 4);
+    const __amdgpu_buffer_rsrc_t ursrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.U ? a.U + (size_t)b * a.N * a.ldu : a.w1x), 0, 0x7fffffff, 0x00020000);
+    f32x4 ureg[NR];
     auto stage0a = [&](int ch, int buf) {
         if (tid < kMC) {
             int j = j0 + ch * (kMC / kBlk) + tid / kBlk;
@@ -262,9 +274,10 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
     auto gather_u = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const int r = rsub + i * (kThreads / C1);
+            const int r = rsub + i * (kThreads / Q1);
             const int p = __float_as_int(rel[(buf * kMC + r) * 4 + 3]);
-            ureg[i] = a.U ? a.U[((size_t)b * a.N + p) * a.ldu + chn] : 0.f;
+            if (a.U) ureg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (p * a.ldu + c4 * 4) * 4, 0, 0));
+            else ureg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     stage0a(0, 0);
@@ -303,16 +316,21 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
     const WBuf w2b = wbuf_make(a.w2, lane), w3b = wbuf_make(a.w3, lane);
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1, nxt = cur ^ 1;
-        const int mts = (jend - (j0 + ch * (kMC / kBlk))) > 2 ? 2 : 1;  // second m-tile holds live blocks?
-        const int ga = blk_group[cur * 4], gb = blk_group[cur * 4 + 1], gc = blk_group[cur * 4 + 2], gd = blk_group[cur * 4 + 3];
+        const int mts = (MC == 64 && (jend - (j0 + ch * (kMC / kBlk))) > 2) ? 2 : 1;  // second m-tile holds live blocks?
+        constexpr int BPC = kMC / kBlk;            // 16-row blocks per chunk
+        const int ga = blk_group[cur * BPC], gb = blk_group[cur * BPC + 1];
+        const int gc = MC == 64 ? blk_group[cur * BPC + (BPC - 2)] : -1, gd = MC == 64 ? blk_group[cur * BPC + (BPC - 1)] : -1;
         if (NT2 >= 4) wring_prime(ring2, w2b, wave_s * KB1 * kFragBytes);  // in flight across stage 0b
         // ---- stage 0b: layer 1 -> act1 -------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const int r = rsub + i * (kThreads / C1);
+            const int r = rsub + i * (kThreads / Q1);
             const f32x4 v = *reinterpret_cast<const f32x4*>(rel + (cur * kMC + r) * 4);
-            const float h = fmaf(w1[2], v[2], fmaf(w1[1], v[1], w1[0] * v[0])) + w1[3] + ureg[i];
-            act1[r * LD1 + chn] = fmaxf(h, 0.f);
+            f32x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                h[e] = fmaxf(fmaf(w1[e][2], v[2], fmaf(w1[e][1], v[1], w1[e][0] * v[0])) + w1[e][3] + ureg[i][e], 0.f);
+            *reinterpret_cast<f32x4*>(act1 + r * LD1 + c4 * 4) = h;
         }
         __syncthreads();  // act1 complete; every wave has finished L3 of the previous chunk (act2 is free)
         // ---- layer 2: C1 -> C2 (+bn, relu) -> act2 -------------------------------------------------
@@ -323,14 +341,14 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
                 f32x16 acc0 = {0}, acc1 = {0};
                 const int wq = nts * KB1 * kFragBytes;
                 const int wn = (q + 1 < NT2 / 4 ? nts + 4 : nts) * KB1 * kFragBytes;
-                if (mts == 2) mfma_ntile<LD1, KB1, 2>(a1base, w2b, wq, wn, ring2, acc0, acc1);
-                else          mfma_ntile<LD1, KB1, 1>(a1base, w2b, wq, wn, ring2, acc0, acc1);
+                if (MC == 64 && mts == 2) mfma_ntile<LD1, KB1, 2>(a1base, w2b, wq, wn, ring2, acc0, acc1);
+                else                      mfma_ntile<LD1, KB1, 1>(a1base, w2b, wq, wn, ring2, acc0, acc1);
                 const float bias = a.b2[nt * 32 + fl];
                 float* dst = c2base + nt * 32;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     dst[c_row_i(i) * LD2] = fmaxf(acc0[i] + bias, 0.f);
-                    dst[(32 + c_row_i(i)) * LD2] = fmaxf(acc1[i] + bias, 0.f);
+                    if (MC == 64) dst[(32 + c_row_i(i)) * LD2] = fmaxf(acc1[i] + bias, 0.f);
                 }
             }
         } else {
@@ -359,13 +377,13 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_kernel(GroupArgs a) {
                 f32x16 acc0 = {0}, acc1 = {0};
                 const int wq = nts * KB2 * kFragBytes;
                 const int wn = (q + 1 < NT3 / 4 ? nts + 4 : nts) * KB2 * kFragBytes;
-                if (mts == 2) mfma_ntile<LD2, KB2, 2>(a2base, w3b, wq, wn, ring3, acc0, acc1);
-                else          mfma_ntile<LD2, KB2, 1>(a2base, w3b, wq, wn, ring3, acc0, acc1);
+                if (MC == 64 && mts == 2) mfma_ntile<LD2, KB2, 2>(a2base, w3b, wq, wn, ring3, acc0, acc1);
+                else                      mfma_ntile<LD2, KB2, 1>(a2base, w3b, wq, wn, ring3, acc0, acc1);
                 const float bias = a.b3[nt * 32 + fl];
                 const TileMax m0 = reduce_tile(acc0, bias);
                 feed(q, ga, m0.lo);
                 feed(q, gb, m0.hi);
-                if (mts == 2) {
+                if (MC == 64 && mts == 2) {
                     const TileMax m1 = reduce_tile(acc1, bias);
                     feed(q, gc, m1.lo);
                     feed(q, gd, m1.hi);
@@ -417,7 +435,12 @@ int launch_group_t(GroupArgs a, int B, hipStream_t st) {
     a.B = B;
     a.wgs_per_cloud = (a.maxblocks + a.blocks_per_wg - 1) / a.blocks_per_wg;  // workgroups past a cloud's block count exit
     dim3 grid((unsigned)((B + 7) / 8 * 8 * a.wgs_per_cloud));
-    hipLaunchKernelGGL((pn2_group_kernel<C1, C2, C3>), grid, dim3(kThreads), 0, st, a);
+    if (iq::tuning(iq::kTuneChainDebug) == 32)   // experiment: 32-row chunks
+        hipLaunchKernelGGL((pn2_group_kernel<C1, C2, C3, 32>), grid, dim3(kThreads), 0, st, a);
+    else if (iq::tuning(iq::kTuneChainDebug) == 33)
+        hipLaunchKernelGGL((pn2_group_kernel<C1, C2, C3, 32, 3>), grid, dim3(kThreads), 0, st, a);
+    else
+        hipLaunchKernelGGL((pn2_group_kernel<C1, C2, C3, 64>), grid, dim3(kThreads), 0, st, a);
     return iq::check_launch("pn2_group_kernel");
 }
 
