@@ -114,12 +114,17 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
                                                                   const float* __restrict__ bias, float* __restrict__ out,
                                                                   int ldo, int M, int K, int Nout, int relu,
                                                                   const int32_t* __restrict__ m_dev,
-                                                                  const float* __restrict__ row_w) {
+                                                                  const float* __restrict__ row_w,
+                                                                  const int32_t* __restrict__ tile_nu, int rows_per_cloud) {
     constexpr int KC = 32, LDA = KC + 4;
     __shared__ __attribute__((aligned(16))) float As[2][128 * LDA];
     if (m_dev) M = min(M, *m_dev);
     const int m0 = blockIdx.x * 128;
     if (m0 >= M) return;
+    if (tile_nu) {   // rows beyond a cloud's live count are not wanted: skip tiles that hold nothing else
+        const int c = m0 / rows_per_cloud;
+        if (m0 - c * rows_per_cloud >= tile_nu[c]) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int KB = K >> 3, nchunks = K / KC;
@@ -270,19 +275,20 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
 }  // namespace
 
 int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,
-                      hipStream_t st, const int32_t* m_dev) {
+                      hipStream_t st, const int32_t* m_dev, const int32_t* tile_nu, int rows_per_cloud) {
     if (M == 0) return IQ_OK;
     IQ_REQUIRE(L.w && L.b && L.cin % 8 == 0 && L.cout >= 1, "dense layer: bad descriptor (cin=%d cout=%d)", L.cin, L.cout);
     const int ntiles = (L.cout + 31) / 32;
+    if (tile_nu && (rows_per_cloud <= 0 || rows_per_cloud % 128 != 0)) tile_nu = nullptr;   // tiles must not straddle clouds
     if (M >= 2048 && ntiles >= 4 && L.cin % 32 == 0 && iq::tuning(iq::kTuneNoLdsGemm) == 0) {
         if (ntiles >= 16 && (long long)((M + 127) / 128) * ((ntiles + 7) / 8) >= 2048) {
             dim3 grid((M + 127) / 128, (ntiles + 7) / 8);
             hipLaunchKernelGGL((pn_gemm_lds_kernel<4, false>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
-                               L.cout, relu, m_dev, nullptr);
+                               L.cout, relu, m_dev, nullptr, tile_nu, rows_per_cloud);
         } else {
             dim3 grid((M + 127) / 128, (ntiles + 3) / 4);
             hipLaunchKernelGGL((pn_gemm_lds_kernel<2, false>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
-                               L.cout, relu, m_dev, nullptr);
+                               L.cout, relu, m_dev, nullptr, tile_nu, rows_per_cloud);
         }
         return iq::check_launch("pn_gemm_lds_kernel");
     }
@@ -346,7 +352,7 @@ int iq::launch_linear_pool(const float* A, int lda, const iq_dense_layer& L, flo
         return iq::fail(IQ_EUNSUPPORTED, "dense layer + pool: cin=%d cout=%d", L.cin, L.cout);
     dim3 grid((M + 127) / 128, (ntiles + 7) / 8);
     hipLaunchKernelGGL((pn_gemm_lds_kernel<4, true>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, partial, 0, M, L.cin, L.cout,
-                       relu, m_dev, row_w);
+                       relu, m_dev, row_w, nullptr, 0);
     return iq::check_launch("pn_gemm_lds_kernel<pool>");
 }
 

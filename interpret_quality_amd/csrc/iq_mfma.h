@@ -108,8 +108,10 @@ namespace iq {
 // Batched dense layer out = act(A W^T + b) on packed weights (iq_linear.hip).
 // relu: 0 = none, 1 = ReLU, 2 = LeakyReLU(0.2).  m_dev (optional, device): the live row count when it is only
 // known on the device (ragged batches); M is then the upper bound the grid is sized for.
+// tile_nu / rows_per_cloud (optional): rows are rows_per_cloud consecutive rows per cloud, of which only the first
+// tile_nu[cloud] are wanted - 128-row tiles that lie entirely beyond are skipped (their outputs are left untouched).
 int launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,
-                  hipStream_t st, const int32_t* m_dev = nullptr);
+                  hipStream_t st, const int32_t* m_dev = nullptr, const int32_t* tile_nu = nullptr, int rows_per_cloud = 0);
 // Same layer for few rows and a very long K: K is split over workgroups in slices of 512 (independent of M), partial
 // sums pass through `scratch` (cin/512 x M x cout floats) and are added in a fixed order.
 int launch_linear_splitk(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu, float* scratch,

@@ -50,15 +50,26 @@ __global__ __launch_bounds__(kThreads) void pc_density_kernel(const float* __res
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= N) return;
     const f32x4 q = *reinterpret_cast<const f32x4*>(pts + i * 4);
+    // exp(-d / c0) / c1 summed as exp2(d * k) with the division by c1 once at the end: the N^2 loop is 3 fma + 2 add + 1 mul +
+    // v_exp_f32 per pair instead of a full-precision expf and two divisions (the density only feeds DensityNet, a smooth
+    // function; agreement with the reference stays at the 1e-6 level)
     const float c0 = 2.0f * bw * bw, c1 = 2.5f * bw;
-    float s = 0.f;
-    for (int j = 0; j < N; ++j) {
+    const float k2 = -1.4426950408889634f / c0;
+    float s0 = 0.f, s1 = 0.f;
+    int j = 0;
+    for (; j + 1 < N; j += 2) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(pts + j * 4);
-        const float dot = fmaf(q[2], v[2], fmaf(q[1], v[1], q[0] * v[0]));
-        const float d = (-2.f * dot + q[3]) + v[3];
-        s += expf(-d / c0) / c1;
+        const f32x4 u = *reinterpret_cast<const f32x4*>(pts + j * 4 + 4);
+        const float d0 = (-2.f * fmaf(q[2], v[2], fmaf(q[1], v[1], q[0] * v[0])) + q[3]) + v[3];
+        const float d1 = (-2.f * fmaf(q[2], u[2], fmaf(q[1], u[1], q[0] * u[0])) + q[3]) + u[3];
+        s0 += __builtin_amdgcn_exp2f(d0 * k2);
+        s1 += __builtin_amdgcn_exp2f(d1 * k2);
     }
-    inv_density[(size_t)b * N + i] = 1.0f / (s / (float)N);
+    if (j < N) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(pts + j * 4);
+        s0 += __builtin_amdgcn_exp2f(((-2.f * fmaf(q[2], v[2], fmaf(q[1], v[1], q[0] * v[0])) + q[3]) + v[3]) * k2);
+    }
+    inv_density[(size_t)b * N + i] = 1.0f / (((s0 + s1) / c1) / (float)N);
 }
 
 // ---- K nearest points (models/pointconv.py:103-114): queries on the lanes, keys on the accumulator rows ----
@@ -66,7 +77,7 @@ template <int K>
 __global__ __launch_bounds__(kThreads, 1) void pc_knn_kernel(const float* __restrict__ keys8 /*(B,N,8)*/,
                                                              const float* __restrict__ q8 /*(B,S,8)*/,
                                                              int16_t* __restrict__ idx /*(B,S,K)*/, int N, int S, int B,
-                                                             int wgs_per_cloud) {
+                                                             int wgs_per_cloud, const int32_t* __restrict__ n_unique) {
     constexpr int LD = 12;
     __shared__ __attribute__((aligned(16))) float tile[2][32 * LD];
     __shared__ float kxx[2][32];
@@ -75,6 +86,7 @@ __global__ __launch_bounds__(kThreads, 1) void pc_knn_kernel(const float* __rest
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;   // XCD-aware: a cloud's workgroups share one L2
     const int b = (slot / wgs_per_cloud) * 8 + xcd;
     if (b >= B) return;
+    if (n_unique && (slot % wgs_per_cloud) * 128 >= n_unique[b]) return;   // duplicate centroids (copies of centroid 0): filled later
     const float* kb = keys8 + (size_t)b * N * 8;
     const int q0 = (slot % wgs_per_cloud) * 128 + wave * 32;
     const int fl = lane & 31, fh = lane >> 5;
@@ -176,12 +188,14 @@ template <int K>
 __global__ __launch_bounds__(kThreads) void pc_member_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                              const int16_t* __restrict__ idx, const float* __restrict__ inv_density,
                                                              TinyNets nets, float* __restrict__ mrel /*(B,S,K,4)*/,
-                                                             float* __restrict__ msw /*(B,S,K,16)*/, int N, int S, size_t total) {
+                                                             float* __restrict__ msw /*(B,S,K,16)*/, int N, int S, size_t total,
+                                                             const int32_t* __restrict__ n_unique) {
     const size_t t = (size_t)blockIdx.x * kThreads + threadIdx.x;       // member index; K divides 64: groups never straddle waves
     const bool live = t < total;
     const size_t tt = live ? t : total - 1;
     const size_t g = tt / K;                                             // b * S + s
     const int bb = (int)(g / S);
+    if (n_unique && (int)(g - (size_t)bb * S) >= n_unique[bb]) return;   // a duplicate centroid's group (whole K-lane group leaves)
     const int p = idx[tt];
     const float* x = xyz + ((size_t)bb * N + p) * 3;
     const float* c = new_xyz + g * 3;
@@ -211,28 +225,31 @@ struct PcGroupArgs {
     const float* w3; const float* b3;
     float* out;                // (B,S,C3*16): [c][w]
     int N, S, K;    int B, wgs_per_cloud, chunks_per_wg;
+    const int32_t* n_unique;   // (B) or null: groups s >= n_unique[b] are copies of group 0 and are not computed
 };
 
 // One workgroup = `chunks_per_wg` consecutive 64-member chunks of one cloud (K = 32: two groups per chunk, K = 64: one).
 //   stage 0a  members' rel / sw rows -> LDS (sw transposed: swT[w][member], row 16 = zeros)      [coalesced, one chunk ahead]
 //   stage 0b  layer 1 (VALU, 4 channels per thread) + U[p] rows by 16-byte buffer loads -> act1
 //   L2, L3    fp32 MFMA as in pn2_group_kernel
-//   contraction out[c][w] = sum_k h[k][c] sw[k][w] ON THE MFMA: accumulator register i of an L3 tile, after bias + ReLU, IS
-//             the A operand (lane (c, kk) holds h[member c_row_i(i) + 4 kk][c]) of one 32x32x2 MFMA whose B operand is
-//             sw[member][w] for w < 16 and 0 for the other 16 columns - 16 MFMAs per tile at half utilisation (+17 % / +33 %
-//             matrix work for sa2 / sa1) instead of 256 FMAs + 64 LDS reads per lane and tile on the VALU while the matrix
-//             pipe of that wave sits idle, and 32 fewer live registers, which is what lets the next chunk's gather travel
-//             behind the L3 MFMAs.
+//   contraction out[c][w] = sum_k h[k][c] sw[k][w] ON THE MFMA (v_mfma_f32_16x16x4_f32, all 16 columns = the 16 WeightNet
+//             outputs): two neighbouring accumulator registers of an L3 tile (bias + ReLU applied) hold, per 16-lane row,
+//             h[member][c] for members m, m+1 (rows 0/1: channels 0-15 / 16-31) and m+4, m+5 (rows 2/3); ONE
+//             v_permlane16_swap turns the pair into the two A operands (channels 0-15 / 16-31 x those 4 members) of a
+//             16x16x4 MFMA whose B operand is sw[member][w], read from LDS as one dword per lane.  16 half-size MFMAs per
+//             32x32 tile (+8 % / +17 % matrix work for sa2 / sa1) replace 256 FMAs + 64 LDS reads per lane and tile on the
+//             VALU (during which the matrix pipe of that wave sat idle) and 32 live registers, which is what lets the next
+//             chunk's gather travel behind the L3 MFMAs.
 template <int C1, int C2, int C3>
 __global__ __launch_bounds__(kThreads, 2) void pc_group_kernel(PcGroupArgs a) {
-    constexpr int LD1 = C1 + 4, LD2 = C2 + 4, LDS_SW = kMC + 4;
+    constexpr int LD1 = C1 + 4, LD2 = C2 + 4, LDS_SW = kMC + 2;   // swT row stride 66: conflict-free dword reads
     constexpr int KB1 = C1 / 8, KB2 = C2 / 8, NT2 = C2 / 32, NT3 = C3 / 32;
     static_assert(NT3 >= 4, "C3 >= 128");
     constexpr int Q1 = C1 / 4, NR = kMC * Q1 / kThreads;
     __shared__ __attribute__((aligned(16))) float act1[kMC * LD1];
     __shared__ __attribute__((aligned(16))) float act2[kMC * LD2];
     __shared__ __attribute__((aligned(16))) float rel[2 * kMC * 4];          // dx,dy,dz, member index (bits); double-buffered
-    __shared__ __attribute__((aligned(16))) float swT[2 * 17 * LDS_SW];      // [buf][w | zero row][member]
+    __shared__ __attribute__((aligned(16))) float swT[2 * 16 * LDS_SW];      // [buf][w][member]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 1-D grid; workgroups go round-robin over the 8 XCDs: keep all workgroups of a cloud on one XCD (one L2 holds its
@@ -241,7 +258,8 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_kernel(PcGroupArgs a) {
     const int b = (slot / a.wgs_per_cloud) * 8 + xcd;
     if (b >= a.B) return;
     const int K = a.K;                                   // 32 or 64
-    const int chunks_total = a.S * K / kMC;
+    const int live_groups = a.n_unique ? min(a.S, a.n_unique[b]) : a.S;
+    const int chunks_total = (live_groups * K + kMC - 1) / kMC;
     const int ch0 = (slot % a.wgs_per_cloud) * a.chunks_per_wg;
     if (ch0 >= chunks_total) return;
     const int nchunks = min(a.chunks_per_wg, chunks_total - ch0);
@@ -253,9 +271,8 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_kernel(PcGroupArgs a) {
     const WBuf w2b = wbuf_make(a.w2, lane), w3b = wbuf_make(a.w3, lane);
     const size_t member0 = (size_t)b * a.S * K;          // first member record of this cloud
 
-    if (tid < 2 * LDS_SW) swT[(tid / LDS_SW) * 17 * LDS_SW + 16 * LDS_SW + tid % LDS_SW] = 0.f;   // the zero rows
-    // B operand rows of the contraction: lanes with w = lane & 31 < 16 read their own row of swT, the others the zero row
-    const float* swlane = swT + (fl < 16 ? fl : 16) * LDS_SW + 4 * fh;
+    // B operand of the contraction: lane (w = lane & 15, k = lane >> 4) reads sw of member base + (k & 1) + 4 (k >> 1)
+    const float* swlane = swT + (lane & 15) * LDS_SW + ((lane >> 4) & 1) + 4 * (lane >> 5);
 
     const int c4 = tid % Q1, rsub = tid / Q1;
     f32x4 w1[4];
@@ -269,7 +286,7 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_kernel(PcGroupArgs a) {
         if (tid < kMC) *reinterpret_cast<f32x4*>(rel + (buf * kMC + tid) * 4) = *reinterpret_cast<const f32x4*>(a.mrel + (m + tid) * 4);
         const int mem = tid >> 2, q4 = tid & 3;
         const f32x4 v = *reinterpret_cast<const f32x4*>(a.msw + (m + mem) * 16 + q4 * 4);
-        float* dst = swT + buf * 17 * LDS_SW + (q4 * 4) * LDS_SW + mem;
+        float* dst = swT + buf * 16 * LDS_SW + (q4 * 4) * LDS_SW + mem;
         dst[0] = v[0]; dst[LDS_SW] = v[1]; dst[2 * LDS_SW] = v[2]; dst[3 * LDS_SW] = v[3];
     };
     auto gather_u = [&](int buf) {
@@ -340,7 +357,7 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_kernel(PcGroupArgs a) {
         __syncthreads();  // act2 complete; rel[nxt] / swT[nxt] visible
         if (ch + 1 < nchunks) gather_u(nxt);                                // consumed after L3
         // ---- layer 3 + contraction over the members (MFMA) -------------------------------------------------------------
-        const float* swc = swlane + cur * 17 * LDS_SW;
+        const float* swc = swlane + cur * 16 * LDS_SW;
         const int g_first = (ch0 + ch) * (kMC / K);                         // first group of this chunk
 #pragma unroll
         for (int q = 0; q < NT3 / 4; ++q) {
@@ -350,31 +367,36 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_kernel(PcGroupArgs a) {
             const int wn = (q + 1 < NT3 / 4 ? nts + 4 : nts) * KB2 * kFragBytes;
             mfma_ntile<LD2, KB2, 2>(a2base, w3b, wq, wn, ring3, acc0, acc1);
             const float bias = a.b3[nt * 32 + fl];
-            f32x16 d0 = {0}, d1 = {0};
+            // d[mt][half]: 16x16 tiles (channels nt*32 + 16 half + 4 (lane >> 4) + j, w = lane & 15) of m-tile mt
+            f32x4 d00 = {0, 0, 0, 0}, d01 = d00, d10 = d00, d11 = d00;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {   // members 8 jj + 4 fh + (0..3) of each m-tile: accumulator registers 4 jj .. 4 jj + 3
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(swc + 8 * jj);
-                const f32x4 s1 = *reinterpret_cast<const f32x4*>(swc + 32 + 8 * jj);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = 4 * jj + e;
-                    d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(acc0[i] + bias, 0.f), s0[e], d0, 0, 0, 0);
-                    d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(acc1[i] + bias, 0.f), s1[e], d1, 0, 0, 0);
-                }
+            for (int p = 0; p < 8; ++p) {      // accumulator registers 2 p, 2 p + 1: members c_row_i(2 p) + {0, 1, 4, 5}
+                const int m = c_row_i(2 * p);
+                const float s0 = swc[m], s1 = swc[32 + m];
+                const auto a0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(fmaxf(acc0[2 * p] + bias, 0.f)),
+                                                                 __float_as_uint(fmaxf(acc0[2 * p + 1] + bias, 0.f)), false, false);
+                const auto a1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(fmaxf(acc1[2 * p] + bias, 0.f)),
+                                                                 __float_as_uint(fmaxf(acc1[2 * p + 1] + bias, 0.f)), false, false);
+                d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a0[0]), s0, d00, 0, 0, 0);
+                d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a0[1]), s0, d01, 0, 0, 0);
+                d10 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a1[0]), s1, d10, 0, 0, 0);
+                d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a1[1]), s1, d11, 0, 0, 0);
             }
-            // D tile: lane (w = fl, kk = fh), register j <-> channel nt*32 + c_row_i(j) + 4 fh; only w < 16 is real
-            if (fl < 16) {
-                if (K == 64) {        // one group: both m-tiles
-                    float* dst = a.out + ((size_t)b * a.S + g_first) * (C3 * 16) + (size_t)(nt * 32 + 4 * fh) * 16 + fl;
+            const int w = lane & 15, cq = 4 * (lane >> 4);
+            float* dst = a.out + ((size_t)b * a.S + g_first) * (C3 * 16) + (size_t)(nt * 32 + cq) * 16 + w;
+            if (K == 64) {        // one group: both m-tiles
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) dst[c_row_i(j) * 16] = d0[j] + d1[j];
-                } else {              // K == 32: m-tile 0 = group g_first, m-tile 1 = g_first + 1
-                    float* dst = a.out + ((size_t)b * a.S + g_first) * (C3 * 16) + (size_t)(nt * 32 + 4 * fh) * 16 + fl;
+                for (int j = 0; j < 4; ++j) {
+                    dst[j * 16] = d00[j] + d10[j];
+                    dst[(16 + j) * 16] = d01[j] + d11[j];
+                }
+            } else {              // K == 32: m-tile 0 = group g_first, m-tile 1 = g_first + 1
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        dst[c_row_i(j) * 16] = d0[j];
-                        dst[C3 * 16 + c_row_i(j) * 16] = d1[j];
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    dst[j * 16] = d00[j];
+                    dst[(16 + j) * 16] = d01[j];
+                    dst[C3 * 16 + j * 16] = d10[j];
+                    dst[C3 * 16 + (16 + j) * 16] = d11[j];
                 }
             }
         }
@@ -456,9 +478,19 @@ __global__ void pc_pad8_kernel(const float* __restrict__ xyz, float* __restrict_
     reinterpret_cast<f32x4*>(out)[(size_t)t * 2 + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
+// rows s >= n_unique[b] of (B,S,C) := row 0 of the cloud (duplicate centroids: FPS returns index 0 once the distinct
+// locations are used up, so those groups ARE group 0)
+__global__ void pc_fill_dup_rows_kernel(float* __restrict__ out, int S, int C, const int32_t* __restrict__ n_unique) {
+    const int b = blockIdx.y, s = n_unique[b] + blockIdx.x;
+    if (s >= S) return;
+    const float* src = out + (size_t)b * S * C;
+    float* dst = out + ((size_t)b * S + s) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) dst[c] = src[c];
+}
+
 struct WsC {
     float *inv1, *inv2, *inv3;
-    int32_t *fps1, *fps2;
+    int32_t *fps1, *fps2, *nu1;
     float *nx1, *nx2;          // (B,512,3), (B,128,3)
     float *k8, *q8;            // padded keys / queries for the kNN MFMA
     int16_t *idx1, *idx2;      // (B,512,32), (B,128,64)
@@ -480,7 +512,7 @@ WsC carve_c(void* base, int B, int N) {
     };
     const size_t b = (size_t)B;
     s.inv1 = (float*)take(b * N * 4); s.inv2 = (float*)take(b * 512 * 4); s.inv3 = (float*)take(b * 128 * 4);
-    s.fps1 = (int32_t*)take(b * 512 * 4); s.fps2 = (int32_t*)take(b * 128 * 4);
+    s.fps1 = (int32_t*)take(b * 512 * 4); s.fps2 = (int32_t*)take(b * 128 * 4); s.nu1 = (int32_t*)take(b * 4);
     s.nx1 = (float*)take(b * 512 * 3 * 4); s.nx2 = (float*)take(b * 128 * 3 * 4);
     s.k8 = (float*)take(b * ((N + 31) / 32 * 32) * 8 * 4); s.q8 = (float*)take(b * 512 * 8 * 4);
     s.idx1 = (int16_t*)take(b * 512 * 32 * 2); s.idx2 = (int16_t*)take(b * 128 * 64 * 2);
@@ -495,33 +527,35 @@ WsC carve_c(void* base, int B, int N) {
 }
 
 template <int K>
-int launch_pc_knn(const float* keys, int nkeys, const float* queries, int S, WsC& s, int16_t* idx, int B, hipStream_t st) {
+int launch_pc_knn(const float* keys, int nkeys, const float* queries, int S, WsC& s, int16_t* idx, int B, hipStream_t st,
+                  const int32_t* n_unique = nullptr) {
     const int nkp = (nkeys + 31) / 32 * 32;
     hipLaunchKernelGGL(pc_pad8_kernel, dim3((B * nkp + 255) / 256), dim3(256), 0, st, keys, s.k8, B, nkeys, nkp);
     hipLaunchKernelGGL(pc_pad8_kernel, dim3((B * S + 255) / 256), dim3(256), 0, st, queries, s.q8, B, S, S);
     const int wpc = (S + 127) / 128;
     hipLaunchKernelGGL(pc_knn_kernel<K>, dim3((unsigned)((B + 7) / 8 * 8 * wpc)), dim3(kThreads), 0, st, s.k8, s.q8, idx, nkp, S, B,
-                       wpc);
+                       wpc, n_unique);
     return iq::check_launch("pc_knn_kernel");
 }
 
 // members -> (rel, sw) records, then the grouped kernel.  xyz (B,N,3) member coordinates, new_xyz (B,S,3) centroids,
 // idx (B,S,K), inv_density (B,N), U (B,N,ldu) or null.
 int launch_pc_group(const iq_pointconv_sa& sa, const float* xyz, const float* new_xyz, const int16_t* idx, const float* inv_density,
-                    const float* U, int ldu, float* out, WsC& s, int N, int S, int K, int B, hipStream_t st) {
+                    const float* U, int ldu, float* out, WsC& s, int N, int S, int K, int B, hipStream_t st,
+                    const int32_t* n_unique = nullptr) {
     IQ_REQUIRE((size_t)S * K <= 16384 && (S * K) % kMC == 0 && (K == 32 || K == 64), "pointconv group: S=%d K=%d", S, K);
     const size_t total = (size_t)B * S * K;
     const TinyNets nets{sa.densitynet, sa.weightnet};
     const unsigned mgrid = (unsigned)((total + kThreads - 1) / kThreads);
-    if (K == 32) hipLaunchKernelGGL(pc_member_kernel<32>, dim3(mgrid), dim3(kThreads), 0, st, xyz, new_xyz, idx, inv_density, nets, s.mrel, s.msw, N, S, total);
-    else         hipLaunchKernelGGL(pc_member_kernel<64>, dim3(mgrid), dim3(kThreads), 0, st, xyz, new_xyz, idx, inv_density, nets, s.mrel, s.msw, N, S, total);
+    if (K == 32) hipLaunchKernelGGL(pc_member_kernel<32>, dim3(mgrid), dim3(kThreads), 0, st, xyz, new_xyz, idx, inv_density, nets, s.mrel, s.msw, N, S, total, n_unique);
+    else         hipLaunchKernelGGL(pc_member_kernel<64>, dim3(mgrid), dim3(kThreads), 0, st, xyz, new_xyz, idx, inv_density, nets, s.mrel, s.msw, N, S, total, n_unique);
     int rc = iq::check_launch("pc_member_kernel");
     if (rc) return rc;
     PcGroupArgs a{};
     a.mrel = s.mrel; a.msw = s.msw; a.U = U; a.ldu = ldu;
     a.w1x = sa.w1x;
     a.w2 = sa.l2.w; a.b2 = sa.l2.b; a.w3 = sa.l3.w; a.b3 = sa.l3.b;
-    a.out = out; a.N = N; a.S = S; a.K = K; a.B = B;
+    a.out = out; a.N = N; a.S = S; a.K = K; a.B = B; a.n_unique = n_unique;
     a.chunks_per_wg = 4;                                   // 256 members per workgroup: the prologue is amortised, the tail stays even
     const int chunks = S * K / kMC;
     a.wgs_per_cloud = (chunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
@@ -530,8 +564,8 @@ int launch_pc_group(const iq_pointconv_sa& sa, const float* xyz, const float* ne
     if (c1 == 64 && c2 == 64 && c3 == 128) hipLaunchKernelGGL((pc_group_kernel<64, 64, 128>), grid, dim3(kThreads), 0, st, a);
     else if (c1 == 128 && c2 == 128 && c3 == 256) {
         // every group runs all its K members (sums, not maxima: nothing is skipped); MFMA work = the two dense layers + the
-        // contraction's 32x32x2 tiles (16 of their 32 columns carry weights)
-        iq::ProfileSpan dom(iq::kSlotDominant, st, 2.0 * (double)B * S * K * ((double)c1 * c2 + (double)c2 * c3 + 32.0 * c3));
+        // contraction's 16x16x4 tiles
+        iq::ProfileSpan dom(iq::kSlotDominant, st, 2.0 * (double)B * S * K * ((double)c1 * c2 + (double)c2 * c3 + 16.0 * c3));
         hipLaunchKernelGGL((pc_group_kernel<128, 128, 256>), grid, dim3(kThreads), 0, st, a);
     }
     else return iq::fail(IQ_EUNSUPPORTED, "pointconv stage %d-%d-%d has no kernel instantiation", c1, c2, c3);
@@ -565,11 +599,15 @@ extern "C" int iq_pointconv_forward(const iq_pointconv_weights* w, const float* 
         iq::ProfileSpan span(iq::kSlotPrepool, st);
         hipLaunchKernelGGL(pc_density_kernel, dim3((N + kThreads - 1) / kThreads, B), dim3(kThreads), (size_t)N * 16, st, xyz,
                            w->sa[0].bandwidth, s.inv1, N);
-        if ((rc = iq::launch_fps(xyz, s.fps1, nullptr, B, N, S1, st))) return rc;
+        if ((rc = iq::launch_fps(xyz, s.fps1, s.nu1, B, N, S1, st))) return rc;
         hipLaunchKernelGGL(pc_gather_xyz_kernel, dim3((B * S1 + 255) / 256), dim3(256), 0, st, xyz, 3, s.fps1, s.nx1, N, S1, B * S1);
-        if ((rc = launch_pc_knn<32>(xyz, N, s.nx1, S1, s, s.idx1, B, st))) return rc;
-        if ((rc = launch_pc_group(w->sa[0], xyz, s.nx1, s.idx1, s.inv1, nullptr, 0, s.g1, s, N, S1, 32, B, st))) return rc;
-        if ((rc = iq::launch_linear(s.g1, 2048, w->sa[0].linear, s.l1, 128, B * S1, 1, st))) return rc;
+        // a masked cloud has at most kept + 1 distinct locations: once FPS has used them up it returns index 0, so centroids
+        // s >= nu1 are copies of centroid 0 and their groups (kNN, members, MLP, contraction, linear layer) are not computed
+        if ((rc = launch_pc_knn<32>(xyz, N, s.nx1, S1, s, s.idx1, B, st, s.nu1))) return rc;
+        if ((rc = launch_pc_group(w->sa[0], xyz, s.nx1, s.idx1, s.inv1, nullptr, 0, s.g1, s, N, S1, 32, B, st, s.nu1))) return rc;
+        if ((rc = iq::launch_linear(s.g1, 2048, w->sa[0].linear, s.l1, 128, B * S1, 1, st, nullptr, s.nu1, S1))) return rc;
+        hipLaunchKernelGGL(pc_fill_dup_rows_kernel, dim3(S1, B), dim3(64), 0, st, s.l1, S1, 128, s.nu1);
+        if ((rc = iq::check_launch("pc_fill_dup_rows_kernel"))) return rc;
     }
     // ---- sa2: 512 -> 128 points, K = 64, 131 -> 128 -> 128 -> 256 --------------------------------------------------
     {
