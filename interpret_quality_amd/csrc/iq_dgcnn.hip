@@ -318,14 +318,20 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
 // ---- out[i][c] = LeakyReLU(max_j P[idx[i][j]][c] + Q[i][c]) ------------------------------------------
 __global__ __launch_bounds__(kThreads) void gather_max_kernel(const float* __restrict__ pq, int Co,
                                                               const int16_t* __restrict__ idx, float* __restrict__ out,
-                                                              int ldo, Ragged rg, int B) {
+                                                              int ldo, Ragged rg, int B, int wgs_per_cloud) {
     const int per = Co / 4;                               // float4 lanes per point
-    // (an XCD-contiguous block order was tried here and lost 30 %: the 8 L2s then stream 8 distant row ranges; in the
-    // plain order all XCDs work on the same few clouds at a time and the MALL absorbs the duplicates)
-    const int t = blockIdx.x * kThreads + threadIdx.x;
-    const int pt = t / per, c4 = t - pt * per;
-    if (pt >= rg.roff[B]) return;
-    const int base = rg.roff[rg.row_cloud[pt]];
+    // Workgroups go round-robin over the 8 XCDs: give each XCD whole clouds (cloud b -> XCD b % 8, its workgroups
+    // consecutive there), so that the ~20 reads of every P row of a cloud hit ONE L2.  In plain block order the rows of a
+    // cloud were pulled into all eight L2s: FETCH_SIZE showed 4-9x the bytes of the PQ matrix per launch at 57 % L2 hit
+    // rate and the kernel ran at the fabric's 6.4 TB/s (profiles/r02_stream_kernels.csv).  Adjacent clouds run on
+    // adjacent XCDs at the same time, so the eight row streams stay close together in memory.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / wgs_per_cloud) * 8 + xcd;
+    if (b >= B) return;
+    const int base = rg.roff[b];
+    const int pt = base + (slot % wgs_per_cloud) * (kThreads / per) + threadIdx.x / per;
+    const int c4 = threadIdx.x % per;
+    if (pt >= rg.roff[b + 1]) return;
     // the 20 neighbour indices of the point: 40 contiguous bytes, read as five 8-byte words
     const uint2* nbw = reinterpret_cast<const uint2*>(idx + (size_t)pt * kK);
     int nb[kK];
@@ -335,17 +341,15 @@ __global__ __launch_bounds__(kThreads) void gather_max_kernel(const float* __res
         nb[4 * w] = (int)(v.x & 0xffffu); nb[4 * w + 1] = (int)(v.x >> 16);
         nb[4 * w + 2] = (int)(v.y & 0xffffu); nb[4 * w + 3] = (int)(v.y >> 16);
     }
-    // Latency-bound gather (rows are L2 / MALL resident): all 20 row loads of a thread are in flight together, as raw
-    // buffer loads with 32-bit offsets (one multiply-add of address arithmetic per load instead of a 64-bit chain).
-    // The resource is based at this workgroup's first cloud row block so that offsets stay far below 4 GB.
-    const int wg_base = rg.roff[rg.row_cloud[min((int)(blockIdx.x * kThreads) / per, rg.roff[B] - 1)]];
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pq) + (size_t)wg_base * (2 * Co), 0, 0x7fffffff, 0x00020000);
+    // All 20 row loads of a thread are in flight together, as raw buffer loads with 32-bit offsets on a resource based at
+    // this cloud's first row (one multiply-add of address arithmetic per load instead of a 64-bit chain).
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pq) + (size_t)base * (2 * Co), 0, 0x7fffffff, 0x00020000);
     const int row_bytes = 2 * Co * 4;
     f32x4 v[kK];
 #pragma unroll
     for (int j = 0; j < kK; ++j)
-        v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (base - wg_base + nb[j]) * row_bytes + c4 * 16, 0, 0));
-    const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (pt - wg_base) * row_bytes + (per + c4) * 16, 0, 0));
+        v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb[j] * row_bytes + c4 * 16, 0, 0));
+    const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (pt - base) * row_bytes + (per + c4) * 16, 0, 0));
     f32x4 m = v[0];
 #pragma unroll
     for (int j = 1; j < kK; ++j) {
@@ -503,9 +507,11 @@ int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, i
         {
             iq::ProfileSpan span(iq::kSlotFstn, st);
             if ((rc = iq::launch_linear(src, ld, w->pq[l], s.pq, 2 * co, rows, 0, st, live))) return rc;
-            const long long nthreads = (long long)rows * (co / 4);
-            hipLaunchKernelGGL(gather_max_kernel, dim3((unsigned)((nthreads + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
-                               s.pq, co, s.idx, s.xc + col, 512, rg, B);
+            // grid sized for the largest cloud (Np rows); workgroups past a cloud's live row count exit at once
+            const int pts_per_wg = kThreads / (co / 4);
+            const int wgs_per_cloud = ((N + 31) / 32 * 32 + pts_per_wg - 1) / pts_per_wg;
+            hipLaunchKernelGGL(gather_max_kernel, dim3((unsigned)((B + 7) / 8 * 8 * wgs_per_cloud)), dim3(kThreads), 0, st,
+                               s.pq, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud);
             if ((rc = iq::check_launch("gather_max_kernel"))) return rc;
         }
         src = s.xc + col; ld = 512; cin = co; creal = co; col += co;

@@ -435,17 +435,18 @@ int launch_group_t(GroupArgs a, int B, hipStream_t st) {
     a.B = B;
     a.wgs_per_cloud = (a.maxblocks + a.blocks_per_wg - 1) / a.blocks_per_wg;  // workgroups past a cloud's block count exit
     dim3 grid((unsigned)((B + 7) / 8 * 8 * a.wgs_per_cloud));
-    if (iq::tuning(iq::kTuneChainDebug) == 32)   // experiment: 32-row chunks
+    // the widest stage (128-128-256: 70 KB of LDS and 150 registers at 64 rows = 2 workgroups per CU) runs 32-row chunks,
+    // 4 workgroups per CU: 44.5 k -> 46.3 k coalitions/s (tuning key 5 = 64 forces 64-row chunks for A/B runs)
+    if (C3 >= 256 && iq::tuning(iq::kTuneExperiment) != 64)
         hipLaunchKernelGGL((pn2_group_kernel<C1, C2, C3, 32>), grid, dim3(kThreads), 0, st, a);
-    else if (iq::tuning(iq::kTuneChainDebug) == 33)
-        hipLaunchKernelGGL((pn2_group_kernel<C1, C2, C3, 32, 3>), grid, dim3(kThreads), 0, st, a);
     else
         hipLaunchKernelGGL((pn2_group_kernel<C1, C2, C3, 64>), grid, dim3(kThreads), 0, st, a);
     return iq::check_launch("pn2_group_kernel");
 }
 
 // FLOP the MFMA tiles of pn2_group_kernel execute for the block table just built (profiling only: reads the per-cloud block
-// counts back, one sync).  A workgroup owns blocks_per_wg 16-row blocks = chunks of 4; a chunk issues 1 or 2 32-row tiles.
+// counts back, one sync).  A workgroup owns blocks_per_wg 16-row blocks; every pair of blocks (or a last single one) is one
+// 32-row MFMA tile, whatever the chunk size.
 double group_work(const GroupArgs& a, int B, int c1, int c2, int c3, hipStream_t st) {
     std::vector<int32_t> nb((size_t)B);
     if (hipMemcpy2DAsync(nb.data(), sizeof(int32_t), a.block_start + a.S, (size_t)(a.S + 1) * sizeof(int32_t), sizeof(int32_t), (size_t)B,
@@ -455,7 +456,7 @@ double group_work(const GroupArgs& a, int B, int c1, int c2, int c3, hipStream_t
     for (int b = 0; b < B; ++b) {
         for (int j0 = 0; j0 < nb[b]; j0 += a.blocks_per_wg) {
             const int jend = std::min(nb[b], j0 + a.blocks_per_wg);
-            for (int j = j0; j < jend; j += 4) rows += (jend - j) > 2 ? 64.0 : 32.0;
+            rows += 32.0 * ((jend - j0 + 1) / 2);
         }
     }
     return rows * 2.0 * ((double)c1 * c2 + (double)c2 * c3);

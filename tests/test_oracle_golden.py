@@ -260,3 +260,19 @@ def test_oracle_dgcnn_on_a_slice_of_the_scale_fixture():
         np.testing.assert_allclose(got.numpy(), g[tag + "_logits"][p:p + 1], rtol=1e-5, atol=1e-5)
         n += got.shape[1]
     assert n == 96 and sum(g["ratio%d_logits" % int(r * 100)].shape[0] * g["ratio%d_logits" % int(r * 100)].shape[1] for r in g["ratios"]) == 2016
+
+
+@pytest.mark.parametrize("name", ["pointnet2", "pointconv"])
+def test_oracle_on_the_32_region_family_fixture(name):
+    """families_r32.npz (reference CPU run, R = 32): the oracle's PointNet++ / PointConv on one interaction pair per ratio."""
+    g = load_golden("families_r32.npz")
+    sd = synth.to_torch({"pointnet2": synth.pointnet2_state_dict, "pointconv": synth.pointconv_state_dict}[name](0))
+    fwd = {"pointnet2": O.pointnet2_forward, "pointconv": O.pointconv_forward}[name]
+    pts, _ = synth.make_cloud(int(g["cloud_id"]))
+    data = torch.from_numpy(pts).unsqueeze(0)
+    for k, ratio in enumerate(g["ratios"]):
+        tag = "%s_ratio%d" % (name, int(ratio * 100))
+        got = O.compute_order_interaction_logits(lambda x: fwd(sd, x), data, g["region_id"].astype(np.int64),
+                                                 g[name + "_pairs"][k:k + 1].astype(np.int64),
+                                                 g[tag + "_contexts"][k:k + 1].astype(np.int64), 4, is_pointnet=False)
+        np.testing.assert_allclose(got.numpy(), g[tag + "_logits"][k:k + 1], rtol=2e-5, atol=2e-5)
