@@ -432,12 +432,18 @@ constexpr int kBins = kMaxN / kMC + 2;
 __global__ __launch_bounds__(kThreads) void pn_order_count_kernel(const int32_t* __restrict__ nrows_all,
                                                                   int32_t* __restrict__ bin_of, int32_t* __restrict__ hist,
                                                                   int B) {
+    __shared__ int lh[kBins];   // per-workgroup histogram: one global atomic per bin and workgroup instead of one per item
+    if (threadIdx.x < kBins) lh[threadIdx.x] = 0;
+    __syncthreads();
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= B) return;
-    const int rows = nrows_all[item] & 0xffff;
-    const int bin = kBins - 1 - min(kBins - 1, (rows + kMC - 1) / kMC);  // bin 0 = most chunks
-    bin_of[item] = bin;
-    atomicAdd(&hist[bin], 1);
+    if (item < B) {
+        const int rows = nrows_all[item] & 0xffff;
+        const int bin = kBins - 1 - min(kBins - 1, (rows + kMC - 1) / kMC);  // bin 0 = most chunks
+        bin_of[item] = bin;
+        atomicAdd(&lh[bin], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < kBins && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
 
 __global__ void pn_order_scan_kernel(int32_t* __restrict__ hist) {
@@ -447,12 +453,24 @@ __global__ void pn_order_scan_kernel(int32_t* __restrict__ hist) {
     }
 }
 
+// position inside a bin: the workgroup reserves a range per bin with one global atomic, its items take consecutive slots
+// (the order inside a bin is irrelevant: equal chunk counts)
 __global__ __launch_bounds__(kThreads) void pn_order_scatter_kernel(const int32_t* __restrict__ bin_of,
                                                                     int32_t* __restrict__ cursor,
                                                                     int32_t* __restrict__ order, int B) {
+    __shared__ int lh[kBins], base[kBins];
+    if (threadIdx.x < kBins) lh[threadIdx.x] = 0;
+    __syncthreads();
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= B) return;
-    order[atomicAdd(&cursor[bin_of[item]], 1)] = item;
+    int bin = 0, pos = 0;
+    if (item < B) {
+        bin = bin_of[item];
+        pos = atomicAdd(&lh[bin], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < kBins && lh[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], lh[threadIdx.x]);
+    __syncthreads();
+    if (item < B) order[base[bin] + pos] = item;
 }
 
 // ---- pooled input-STN feature of a coalition: max over kept regions (+ centre) -------------

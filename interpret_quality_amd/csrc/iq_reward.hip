@@ -46,7 +46,21 @@ __global__ void shapley_sum_kernel(const double* __restrict__ sv_rows, double* _
     if (r >= R) return;
     double acc = 0.0;
     int k = 0;
-    for (int o = 0; o < S; ++o) {
+    // the adds stay strictly in permutation order; the loads run 8 rows ahead of them (a plain loop paid one memory
+    // latency per permutation: 260 us for 1000 permutations)
+    constexpr int U = 8;
+    int o = 0;
+    for (; o + U <= S; o += U) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = sv_rows[(size_t)(o + u) * R + r];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc += v[u];
+            while (k < n_snap && snap_counts[k] == o + u + 1) { snaps[(size_t)k * R + r] = acc; ++k; }
+        }
+    }
+    for (; o < S; ++o) {
         acc += sv_rows[(size_t)o * R + r];
         while (k < n_snap && snap_counts[k] == o + 1) { snaps[(size_t)k * R + r] = acc; ++k; }
     }
