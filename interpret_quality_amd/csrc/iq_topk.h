@@ -62,10 +62,13 @@ struct QueuedTopK {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             drain(lane, 8);
+            // the partner half-wave (lane ^ 32) holds the same query's top K of the OTHER half of the keys: the K-th largest
+            // of the union is at least the larger of the two K-th values, so that value filters for both
+            const float thr_f = fmaxf(thr, __shfl_xor(thr, 32));
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
                 const int r = half * 8 + rr;
-                if (d[r] > thr) {
+                if (d[r] > thr_f) {
                     q[cnt * 64 + lane] = pack(d[r], idx_base + (r & 3) + 8 * (r >> 2) + 4 * fh);
                     ++cnt;
                 }
