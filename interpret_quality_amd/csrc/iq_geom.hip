@@ -118,6 +118,71 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(const float* __restric
     if (threadIdx.x == 0 && n_unique) n_unique[blockIdx.x] = S;
 }
 
+// One WAVE per cloud, the points in registers (lane l owns points l, l + 64, ...): no LDS, no barrier.  FPS is a chain of S
+// dependent arg-max rounds, so a launch is latency-bound per cloud and throughput comes from how many clouds are in flight;
+// the workgroup form above keeps 2-3 clouds per CU busy with two barriers per round, this one a wave per cloud on every SIMD.
+// Same arithmetic per point and the same tie rule (largest distance, then lowest index), so the picks are identical.
+// The arg-max runs on a 64-bit key (float bits of the running min-distance, which is >= +0, above the complemented index);
+// the winner's coordinates are read from the lane that owns it (its local best IS the winner).
+template <int PPL>
+__global__ __launch_bounds__(64) void fps_wave_kernel(const float* __restrict__ xyz, int32_t* __restrict__ idx,
+                                                      int32_t* __restrict__ n_unique, int N, int S) {
+    const int lane = threadIdx.x;
+    const float* src = xyz + (size_t)blockIdx.x * N * 3;
+    float px[PPL], py[PPL], pz[PPL], md[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        const int p = lane + 64 * j;
+        const bool live = p < N;
+        px[j] = live ? src[p * 3] : 0.f;
+        py[j] = live ? src[p * 3 + 1] : 0.f;
+        pz[j] = live ? src[p * 3 + 2] : 0.f;
+        md[j] = live ? 1e10f : -1.f;           // a point that does not exist never wins (keys are built from md >= 0 only)
+    }
+    int far = 0;
+    float cx, cy, cz;
+    cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[0]), 0));
+    cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[0]), 0));
+    cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[0]), 0));
+    int32_t* out = idx + (size_t)blockIdx.x * S;
+    for (int it = 0; it < S; ++it) {
+        if (lane == 0) out[it] = far;
+        unsigned long long best = 0ull;         // (float bits of min-distance) << 32 | ~index ; 0 = nothing
+        float bx = 0.f, by = 0.f, bz = 0.f;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const float dx = __fsub_rn(px[j], cx), dy = __fsub_rn(py[j], cy), dz = __fsub_rn(pz[j], cz);
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            float m = md[j];
+            if (d < m && m >= 0.f) { m = d; md[j] = d; }
+            if (m >= 0.f) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(m) << 32) | (unsigned)(~(lane + 64 * j));
+                if (key > best) { best = key; bx = px[j]; by = py[j]; bz = pz[j]; }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffu), off);
+            const unsigned hi = __shfl_xor((unsigned)(best >> 32), off);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            best = other > best ? other : best;
+        }
+        const float v = __uint_as_float((unsigned)(best >> 32));
+        const int win = (int)~(unsigned)(best & 0xffffffffu);
+        if (v == 0.f) {                         // every remaining point coincides with a sampled one: arg-max returns 0 from now on
+            for (int j2 = it + 1 + lane; j2 < S; j2 += 64) out[j2] = 0;
+            if (lane == 0 && n_unique) n_unique[blockIdx.x] = it + 1;
+            return;
+        }
+        far = win;
+        const int owner = __builtin_amdgcn_readfirstlane(win) & 63;
+        cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx), owner));
+        cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by), owner));
+        cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz), owner));
+    }
+    if (lane == 0 && n_unique) n_unique[blockIdx.x] = S;
+}
+
 }  // namespace
 
 extern "C" int iq_region_assign(const float* cloud, const int32_t* fps_idx, int32_t* region_id,
@@ -133,6 +198,13 @@ int iq::launch_fps(const float* xyz, int32_t* idx, int32_t* n_unique, int B, int
     IQ_REQUIRE(B >= 0 && N > 0 && N <= 8192 && S >= 1, "iq_fps: B=%d N=%d S=%d", B, N, S);
     if (B == 0) return IQ_OK;
     IQ_REQUIRE(xyz && idx, "iq_fps: null pointer");
+    // many clouds of at most 1024 points: one wave per cloud (points in registers); few or larger clouds: one workgroup per cloud
+    if (B >= 64 && N <= 1024) {
+        if (N <= 128) hipLaunchKernelGGL(fps_wave_kernel<2>, dim3(B), dim3(64), 0, st, xyz, idx, n_unique, N, S);
+        else if (N <= 512) hipLaunchKernelGGL(fps_wave_kernel<8>, dim3(B), dim3(64), 0, st, xyz, idx, n_unique, N, S);
+        else hipLaunchKernelGGL(fps_wave_kernel<16>, dim3(B), dim3(64), 0, st, xyz, idx, n_unique, N, S);
+        return iq::check_launch("fps_wave_kernel");
+    }
     const size_t lds = (size_t)N * 4 * sizeof(float);
     if (lds > 48 * 1024) {  // above the default dynamic-LDS limit (N > 3072): opt in, up to 128 KB at N = 8192
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

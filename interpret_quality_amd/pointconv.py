@@ -120,8 +120,8 @@ def _sa_holder(cfg):
 class PointConvDensityClsSsg(nn.Module):
     """Parameter container with the reference's state-dict layout; forward runs on the HIP path."""
 
-    max_clouds_per_call = 1024  # bounds the workspace (9.4 MB per cloud)
-    preferred_clouds_per_call = 1024  # drivers batch at least this many materialised clouds per launch
+    max_clouds_per_call = 4096  # bounds the workspace (9.5 MB per cloud: 39 GB of the 288 GB; one launch covers a 3300-coalition pose)
+    preferred_clouds_per_call = 4096  # drivers batch at least this many materialised clouds per launch
 
     def __init__(self, args=None):
         super().__init__()

@@ -150,7 +150,7 @@ def _holder_msg(cfg):
 class PointNet2ClsMsg(nn.Module):
     """Parameter container with the reference's state-dict layout; forward runs on the HIP path."""
 
-    max_clouds_per_call = 2048  # bounds the workspace (2.9 MB per cloud)
+    max_clouds_per_call = 4096  # bounds the workspace (3.2 MB per cloud: 13 GB; one launch covers a 3300-coalition pose)
     preferred_clouds_per_call = 1024  # drivers batch at least this many materialised clouds per launch
 
     def __init__(self, args=None):

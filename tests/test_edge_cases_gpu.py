@@ -397,3 +397,27 @@ def test_fps_at_the_advertised_maximum_cloud_size(n):
     got = hip_ops.fps(torch.from_numpy(x).to(dev()), 64).cpu().numpy()
     want = O.farthest_point_sample(torch.from_numpy(x), 64).numpy()
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n,s", [(1024, 512), (512, 128), (100, 32), (1000, 64)])
+def test_fps_wave_per_cloud_kernel_equals_the_workgroup_kernel(n, s):
+    """iq_fps picks its kernel by the batch: >= 64 clouds of <= 1024 points run one WAVE per cloud with the points in registers,
+    smaller batches one workgroup per cloud through LDS.  Same picks on raw clouds, on masked clouds (FPS runs out of distinct
+    locations and returns index 0 from then on) and on a fully collapsed cloud; a few clouds also against the oracle."""
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(n + s)
+    clouds = []
+    for i in range(72):
+        pts = synth.make_cloud(i, 1024)[0][:n].copy()
+        if i % 3 == 1:                                    # masked: a random subset collapses onto the centre
+            drop = rng.random(n) < rng.uniform(0.3, 0.95)
+            pts[drop] = pts.mean(axis=0)
+        if i == 5:
+            pts[:] = pts[0]                               # one location only
+        clouds.append(pts)
+    x = torch.from_numpy(np.stack(clouds)).to(dev())
+    wave = hip_ops.fps(x, s).cpu().numpy()                                                 # 72 clouds: wave kernel
+    block = np.concatenate([hip_ops.fps(x[i:i + 8].contiguous(), s).cpu().numpy() for i in range(0, 72, 8)])   # 8 at a time: workgroup kernel
+    assert np.array_equal(wave, block)
+    want = O.farthest_point_sample(x[:7].cpu(), s).numpy()
+    assert np.array_equal(wave[:7], want)
