@@ -331,7 +331,11 @@ def main():
         logits = model.coalition_logits(data, center, region_id, keep, None, num_regions=R, validate=False)
         v = hip_ops.reward(logits, label, True)
         phi_sum, _, _ = hip_ops.shapley_accum(v, orders)
-        if collectives:
+        if collectives and rehearsal:     # gloo: stage through the host (gloo's device-tensor path is not what is rehearsed)
+            host = torch.empty((world * n_coal, 10), dtype=torch.float32)
+            dist.all_gather_into_tensor(host, logits.cpu())
+            gathered.copy_(host)
+        elif collectives:
             dist.all_gather_into_tensor(gathered, logits)
         return phi_sum, logits
 
@@ -351,7 +355,7 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.iq_profile_enable(0)
     if collectives:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # every rank's chunk of the gather must hold that rank's logits (rank r's own chunk is checkable locally)

@@ -81,8 +81,15 @@ def all_gather_rows(t, n_total):
         pad[:t.shape[0]] = t
     # ONE preallocated (w * cap, ...) receive buffer: all_gather_into_tensor writes every rank's chunk in place (the
     # list form of all_gather costs an extra copy per rank on RCCL, and these payloads are latency-bound)
-    out = torch.empty((w * cap,) + tail, dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, pad)
+    if t.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal runs (IQ_REHEARSAL: several ranks on one GPU, gloo): gloo's own device-tensor path is the one piece of this
+        # stack that has aborted intermittently under two ranks sharing a GPU, so device tensors are staged through the host
+        host = torch.empty((w * cap,) + tail, dtype=t.dtype)
+        dist.all_gather_into_tensor(host, pad.cpu())
+        out = host.to(t.device)
+    else:
+        out = torch.empty((w * cap,) + tail, dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, pad)
     if all(c == cap for c in counts):
         return out
     return torch.cat([out[r * cap:r * cap + c] for r, c in enumerate(counts)], dim=0)

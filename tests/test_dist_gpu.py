@@ -36,7 +36,14 @@ def _torchrun(nproc, port):
 
 def _run(cmd, cwd, env, timeout=900):
     r = subprocess.run(cmd, cwd=str(cwd), env=env, capture_output=True, text=True, timeout=timeout)
-    # the HEAD and the tail of stderr: a child's own traceback comes before torchrun's wrapper trace
+    if r.returncode != 0:
+        # keep the WHOLE output of a failed launch where it survives the run (gpurun_out/ is merged back): the assertion text below
+        # is shortened by pytest, and a child's own traceback comes before torchrun's wrapper trace
+        keep = os.path.join(REPO, "gpurun_out", "test_failures")
+        os.makedirs(keep, exist_ok=True)
+        tag = "%s_%d" % (os.path.basename([c for c in cmd if c.endswith(".py")][-1])[:-3], os.getpid())
+        with open(os.path.join(keep, tag + ".txt"), "w") as f:
+            f.write("cmd: %r\ncwd: %s\nrc: %d\n---- stdout ----\n%s\n---- stderr ----\n%s\n" % (cmd, cwd, r.returncode, r.stdout, r.stderr))
     assert r.returncode == 0, (cmd[-6:], r.stderr[:3000], r.stderr[-3000:])
     return r
 
