@@ -213,6 +213,17 @@ int iq_pointnet_coalitions(const iq_pointnet_weights* w /*host struct of device 
                            int B, int nclouds, int N, int R, int channel_first,
                            iq_stream_t stream);
 
+/* The same with PointNetfeat's `crt_points` (models/pointnet.py:83: the arg-max of the trunk's max-pool, third element of
+ * PointNetCls's output tuple): crt_points (B, 1024) int32 receives, per coalition and channel, the index of the point that
+ * attains the maximum (largest value, then the first in region-sorted row order = lowest point index for the dense
+ * forward, where all points share one region); index N stands for the centre that masked points collapse to.  NULL = the
+ * entry point above.  The hot-path callers discard crt_points (tools/final_common.py:36-37); the arg-max variant of the
+ * trunk kernel costs a few percent and is only instantiated for this entry point. */
+int iq_pointnet_coalitions_crt(const iq_pointnet_weights* w, const float* clouds, const float* centers,
+                               const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of, float* logits,
+                               float* trans_feat_packed, int32_t* crt_points, void* workspace, size_t workspace_bytes,
+                               int B, int nclouds, int N, int R, int channel_first, iq_stream_t stream);
+
 /* Algorithmic FLOP of the dense reference network per coalition (0.879 GFLOP at
  * N = 1024), the basis of bench.py's roofline figures. */
 double iq_pointnet_flops_per_coalition(int N);

@@ -93,6 +93,8 @@ SIGNATURES = {
     "iq_pointnet_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "iq_pointnet_coalitions": (_I, [ctypes.POINTER(PointNetWeights), _P, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                     _I, _I, _I, _I, _I, _P]),
+    "iq_pointnet_coalitions_crt": (_I, [ctypes.POINTER(PointNetWeights), _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ,
+                                        _I, _I, _I, _I, _I, _P]),
     "iq_pointnet_flops_per_coalition": (ctypes.c_double, [_I]),
     "iq_ball_query": (_I, [_P, _P, ctypes.c_float, _I, _P, _I, _I, _I, _P]),
     "iq_pointnet2_workspace_bytes": (_SZ, [_I]),

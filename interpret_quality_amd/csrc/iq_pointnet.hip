@@ -55,6 +55,7 @@ struct ChainArgs {
     const float* w3;
     const float* b3;
     float* out;                // (items,1024)
+    int32_t* argrow;           // (items,1024) point index of the row that attains each column maximum, or null [ARGMAX trunk only]
     int N, R, items, nclouds, with_centre;
     unsigned long long* stamps;  // diagnostic build only
 };
@@ -101,8 +102,11 @@ __device__ __forceinline__ void bring_init(BRing& ring, const WBuf& w3, int wave
 }
 
 // wave_s: the wave index as a scalar; the fragment offsets are then scalar too (iq_mfma.h: WBuf)
-template <int MTS>
-__device__ __forceinline__ void l3_pass_v2(const WBuf& w3, const float* abase, int wave_s, float (&runmax)[8], BRing& ring) {
+// ARGMAX (dense forward with crt_points only): besides the column maximum, the position in the item's row list of the row
+// that attains it (largest value, then lowest row).  `rowbase` = first row of this chunk, fh = lane >> 5.
+template <int MTS, bool ARGMAX = false>
+__device__ __forceinline__ void l3_pass_v2(const WBuf& w3, const float* abase, int wave_s, float (&runmax)[8], BRing& ring,
+                                           int (&runarg)[8], int rowbase = 0, int fh = 0) {
     const int w0 = wave_s * 16 * kFragBytes;
     int wq = w0;
 #pragma unroll 1
@@ -127,10 +131,30 @@ __device__ __forceinline__ void l3_pass_v2(const WBuf& w3, const float* abase, i
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // ring refill
             __builtin_amdgcn_sched_barrier(0);
         }
-        float m = max16(acc0);
-        if (MTS == 2) m = fmaxf(m, max16(acc1));
+        if (ARGMAX) {
+            float m = -INFINITY;
+            int r = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? fmaxf(runmax[i], m) : runmax[i];
+            for (int i = 0; i < 16; ++i) {          // rows ascend with i inside a tile: strict > keeps the lowest row
+                if (acc0[i] > m) { m = acc0[i]; r = rowbase + c_row_i(i) + 4 * fh; }
+            }
+            if (MTS == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (acc1[i] > m) { m = acc1[i]; r = rowbase + 32 + c_row_i(i) + 4 * fh; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {           // chunks come in row order: strict > again
+                const bool better = (i == q) && m > runmax[i];
+                runarg[i] = better ? r : runarg[i];
+                runmax[i] = better ? m : runmax[i];
+            }
+        } else {
+            float m = max16(acc0);
+            if (MTS == 2) m = fmaxf(m, max16(acc1));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? fmaxf(runmax[i], m) : runmax[i];
+        }
         wq = wn;
     }
 }
@@ -152,7 +176,7 @@ __device__ __forceinline__ unsigned long long stamp_now() {
         }                                                           \
     } while (0)
 
-template <int MODE, int L3V, bool STAMP = false>
+template <int MODE, int L3V, bool STAMP = false, bool ARGMAX = false>
 __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) float bufA[kMC * kLd2];  // act0 (ld 68) then act2 (ld 132)
     __shared__ __attribute__((aligned(16))) float bufB[kMC * kLd1];  // act1
@@ -188,8 +212,9 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
     float* c2base = bufA + (4 * frag_h) * kLd2 + frag_lane;         // C tiles of L2 -> act2
 
     float runmax[8];
+    int runarg[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) runmax[q] = -INFINITY;
+    for (int q = 0; q < 8; ++q) { runmax[q] = -INFINITY; runarg[q] = 0; }
 
     // Input points travel ahead in registers: lanes 0..15 of each wave own 16 rows of a chunk.  The
     // row index of chunk c+2 and the coordinates of chunk c+1 are requested while chunk c computes, so
@@ -313,8 +338,8 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
             if (mts == 2) l3_pass_v0<2>(w3b, a2base, wave_s, runmax);
             else          l3_pass_v0<1>(w3b, a2base, wave_s, runmax);
         } else {
-            if (mts == 2) l3_pass_v2<2>(w3b, a2base, wave_s, runmax, ring);
-            else          l3_pass_v2<1>(w3b, a2base, wave_s, runmax, ring);
+            if (mts == 2) l3_pass_v2<2, ARGMAX>(w3b, a2base, wave_s, runmax, ring, runarg, ch * kMC, frag_h);
+            else          l3_pass_v2<1, ARGMAX>(w3b, a2base, wave_s, runmax, ring, runarg, ch * kMC, frag_h);
         }
         IQ_STAMP(6);
     }
@@ -327,8 +352,14 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         float v = runmax[q];
-        v = fmaxf(v, __shfl_xor(v, 32));
         const int n = (q * 4 + wave) * 32 + (lane & 31);
+        if (ARGMAX) {   // the other half-wave saw rows 4..7 (+8 k) of every tile: larger value wins, then the lower row
+            const float v2 = __shfl_xor(v, 32);
+            const int r2 = __shfl_xor(runarg[q], 32);
+            const int r = (v2 > v || (v2 == v && r2 < runarg[q])) ? r2 : runarg[q];
+            if (lane < 32 && a.argrow) a.argrow[(size_t)item * kFeat + n] = (int)a.rows[(size_t)item * kRowCap + r];   // row -> point
+        }
+        v = fmaxf(v, __shfl_xor(v, 32));
         v += a.b3[n];
         if (MODE != kTrunk) v = fmaxf(v, 0.f);
         if (lane < 32) outp[n] = v;
@@ -507,6 +538,8 @@ void launch_chain(const ChainArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((pn_chain_kernel<kFstn, 2, true>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
     else if (iq::tuning(iq::kTuneL3Variant) == 0)
         hipLaunchKernelGGL((pn_chain_kernel<MODE, 0>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
+    else if (MODE == kTrunk && a.argrow)
+        hipLaunchKernelGGL((pn_chain_kernel<kTrunk, 2, false, true>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
     else
         hipLaunchKernelGGL((pn_chain_kernel<MODE, 2>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
 }
@@ -609,6 +642,15 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
                                       float* logits, float* trans_feat_packed, void* workspace,
                                       size_t workspace_bytes, int B, int nclouds, int N, int R,
                                       int channel_first, iq_stream_t stream) {
+    return iq_pointnet_coalitions_crt(w, clouds, centers, region_id, keep, cloud_of, logits, trans_feat_packed, nullptr, workspace,
+                                      workspace_bytes, B, nclouds, N, R, channel_first, stream);
+}
+
+extern "C" int iq_pointnet_coalitions_crt(const iq_pointnet_weights* w, const float* clouds, const float* centers,
+                                          const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of,
+                                          float* logits, float* trans_feat_packed, int32_t* crt_points, void* workspace,
+                                          size_t workspace_bytes, int B, int nclouds, int N, int R,
+                                          int channel_first, iq_stream_t stream) {
     IQ_REQUIRE(B >= 0 && nclouds >= 1, "iq_pointnet_coalitions: B=%d nclouds=%d", B, nclouds);
     IQ_REQUIRE(w && clouds && region_id && (logits || B == 0), "iq_pointnet_coalitions: null pointer");
     IQ_REQUIRE(N >= 1 && N <= kMaxN, "iq_pointnet_coalitions: N=%d not in [1,%d]", N, kMaxN);
@@ -616,6 +658,7 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
     IQ_REQUIRE(cloud_of || nclouds == 1 || nclouds == B, "iq_pointnet_coalitions: cloud_of required when 1 < nclouds != B");
     const int with_centre = centers ? 1 : 0;  // no centre = dense mode (nothing is ever masked)
     IQ_REQUIRE(centers || !keep, "iq_pointnet_coalitions: keep masks need centers");
+    IQ_REQUIRE(!crt_points || iq::tuning(iq::kTuneL3Variant) == 2, "iq_pointnet_coalitions_crt: crt_points need the default L3 variant");
     if (B == 0) return IQ_OK;
     const size_t need = iq_pointnet_workspace_bytes(B, nclouds, N, R);
     if (!workspace || workspace_bytes < need)
@@ -699,6 +742,7 @@ extern "C" int iq_pointnet_coalitions(const iq_pointnet_weights* w, const float*
     if ((rc = launch_linear(ws.h2, 256, w->fstn_fc3, tfp, 4096, B, 0, st))) return rc;
 
     // 3. trunk chain
+    a.argrow = crt_points;
     a.w1 = tfp; a.b1 = nullptr;
     a.w2 = w->feat_c2.w; a.b2 = w->feat_c2.b;
     a.w3 = w->feat_c3.w; a.b3 = w->feat_c3.b;

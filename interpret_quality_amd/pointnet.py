@@ -124,10 +124,11 @@ class PointNetEngine:
         return self._ws
 
     def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None, num_regions=None,
-                         channel_first=False, return_trans_feat=False):
+                         channel_first=False, return_trans_feat=False, return_crt=False):
         """clouds (nc,N,3) [or (nc,3,N)], centers (nc,3) or None (dense: nothing masked),
         region_id (nc,N) int32, keep (B,) int64 bit masks or None, cloud_of (B,) int32 or None.
-        -> logits (B, num_classes) [and packed trans_feat (B,4096)]."""
+        -> logits (B, num_classes) [, packed trans_feat (B,4096)] [, crt_points (B,1024) int32: the point that attains each
+        pooled channel's maximum, index N = the centre (iq_pointnet_coalitions_crt)]."""
         nc = clouds.shape[0]
         n = clouds.shape[2] if channel_first else clouds.shape[1]
         b = keep.shape[0] if keep is not None else (cloud_of.shape[0] if cloud_of is not None else nc)
@@ -141,24 +142,26 @@ class PointNetEngine:
                 raise _lib.IqError("%s must be a contiguous %s GPU tensor" % (nm, dt))
         logits = torch.empty((b, self.weights.num_classes), dtype=torch.float32, device=self.device)
         tfp = torch.empty((b, 4096), dtype=torch.float32, device=self.device) if return_trans_feat else None
+        crt = torch.empty((b, 1024), dtype=torch.int32, device=self.device) if return_crt else None
         need = self.lib.iq_pointnet_workspace_bytes(b, nc, n, r)
         ws = self._workspace(need)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
-        rc = self.lib.iq_pointnet_coalitions(ctypes.byref(self.weights.struct), p(clouds), p(centers), p(region_id),
-                                             p(keep), p(cloud_of), p(logits), p(tfp), p(ws), ws.numel(),
-                                             b, nc, n, r, int(channel_first),
-                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = self.lib.iq_pointnet_coalitions_crt(ctypes.byref(self.weights.struct), p(clouds), p(centers), p(region_id),
+                                                 p(keep), p(cloud_of), p(logits), p(tfp), p(crt), p(ws), ws.numel(),
+                                                 b, nc, n, r, int(channel_first),
+                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "iq_pointnet_coalitions")
-        return (logits, tfp) if return_trans_feat else logits
+        out = (logits,) + ((tfp,) if return_trans_feat else ()) + ((crt,) if return_crt else ())
+        return out if len(out) > 1 else logits
 
     def forward(self, x):
-        """Dense forward, x (B,3,N) -> (logits, trans_feat (B,64,64))."""
+        """Dense forward, x (B,3,N) -> (logits, trans_feat (B,64,64), crt_points (B,1024) int64)."""
         b, _, n = x.shape
         rid = torch.zeros((b, n), dtype=torch.int32, device=self.device)
-        logits, tfp = self.coalition_logits(x.contiguous(), None, rid, None, None, num_regions=1,
-                                            channel_first=True, return_trans_feat=True)
+        logits, tfp, crt = self.coalition_logits(x.contiguous(), None, rid, None, None, num_regions=1,
+                                                 channel_first=True, return_trans_feat=True, return_crt=True)
         trans_feat = tfp.index_select(1, self.weights.unpack_index).reshape(b, 64, 64)
-        return logits, trans_feat
+        return logits, trans_feat, crt.long()
 
 
 def _param_holder_stn(k):
@@ -208,11 +211,10 @@ class PointNetCls(nn.Module):
         return self._engine
 
     def forward(self, x):
-        """x (B,3,N) -> (logits, trans_feat, crt_points).  crt_points (the arg-max point per pooled
-        channel, models/pointnet.py:83) is not produced by the fused kernel and returned as None;
-        every caller on the hot path discards it (tools/final_common.py:36-37)."""
-        logits, trans_feat = self.engine().forward(x)
-        return logits, trans_feat, None
+        """x (B,3,N) -> (logits, trans_feat, crt_points), the reference's tuple (models/pointnet.py:109-115): crt_points (B,1024)
+        int64 = the point that attains each pooled channel's maximum (:83), from the arg-max variant of the trunk kernel.
+        The coalition path (every hot-path caller discards crt_points, tools/final_common.py:36-37) does not compute it."""
+        return self.engine().forward(x)
 
     def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None, num_regions=None, validate=True):
         """``validate``: check region_id against [0, num_regions) first (one stream sync); the drivers validate the ids

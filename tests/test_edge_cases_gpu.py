@@ -421,3 +421,37 @@ def test_fps_wave_per_cloud_kernel_equals_the_workgroup_kernel(n, s):
     assert np.array_equal(wave, block)
     want = O.farthest_point_sample(x[:7].cpu(), s).numpy()
     assert np.array_equal(wave[:7], want)
+
+
+def test_crt_points_of_coalitions_point_at_kept_points_or_the_centre(model):
+    """iq_pointnet_coalitions_crt on masked coalitions: every arg-max index is a kept point of that coalition or N (the centre
+    that masked points collapse to), and it is consistent with the dense forward on the materialised cloud where the maximum is
+    attained by a kept point."""
+    d = dev()
+    pts, _ = synth.make_cloud(6)
+    data = torch.from_numpy(pts).unsqueeze(0).to(d)
+    center = torch.mean(data, dim=1)
+    rid = hip_ops.region_assign(data[0].contiguous(), hip_ops.fps(data, 8)[0].contiguous())
+    keep_list = [0x0f, 0xf0, 0xff, 0x01]
+    keep = hip_ops.masks_to_tensor(keep_list, d)
+    eng = model.engine()
+    logits, crt = eng.coalition_logits(data, center, rid.reshape(1, -1), keep, None, num_regions=8, return_crt=True)
+    crt = crt.cpu().numpy()
+    rid_np = rid.cpu().numpy()
+    for b, k in enumerate(keep_list):
+        kept = ((k >> rid_np) & 1).astype(bool)
+        ok = (crt[b] == 1024) | kept[np.minimum(crt[b], 1023)]
+        assert ok.all()
+        if k == 0xff:
+            assert (crt[b] < 1024).all()                       # nothing masked: no centre row
+    masked = torch.from_numpy(masked_by_keep(pts, rid_np, keep_list, center[0].cpu().numpy())).permute(0, 2, 1).contiguous().to(d)
+    dense_logits, _, dense_crt = model(masked)
+    assert torch.equal(dense_logits, logits)                    # fused == dense, still bitwise with the arg-max variant
+    dense_crt = dense_crt.cpu().numpy()
+    for b, k in enumerate(keep_list):
+        kept = ((k >> rid_np) & 1).astype(bool)
+        at_kept = crt[b] < 1024
+        # in the materialised cloud a masked point sits at the centre: where the coalition's arg-max is a kept point the dense
+        # forward finds the same point unless a masked copy of the centre ties... compare only channels won by kept points on both sides
+        both = at_kept & kept[np.minimum(dense_crt[b], 1023)]
+        assert (crt[b][both] == dense_crt[b][both]).mean() > 0.99

@@ -197,7 +197,12 @@ def test_region_assign(oracle, num_regions):
 def test_pointnet_dense_forward(model, oracle, pointnet_sd):
     g = load_golden("pointnet_dense.npz")
     x = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in range(4)]).permute(0, 2, 1).contiguous()
-    logits, trans_feat, _ = model(x.to(dev()))
+    logits, trans_feat, crt = model(x.to(dev()))
+    # crt_points (models/pointnet.py:83), the third element of the reference's tuple: the point that attains each pooled
+    # channel's maximum, from the arg-max variant of the trunk kernel; the reference's own 4 x 1024 indices (a near-tie between
+    # two points may resolve differently under a different fp32 summation order: at most 4 of 4096 may differ)
+    assert crt.dtype == torch.int64 and tuple(crt.shape) == (4, 1024)
+    assert int((crt.cpu().numpy() != g["crt_points"]).sum()) <= 4
     assert rel_err(logits.cpu().numpy(), g["logits"]) < RTOL
     assert_close_elementwise(logits.cpu().numpy(), g["logits"])   # and element-wise, with an absolute floor (conftest.py)
     o_logits, o_tf, _ = oracle.PointNetOracle(pointnet_sd)(x)
