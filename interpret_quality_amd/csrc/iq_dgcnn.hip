@@ -289,10 +289,7 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
             ++t;
             if (dbg == 2) { half = 2; continue; }
         }
-        // The two half-waves of a query each keep the top 20 of THEIR half of the keys; the 20th largest of the union is at
-        // least the larger of the two 20th values, so that larger value is a valid filter for both (a key below it cannot be
-        // among the final 20): about a third fewer candidates reach the sorted inserts than with each lane's own threshold.
-        const float thr_f = fmaxf(top.thr, __shfl_xor(top.thr, 32));
+        const float thr_f = top.union_threshold();   // bound on the 20th largest of both half-waves' keys (iq_topk.h)
         // queue the candidates of this half of the tile (accumulator registers 8 half .. 8 half + 7)
         const int ib = (t - 1) * 32 + 4 * fh + 16 * half;
 #pragma unroll

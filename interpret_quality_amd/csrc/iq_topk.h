@@ -39,6 +39,16 @@ struct QueuedTopK {
         v[0] = fmax(c, v[0]);
         thr = (float)v[K - 1];
     }
+    // Filter threshold for candidates: the two half-waves of a query (lane, lane ^ 32) each keep the top K of THEIR half of the
+    // keys, sorted.  a_i of one list and b_j of the other with i + j + 2 >= K give K elements >= min(a_i, b_j), so the K-th
+    // largest of the union - below which no key can reach the final K - is at least that; the best of five such pairs is
+    // used (own and partner's K-th, the two medians, the two quartile crossings).  Against each lane's own K-th value this
+    // cuts the sorted inserts by a quarter (68 -> 50 per lane at K = 20, n = 544).
+    __device__ __forceinline__ float union_threshold() const {
+        const float a1 = (float)v[K / 4 - 1], a2 = (float)v[K / 2 - 1], a3 = (float)v[3 * K / 4 - 1], a4 = thr;
+        const float b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32), b3 = __shfl_xor(a3, 32), b4 = __shfl_xor(a4, 32);
+        return fmaxf(fmaxf(a4, b4), fmaxf(fminf(a2, b2), fmaxf(fminf(a1, b3), fminf(a3, b1))));
+    }
     __device__ __forceinline__ void round(int lane) {
         double c = -INFINITY;
         if (cnt > 0) c = q[(--cnt) * 64 + lane];
@@ -62,9 +72,7 @@ struct QueuedTopK {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             drain(lane, 8);
-            // the partner half-wave (lane ^ 32) holds the same query's top K of the OTHER half of the keys: the K-th largest
-            // of the union is at least the larger of the two K-th values, so that value filters for both
-            const float thr_f = fmaxf(thr, __shfl_xor(thr, 32));
+            const float thr_f = union_threshold();
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
                 const int r = half * 8 + rr;
