@@ -365,6 +365,227 @@ __global__ __launch_bounds__(kThreads) void gather_max_kernel(const float* __res
     *reinterpret_cast<f32x4*>(out + (size_t)pt * ldo + c4 * 4) = o;
 }
 
+// ---- the same with the P rows of a cloud staged in LDS -----------------------------------------------------------------
+// Every P row of a cloud is read ~20 times (once per query that has it among its neighbours), in no order the caches can
+// use: gather_max_kernel moves 20 x the P matrix through the texture-address path and L2 (7 TB/s measured, the fabric's
+// limit).  Here a workgroup owns (cloud, channel chunk): it streams its D x cw slice of P into LDS once (coalesced, every
+// byte of P leaves L2 once), and the 20 reads per output come from LDS.  cw is chosen per cloud so that the slice fills the
+// 64 KB budget (D <= 256: 64 channels, <= 512: 32, <= 1024: 16); the grid holds Co / 16 workgroups per cloud and the
+// surplus ones of small clouds exit at once.  Two workgroups per CU: one streams while the other gathers.
+// max() is order-independent on the finite values here, so the result is bit-identical to gather_max_kernel.
+constexpr int kGlThreads = 512;
+constexpr int kGlFloats = 16384;   // 64 KB of P slice per workgroup
+constexpr int kGlMaxRows = 1024;   // D * 16 channels must fit
+
+__global__ __launch_bounds__(kGlThreads, 4) void gather_lds_kernel(const float* __restrict__ pq, int Co,
+                                                                const int16_t* __restrict__ idx, float* __restrict__ out,
+                                                                int ldo, Ragged rg, int B, int wgs_per_cloud) {
+    __shared__ f32x4 slice[kGlFloats / 4];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;   // whole clouds per XCD, as in gather_max_kernel
+    const int b = (slot / wgs_per_cloud) * 8 + xcd;
+    if (b >= B) return;
+    const int base = rg.roff[b];
+    const int D = rg.roff[b + 1] - base;
+    int shift = 2;                                            // log2(float4 lanes per row of the slice)
+    if (D * 32 <= kGlFloats && Co >= 32) shift = 3;
+    if (D * 64 <= kGlFloats && Co >= 64) shift = 4;
+    const int per = 1 << shift, cw = 4 * per;
+    const int chunk = slot % wgs_per_cloud;
+    if (chunk * cw >= Co || D == 0) return;
+    const int c0 = chunk * cw;                                // first channel of this workgroup
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pq) + (size_t)base * (2 * Co), 0, 0x7fffffff, 0x00020000);
+    const int row_bytes = 2 * Co * 4;
+    const int items = D << shift;                             // (row, float4 lane) pairs, <= 4096; D % 32 == 0
+    const int tid = threadIdx.x;
+    // the neighbour lists (40 bytes per row, five 8-byte words) and the Q values of an item; the first item's are
+    // requested before the slice, every later item's one item ahead
+    const __amdgpu_buffer_rsrc_t irsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(idx) + (size_t)base * kK, 0, 0x7fffffff, 0x00020000);
+    struct Item { uint2 w[kK / 4]; f32x4 q; };
+    auto fetch = [&](int t) {
+        Item it;
+        const int r = min(t, items - 1) >> shift, c4 = t & (per - 1);
+#pragma unroll
+        for (int w = 0; w < kK / 4; ++w) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(irsrc, r * (kK * 2) + 8 * w, 0, 0);
+            it.w[w] = __builtin_bit_cast(uint2, v);
+        }
+        it.q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, r * row_bytes + (Co + c0 + 4 * c4) * 4, 0, 0));
+        return it;
+    };
+    Item cur = fetch(tid);
+    // phase 1: the slice, all (up to eight) loads of a thread in flight (items is a multiple of 128, at most 4096)
+    {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = tid + u * kGlThreads;
+            const int off = (t >> shift) * row_bytes + (c0 + 4 * (t & (per - 1))) * 4;
+            if (t < items) v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = tid + u * kGlThreads;
+            if (t < items) slice[t] = v[u];
+        }
+    }
+    __syncthreads();
+    // phase 2
+    const unsigned last = (unsigned)D - 1u;
+    for (int t = tid; t < items; t += kGlThreads) {
+        const int r = t >> shift, c4 = t & (per - 1);
+        const Item it = cur;
+        if (t + kGlThreads < items) cur = fetch(t + kGlThreads);
+        const f32x4 q = it.q;
+        unsigned nb[kK];
+#pragma unroll
+        for (int w = 0; w < kK / 4; ++w) {
+            const uint2 v = it.w[w];
+            nb[4 * w] = v.x & 0xffffu; nb[4 * w + 1] = v.x >> 16;
+            nb[4 * w + 2] = v.y & 0xffffu; nb[4 * w + 3] = v.y >> 16;
+        }
+        f32x4 m = slice[(min(nb[0], last) << shift) + c4];
+#pragma unroll
+        for (int j = 1; j < kK; ++j) {
+            const f32x4 v = slice[(min(nb[j], last) << shift) + c4];   // min: rows outside the slice are never addressed
+            m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float y = m[e] + q[e];
+            o[e] = y > 0.f ? y : 0.2f * y;
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)(base + r) * ldo + c0 + 4 * c4) = o;
+    }
+}
+
+// ---- EdgeConv layer in one kernel: P/Q GEMM + neighbourhood max --------------------------------------------------------
+// out[i][c] = LeakyReLU(max_j P[idx[i][j]][c] + Q[i][c]) with [P | Q] = x W^T + bias computed HERE: the (rows, 2 Co) matrix
+// never goes to HBM (the separate GEMM wrote it and the gather read it back: 2 x 8 KB per row over the four layers, and
+// both ran at 2-3 TB/s).  A workgroup owns (cloud, 16 output channels).  The MFMA runs TRANSPOSED: its 32 "rows" are 32
+// columns of the layer - 16 of P and the 16 of Q for the same channels - and its 32 "columns" are 32 points, so one
+// 32x32 tile gives a lane (point = lane & 31, half h) P and Q of 8 channels of its point:
+//     accumulator i:  0-3  P[4h + i]    4-7  P[8 + 4h + (i-4)]    8-11  Q[4h + (i-8)]    12-15  Q[8 + 4h + (i-12)]
+// (weights are the A operand: lane m = lane & 31 holds column m < 16 ? c0 + m : Co + c0 + m - 16 of the packed image;
+// products and the order over k are those of the plain GEMM, so the results are bit-identical to launch_linear +
+// gather_max_kernel).  P goes to LDS (D x 16 floats <= 64 KB), Q stays in the accumulators; after the barrier every lane
+// takes the maxima of its point's 20 neighbours from LDS (two 16-byte reads per neighbour) and writes 2 x 16 bytes.
+// Two workgroups per CU: the MFMA phase of one runs under the LDS phase of the other.
+template <int KB>   // Cin / 8
+__global__ __launch_bounds__(kGlThreads, 4) void edge_fused_kernel(const float* __restrict__ x, int ldx,
+                                                                   const float* __restrict__ wp, const float* __restrict__ bias,
+                                                                   int Co, const int16_t* __restrict__ idx,
+                                                                   float* __restrict__ out, int ldo, Ragged rg, int B,
+                                                                   int wgs_per_cloud) {
+    __shared__ f32x4 slice[kGlFloats / 4];                    // [row][4 float4]
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;   // whole clouds per XCD, as in gather_max_kernel
+    const int b = (slot / wgs_per_cloud) * 8 + xcd;
+    if (b >= B) return;
+    const int base = rg.roff[b];
+    const int D = rg.roff[b + 1] - base;                      // multiple of 32, <= kGlMaxRows (host)
+    if (D == 0) return;
+    const int c0 = (slot % wgs_per_cloud) * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const int ntiles = D >> 5;
+    const int nv = min(4, max(0, (ntiles - wave + 7) >> 3));  // this wave's point tiles: wave, wave + 8, ... (wave-uniform)
+
+    const int n = p < 16 ? c0 + p : Co + c0 + p - 16;         // layer column in MFMA row `p`
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7fffffff, 0x00020000);
+    const int wvoff = (((n >> 5) * KB) * 64 + (n & 31) + 32 * h) * 16;
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)base * ldx, 0, 0x7fffffff, 0x00020000);
+    int xvoff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xvoff[u] = ((min(wave + 8 * u, ntiles - 1) * 32 + p) * ldx + 4 * h) * 4;
+    auto wfrag = [&](int kb) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, kb * kFragBytes, 0)); };
+    auto xfrag = [&](int u, int kb) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff[u], kb * 32, 0)); };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = (f32x16){0};
+    f32x4 wn = wfrag(0), xn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xn[u] = xfrag(u, 0);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const f32x4 wf = wn;
+        f32x4 xf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xf[u] = xn[u];
+        if (kb + 1 < KB) {
+            wn = wfrag(kb + 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xn[u] = xfrag(u, kb + 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < nv) acc[u] = mfma4(wf, xf[u], acc[u]);
+    }
+    // bias of this lane's 8 channels: P columns c0 + 4h.., c0 + 8 + 4h.. and the Q columns Co further on
+    const f32x4 bp0 = *reinterpret_cast<const f32x4*>(bias + c0 + 4 * h), bp1 = *reinterpret_cast<const f32x4*>(bias + c0 + 8 + 4 * h);
+    const f32x4 bq0 = *reinterpret_cast<const f32x4*>(bias + Co + c0 + 4 * h), bq1 = *reinterpret_cast<const f32x4*>(bias + Co + c0 + 8 + 4 * h);
+    const __amdgpu_buffer_rsrc_t irs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(idx) + (size_t)base * kK, 0, 0x7fffffff, 0x00020000);
+    struct Nb { uint2 w[kK / 4]; };
+    auto fetch_nb = [&](int u) {
+        Nb v;
+        const int r = min(wave + 8 * u, ntiles - 1) * 32 + p;
+#pragma unroll
+        for (int w = 0; w < kK / 4; ++w) v.w[w] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(irs, r * (kK * 2) + 8 * w, 0, 0));
+        return v;
+    };
+    Nb cur = fetch_nb(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (u < nv) {
+            const int r = (wave + 8 * u) * 32 + p;
+            f32x4 p0, p1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { p0[e] = acc[u][e] + bp0[e]; p1[e] = acc[u][4 + e] + bp1[e]; }
+            slice[r * 4 + h] = p0;
+            slice[r * 4 + 2 + h] = p1;
+        }
+    }
+    __syncthreads();
+    const unsigned last = (unsigned)D - 1u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (u < nv) {
+            const Nb it = cur;
+            if (u + 1 < nv) cur = fetch_nb(u + 1);
+            const int r = (wave + 8 * u) * 32 + p;
+            unsigned nb[kK];
+#pragma unroll
+            for (int w = 0; w < kK / 4; ++w) {
+                const uint2 v = it.w[w];
+                nb[4 * w] = v.x & 0xffffu; nb[4 * w + 1] = v.x >> 16;
+                nb[4 * w + 2] = v.y & 0xffffu; nb[4 * w + 3] = v.y >> 16;
+            }
+            f32x4 m0 = slice[min(nb[0], last) * 4 + h], m1 = slice[min(nb[0], last) * 4 + 2 + h];
+#pragma unroll
+            for (int j = 1; j < kK; ++j) {
+                const unsigned a = min(nb[j], last) * 4 + h;   // min: rows outside the slice are never addressed
+                const f32x4 v0 = slice[a], v1 = slice[a + 2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { m0[e] = fmaxf(m0[e], v0[e]); m1[e] = fmaxf(m1[e], v1[e]); }
+            }
+            f32x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y0 = m0[e] + (acc[u][8 + e] + bq0[e]), y1 = m1[e] + (acc[u][12 + e] + bq1[e]);
+                o0[e] = y0 > 0.f ? y0 : 0.2f * y0;
+                o1[e] = y1 > 0.f ? y1 : 0.2f * y1;
+            }
+            float* o = out + (size_t)(base + r) * ldo + c0 + 4 * h;
+            *reinterpret_cast<f32x4*>(o) = o0;
+            *reinterpret_cast<f32x4*>(o + 8) = o1;
+        }
+    }
+}
+
 // ---- global max and mean pooling over the N points of each cloud: folded into conv5 (launch_linear_pool) -------------
 // Kept rows count once, the centre (all copies identical) counts with its multiplicity M = N - kept (row_w).
 // second stage of the pooling after launch_linear_pool: tiles of 32 rows never straddle clouds
@@ -507,12 +728,39 @@ int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, i
         }
         {
             iq::ProfileSpan span(iq::kSlotFstn, st);
+            const int Np = (N + 31) / 32 * 32;
+            const int knob = iq::tuning(iq::kTuneExperiment);   // 7: GEMM + L2 gather, 8: GEMM + LDS gather (A/B and tests)
+            const bool fits = Np <= kGlMaxRows && co % 16 == 0;
+            if (fits && knob != 7 && knob != 8 && (cin == 8 || cin == 64 || cin == 128) &&
+                reinterpret_cast<uintptr_t>(w->pq[l].b) % 16 == 0) {
+                // the whole layer in one kernel: co / 16 workgroups per cloud
+                const int wgs_per_cloud = co / 16;
+                const dim3 grid((unsigned)((B + 7) / 8 * 8 * wgs_per_cloud));
+                const iq_dense_layer& L = w->pq[l];
+                if (cin == 8)
+                    hipLaunchKernelGGL(edge_fused_kernel<1>, grid, dim3(kGlThreads), 0, st, src, ld, L.w, L.b, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud);
+                else if (cin == 64)
+                    hipLaunchKernelGGL(edge_fused_kernel<8>, grid, dim3(kGlThreads), 0, st, src, ld, L.w, L.b, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud);
+                else
+                    hipLaunchKernelGGL(edge_fused_kernel<16>, grid, dim3(kGlThreads), 0, st, src, ld, L.w, L.b, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud);
+                if ((rc = iq::check_launch("edge_fused_kernel"))) return rc;
+                src = s.xc + col; ld = 512; cin = co; creal = co; col += co;
+                continue;
+            }
             if ((rc = iq::launch_linear(src, ld, w->pq[l], s.pq, 2 * co, rows, 0, st, live))) return rc;
-            // grid sized for the largest cloud (Np rows); workgroups past a cloud's live row count exit at once
-            const int pts_per_wg = kThreads / (co / 4);
-            const int wgs_per_cloud = ((N + 31) / 32 * 32 + pts_per_wg - 1) / pts_per_wg;
-            hipLaunchKernelGGL(gather_max_kernel, dim3((unsigned)((B + 7) / 8 * 8 * wgs_per_cloud)), dim3(kThreads), 0, st,
-                               s.pq, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud);
+            if (fits && knob != 7) {
+                // P slices through LDS: co / 16 workgroups per cloud (the surplus ones of small clouds exit at once)
+                const int wgs_per_cloud = co / 16;
+                hipLaunchKernelGGL(gather_lds_kernel, dim3((unsigned)((B + 7) / 8 * 8 * wgs_per_cloud)), dim3(kGlThreads), 0, st,
+                                   s.pq, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud);
+            } else {
+                // clouds of more than 1024 rows: straight from L2
+                // grid sized for the largest cloud (Np rows); workgroups past a cloud's live row count exit at once
+                const int pts_per_wg = kThreads / (co / 4);
+                const int wgs_per_cloud = (Np + pts_per_wg - 1) / pts_per_wg;
+                hipLaunchKernelGGL(gather_max_kernel, dim3((unsigned)((B + 7) / 8 * 8 * wgs_per_cloud)), dim3(kThreads), 0, st,
+                                   s.pq, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud);
+            }
             if ((rc = iq::check_launch("gather_max_kernel"))) return rc;
         }
         src = s.xc + col; ld = 512; cin = co; creal = co; col += co;

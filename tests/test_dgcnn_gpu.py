@@ -207,3 +207,46 @@ def test_interaction_shape_properties_at_bench_size():
     i1 = interaction.compute_order_interaction(logits, lbl, args)
     i2 = interaction.compute_order_interaction(swapped, lbl, args)
     assert i1.shape == (30, 100) and np.abs(i1 - i2).max() < 1e-6   # (v0 + v3) - v1 - v2 vs (v0 + v3) - v2 - v1 in float32
+
+
+@pytest.mark.parametrize("cls", [DGCNN_cls, GCNN_cls])
+def test_fused_edgeconv_is_bitwise_the_gemm_plus_gather(cls):
+    """edge_fused_kernel (P/Q GEMM transposed onto the MFMA, P slice of the cloud in LDS, neighbourhood max from LDS) against
+    the separate GEMM + gather_lds_kernel (tuning key 5 = 8) and GEMM + gather_max_kernel (5 = 7): the same products in
+    the same order and the same maxima, so bit-identical logits - dense clouds and compact coalitions of every size class."""
+    from interpret_quality_amd import _lib
+    lib = _lib.load()
+    model = make(cls)
+    d = dev()
+    rng = np.random.default_rng(5)
+    clouds = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in (0, 1)]).to(d)
+    rid = torch.from_numpy(rng.integers(0, 32, size=(2, 1024)).astype(np.int32)).to(d)
+    centers = clouds.mean(dim=1)
+    full = (1 << 32) - 1
+    keep = [full, 0, 1, 3, 0xff, 0xffff, 0xffffff, full ^ 1, 0x0f0f0f0f, 0x55555555, 1 << 31, 0x3fffffff] * 3
+    cloud_of = [i % 2 for i in range(len(keep))]
+    keep_t = hip_ops.masks_to_tensor(keep, d)
+    co_t = torch.tensor(cloud_of, dtype=torch.int32, device=d)
+
+    def both():
+        return (model.coalition_logits(clouds, centers, rid, keep_t, co_t, num_regions=32).clone(),
+                model.forward_points(clouds).clone())
+    fused = both()
+    for knob in (8, 7):
+        lib.iq_set_tuning(5, knob)
+        try:
+            split = both()
+        finally:
+            lib.iq_set_tuning(5, 0)
+        assert torch.equal(fused[0], split[0]) and torch.equal(fused[1], split[1]), knob
+
+
+def test_forward_on_clouds_of_more_than_1024_points(oracle):
+    """N = 1500 (the P slice of a cloud no longer fits the LDS budget: the L2 gather runs) against the CPU oracle."""
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.uniform(-1, 1, size=(2, 1500, 3)).astype(np.float32))
+    sd = synth.to_torch(synth.dgcnn_state_dict(0))
+    with torch.no_grad():
+        want = oracle.dgcnn_forward(sd, x.permute(0, 2, 1).contiguous(), 20, False)
+    got = make(DGCNN_cls).forward_points(x.to(dev()))
+    assert_close_elementwise(got.cpu().numpy(), want.numpy())
