@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
         const unsigned long long busy = __ballot(top.cnt > 0);
         const bool last = half == 2 && t == ntiles;
         if (busy != 0 && (last || __popcll(busy) >= 16 || __any(top.cnt > 8))) {
-            if (dbg == 3) { ++dbg_rounds; dbg_work += __popcll(busy); }
+            if ((dbg & 3) == 3) { ++dbg_rounds; dbg_work += __popcll(busy); }
             top.round(lane);
             continue;
         }
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
             }
             half = 0;
             ++t;
-            if (dbg == 2) { half = 2; continue; }
+            if ((dbg & 3) == 2) { half = 2; continue; }
         }
         const float thr_f = top.union_threshold();   // bound on the 20th largest of both half-waves' keys (iq_topk.h)
         // queue the candidates of this half of the tile (accumulator registers 8 half .. 8 half + 7)
@@ -301,9 +301,9 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
             }
         }
         ++half;
-        if (dbg == 1) top.cnt = 0;
+        if ((dbg & 3) == 1) top.cnt = 0;
     }
-    if (dbg == 3 && lane == 0) {  // diagnostic counters (tools/knn_probe.py)
+    if ((dbg & 3) == 3 && lane == 0) {  // diagnostic counters (tools/knn_probe.py)
         atomicAdd(&g_knn_dbg[0], (unsigned long long)dbg_rounds);
         atomicAdd(&g_knn_dbg[1], (unsigned long long)dbg_work);
         atomicAdd(&g_knn_dbg[2], 1ull);
@@ -473,13 +473,38 @@ __global__ __launch_bounds__(kGlThreads, 4) void gather_lds_kernel(const float* 
 // gather_max_kernel).  P goes to LDS (D x 16 floats <= 64 KB), Q stays in the accumulators; after the barrier every lane
 // takes the maxima of its point's 20 neighbours from LDS (two 16-byte reads per neighbour) and writes 2 x 16 bytes.
 // Two workgroups per CU: the MFMA phase of one runs under the LDS phase of the other.
+//
+// Operand traffic.  The 32 x Cin weight slice of the workgroup (<= 16 KB) is staged in LDS once and read from there
+// as fragments.  A wave works through its point tiles one after the other; the x fragments of FOUR k-blocks - the
+// 128-byte line of every row - are requested back to back, one group ahead of the MFMAs, so each line of x is fetched
+// from L2 once (requested k-block by k-block with MFMAs of four tiles in between, the 32-byte pieces of a line arrived
+// in an L1 that 16 waves had long flushed: four L2 fetches per line, 4.2 ms for the 128 -> 256 layer instead of 2.x).
+__device__ unsigned long long g_edge_dbg[8];   // tuning key 5 = 10: shader cycles per phase summed over workgroups (wave 0), count
+__global__ void edge_dbg_print_kernel(int layer) {
+    const double n = (double)g_edge_dbg[5];
+    printf("edge_fused layer %d: %llu workgroups; cycles per workgroup (wave 0): prologue+weights %.0f, MFMA phase %.0f, "
+           "wait at slice barrier %.0f, gather %.0f, total %.0f; tiles per wave 0: %.2f\n", layer, g_edge_dbg[5],
+           g_edge_dbg[0] / n, g_edge_dbg[1] / n, g_edge_dbg[2] / n, g_edge_dbg[3] / n, g_edge_dbg[4] / n, g_edge_dbg[6] / n);
+    for (int i = 0; i < 8; ++i) g_edge_dbg[i] = 0;
+}
+__device__ __forceinline__ unsigned long long edge_clock() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
 template <int KB>   // Cin / 8
 __global__ __launch_bounds__(kGlThreads, 4) void edge_fused_kernel(const float* __restrict__ x, int ldx,
                                                                    const float* __restrict__ wp, const float* __restrict__ bias,
                                                                    int Co, const int16_t* __restrict__ idx,
                                                                    float* __restrict__ out, int ldo, Ragged rg, int B,
-                                                                   int wgs_per_cloud) {
+                                                                   int wgs_per_cloud, int stamps = 0) {
+    constexpr int G = KB >= 4 ? 4 : KB;                       // k-blocks per group (one 128-byte line of x when KB >= 4)
+    constexpr int NG = KB / G;
     __shared__ f32x4 slice[kGlFloats / 4];                    // [row][4 float4]
+    __shared__ f32x4 wl[KB * 64];                             // weight fragments [kb][lane]
+    unsigned long long ts[5];
+    if (stamps) ts[0] = edge_clock();
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;   // whole clouds per XCD, as in gather_max_kernel
     const int b = (slot / wgs_per_cloud) * 8 + xcd;
     if (b >= B) return;
@@ -492,41 +517,38 @@ __global__ __launch_bounds__(kGlThreads, 4) void edge_fused_kernel(const float* 
     const int ntiles = D >> 5;
     const int nv = min(4, max(0, (ntiles - wave + 7) >> 3));  // this wave's point tiles: wave, wave + 8, ... (wave-uniform)
 
-    const int n = p < 16 ? c0 + p : Co + c0 + p - 16;         // layer column in MFMA row `p`
+    // weight slice -> LDS: entry e = (kb, lane l) is the fragment element of MFMA row m = l & 31, half l >> 5
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7fffffff, 0x00020000);
-    const int wvoff = (((n >> 5) * KB) * 64 + (n & 31) + 32 * h) * 16;
+    for (int e = tid; e < KB * 64; e += kGlThreads) {
+        const int kb = e >> 6, l = e & 63, m = l & 31;
+        const int n = m < 16 ? c0 + m : Co + c0 + m - 16;     // layer column in MFMA row m
+        wl[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, ((((n >> 5) * KB + kb) * 64) + (n & 31) + (l & 32)) * 16, 0, 0));
+    }
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)base * ldx, 0, 0x7fffffff, 0x00020000);
-    int xvoff[4];
+    auto xvoff = [&](int u) { return ((min(wave + 8 * u, ntiles - 1) * 32 + p) * ldx + 4 * h) * 4; };
+    struct XG { f32x4 f[G]; };
+    auto xgroup = [&](int voff, int g) {
+        XG r;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) xvoff[u] = ((min(wave + 8 * u, ntiles - 1) * 32 + p) * ldx + 4 * h) * 4;
-    auto wfrag = [&](int kb) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, kb * kFragBytes, 0)); };
-    auto xfrag = [&](int u, int kb) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff[u], kb * 32, 0)); };
-
-    f32x16 acc[4];
+        for (int j = 0; j < G; ++j) r.f[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, (g * G + j) * 32, 0));
+        return r;
+    };
+    // Operand pipeline: the x group (global) and the weight group (LDS) of stage q + 1 are requested before the MFMAs of
+    // stage q (a stage = G k-blocks of one tile = 4 G MFMAs); sched_group_barrier pins that order - left alone the
+    // scheduler read two weight fragments, waited for them, issued 8 MFMAs, read the next two ... and the wave stood
+    // still for an LDS round trip (behind the other workgroup's gather traffic) every 8 MFMAs: 50 % MFMA-busy.
+    constexpr int TOTAL = 4 * NG;
+    struct WGp { f32x4 f[G]; };
+    auto wgroup = [&](int g) {
+        WGp r;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc[u] = (f32x16){0};
-    f32x4 wn = wfrag(0), xn[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) xn[u] = xfrag(u, 0);
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        const f32x4 wf = wn;
-        f32x4 xf[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) xf[u] = xn[u];
-        if (kb + 1 < KB) {
-            wn = wfrag(kb + 1);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) xn[u] = xfrag(u, kb + 1);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (u < nv) acc[u] = mfma4(wf, xf[u], acc[u]);
-    }
-    // bias of this lane's 8 channels: P columns c0 + 4h.., c0 + 8 + 4h.. and the Q columns Co further on
-    const f32x4 bp0 = *reinterpret_cast<const f32x4*>(bias + c0 + 4 * h), bp1 = *reinterpret_cast<const f32x4*>(bias + c0 + 8 + 4 * h);
-    const f32x4 bq0 = *reinterpret_cast<const f32x4*>(bias + Co + c0 + 4 * h), bq1 = *reinterpret_cast<const f32x4*>(bias + Co + c0 + 8 + 4 * h);
+        for (int j = 0; j < G; ++j) r.f[j] = wl[(g * G + j) * 64 + lane];
+        return r;
+    };
+    XG xr[2];
+    WGp wr[2];
+    xr[0] = xgroup(xvoff(0), 0);
     const __amdgpu_buffer_rsrc_t irs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(idx) + (size_t)base * kK, 0, 0x7fffffff, 0x00020000);
     struct Nb { uint2 w[kK / 4]; };
@@ -537,19 +559,59 @@ __global__ __launch_bounds__(kGlThreads, 4) void edge_fused_kernel(const float* 
         for (int w = 0; w < kK / 4; ++w) v.w[w] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(irs, r * (kK * 2) + 8 * w, 0, 0));
         return v;
     };
-    Nb cur = fetch_nb(0);
+    // bias of the 16 channels (P) and of their Q columns: wave-uniform, in SGPRs; a lane picks its 8 by h
+    float bps[16], bqs[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        bps[e] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bias[c0 + e])));
+        bqs[e] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bias[Co + c0 + e])));
+    }
+    __syncthreads();                                          // wl complete
+    if (stamps) ts[1] = edge_clock();
+    wr[0] = wgroup(0);
+
+    // The slice is XOR-swizzled: float4 column c of row r sits at r * 4 + (c ^ ((r >> 2) & 3)).  Unswizzled, the 16 lanes
+    // of a ds_read_b128 lane group (same h, random rows) all read column h: 16 of the 64 banks, a 4-way conflict at best.
+    // With the swizzle a row's column lands in one of 16 slots (SQ_LDS_BANK_CONFLICT per LDS instruction 17 -> 7 cycles).
+    f32x4 q0[4], q1[4];                                       // Q of this lane's channels, per tile
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         if (u < nv) {
+            f32x16 acc = {0};
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int q = u * NG + g;
+                const XG xf = xr[q & 1];
+                const WGp wf = wr[q & 1];
+                if (q + 1 < TOTAL) {
+                    const int un = (q + 1) / NG;              // compile-time after unrolling
+                    xr[(q + 1) & 1] = xgroup(xvoff(min(un, nv - 1)), (q + 1) % NG);
+                    wr[(q + 1) & 1] = wgroup((q + 1) % NG);
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j) acc = mfma4(wf.f[j], xf.f[j], acc);
+                if (q + 1 < TOTAL) {
+                    __builtin_amdgcn_sched_group_barrier(0x020, G, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, G, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * G, 0);
+            }
             const int r = (wave + 8 * u) * 32 + p;
             f32x4 p0, p1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { p0[e] = acc[u][e] + bp0[e]; p1[e] = acc[u][4 + e] + bp1[e]; }
-            slice[r * 4 + h] = p0;
-            slice[r * 4 + 2 + h] = p1;
+            for (int e = 0; e < 4; ++e) {
+                p0[e] = acc[e] + (h ? bps[4 + e] : bps[e]); p1[e] = acc[4 + e] + (h ? bps[12 + e] : bps[8 + e]);
+                q0[u][e] = acc[8 + e] + (h ? bqs[4 + e] : bqs[e]); q1[u][e] = acc[12 + e] + (h ? bqs[12 + e] : bqs[8 + e]);
+            }
+            const int a = r * 4 + (h ^ ((r >> 2) & 3));
+            slice[a] = p0;
+            slice[a ^ 2] = p1;
         }
     }
-    __syncthreads();
+    Nb cur = fetch_nb(0);                                     // neighbour lists of the first tile (in flight across the barrier)
+    if (stamps) ts[2] = edge_clock();
+    __syncthreads();                                          // slice complete
+    if (stamps) ts[3] = edge_clock();
     const unsigned last = (unsigned)D - 1u;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -564,18 +626,19 @@ __global__ __launch_bounds__(kGlThreads, 4) void edge_fused_kernel(const float* 
                 nb[4 * w] = v.x & 0xffffu; nb[4 * w + 1] = v.x >> 16;
                 nb[4 * w + 2] = v.y & 0xffffu; nb[4 * w + 3] = v.y >> 16;
             }
-            f32x4 m0 = slice[min(nb[0], last) * 4 + h], m1 = slice[min(nb[0], last) * 4 + 2 + h];
+            auto at = [&](unsigned row) { const unsigned rr = min(row, last); return rr * 4 + (h ^ ((rr >> 2) & 3)); };   // min: rows outside the slice are never addressed
+            f32x4 m0 = slice[at(nb[0])], m1 = slice[at(nb[0]) ^ 2];
 #pragma unroll
             for (int j = 1; j < kK; ++j) {
-                const unsigned a = min(nb[j], last) * 4 + h;   // min: rows outside the slice are never addressed
-                const f32x4 v0 = slice[a], v1 = slice[a + 2];
+                const unsigned a = at(nb[j]);
+                const f32x4 v0 = slice[a], v1 = slice[a ^ 2];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { m0[e] = fmaxf(m0[e], v0[e]); m1[e] = fmaxf(m1[e], v1[e]); }
             }
             f32x4 o0, o1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float y0 = m0[e] + (acc[u][8 + e] + bq0[e]), y1 = m1[e] + (acc[u][12 + e] + bq1[e]);
+                const float y0 = m0[e] + q0[u][e], y1 = m1[e] + q1[u][e];
                 o0[e] = y0 > 0.f ? y0 : 0.2f * y0;
                 o1[e] = y1 > 0.f ? y1 : 0.2f * y1;
             }
@@ -583,6 +646,12 @@ __global__ __launch_bounds__(kGlThreads, 4) void edge_fused_kernel(const float* 
             *reinterpret_cast<f32x4*>(o) = o0;
             *reinterpret_cast<f32x4*>(o + 8) = o1;
         }
+    }
+    if (stamps && tid == 0) {
+        ts[4] = edge_clock();
+        atomicAdd(&g_edge_dbg[0], ts[1] - ts[0]); atomicAdd(&g_edge_dbg[1], ts[2] - ts[1]); atomicAdd(&g_edge_dbg[2], ts[3] - ts[2]);
+        atomicAdd(&g_edge_dbg[3], ts[4] - ts[3]); atomicAdd(&g_edge_dbg[4], ts[4] - ts[0]); atomicAdd(&g_edge_dbg[5], 1ull);
+        atomicAdd(&g_edge_dbg[6], (unsigned long long)nv);
     }
 }
 
@@ -738,11 +807,12 @@ int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, i
                 const dim3 grid((unsigned)((B + 7) / 8 * 8 * wgs_per_cloud));
                 const iq_dense_layer& L = w->pq[l];
                 if (cin == 8)
-                    hipLaunchKernelGGL(edge_fused_kernel<1>, grid, dim3(kGlThreads), 0, st, src, ld, L.w, L.b, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud);
+                    hipLaunchKernelGGL(edge_fused_kernel<1>, grid, dim3(kGlThreads), 0, st, src, ld, L.w, L.b, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud, knob == 10);
                 else if (cin == 64)
-                    hipLaunchKernelGGL(edge_fused_kernel<8>, grid, dim3(kGlThreads), 0, st, src, ld, L.w, L.b, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud);
+                    hipLaunchKernelGGL(edge_fused_kernel<8>, grid, dim3(kGlThreads), 0, st, src, ld, L.w, L.b, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud, knob == 10);
                 else
-                    hipLaunchKernelGGL(edge_fused_kernel<16>, grid, dim3(kGlThreads), 0, st, src, ld, L.w, L.b, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud);
+                    hipLaunchKernelGGL(edge_fused_kernel<16>, grid, dim3(kGlThreads), 0, st, src, ld, L.w, L.b, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud, knob == 10);
+                if (knob == 10) hipLaunchKernelGGL(edge_dbg_print_kernel, dim3(1), dim3(1), 0, st, l + 1);
                 if ((rc = iq::check_launch("edge_fused_kernel"))) return rc;
                 src = s.xc + col; ld = 512; cin = co; creal = co; col += co;
                 continue;
