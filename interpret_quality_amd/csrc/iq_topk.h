@@ -33,10 +33,29 @@ struct QueuedTopK {
     static __device__ __forceinline__ double pack(float d, int idx) {
         return __longlong_as_double(__double_as_longlong((double)d) | (long long)idx);
     }
+    // v_min_f64 / v_max_f64 written out: through fmin() / fmax() the compiler quiets every operand it cannot prove
+    // canonical first (v_max_f64 x, x, x) - the whole list, since it is carried by a loop - and an insert cost 60 fp64
+    // instructions instead of 39 (8.8 cycles each per wave: tools/micro/valu_rate.hip).  No NaN ever enters the list.
+    static __device__ __forceinline__ double min_f64(double a, double b) {
+        double r;
+        asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
+    static __device__ __forceinline__ double max_f64(double a, double b) {
+        double r;
+        asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
     __device__ __forceinline__ void insert(double c) {
+        if (K <= 32) {
 #pragma unroll
-        for (int i = K - 1; i >= 1; --i) v[i] = fmax(fmin(c, v[i - 1]), v[i]);
-        v[0] = fmax(c, v[0]);
+            for (int i = K - 1; i >= 1; --i) v[i] = max_f64(min_f64(c, v[i - 1]), v[i]);
+            v[0] = max_f64(c, v[0]);
+        } else {   // K = 64: the list spills into AGPRs, which the asm operands cannot name (10 more spills, 40 % slower)
+#pragma unroll
+            for (int i = K - 1; i >= 1; --i) v[i] = fmax(fmin(c, v[i - 1]), v[i]);
+            v[0] = fmax(c, v[0]);
+        }
         thr = (float)v[K - 1];
     }
     // Filter threshold for candidates: the two half-waves of a query (lane, lane ^ 32) each keep the top K of THEIR half of the
