@@ -113,8 +113,10 @@ __global__ __launch_bounds__(kThreads) void ball_query_kernel(BallArgs a) {
     }
 }
 
-// ---- block table: group g of cloud b owns ceil(cnt/16) blocks of 16 rows (0 if g >= n_unique) -------
-constexpr int kBlk = 16;
+// ---- block table: group g of cloud b owns ceil(cnt/8) blocks of 8 rows (0 if g >= n_unique) ---------
+// 8-row blocks (a quarter of a 32-row MFMA tile): a group wastes 4 rows on average instead of 8 - 4 % fewer MFMA tiles on
+// the BASELINE shape, where a ball holds ~70 members.
+constexpr int kBlk = 8;
 
 __global__ __launch_bounds__(kThreads) void pn2_blocks_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ n_unique,
                                                               int32_t* __restrict__ block_start /*(B,S+1)*/,
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void pn2_blocks_kernel(const int32_t* __r
     if (t == kThreads - 1) block_start[(size_t)b * (S + 1) + S] = part[t];
 }
 
-// ---- grouped MLP + max over ragged 16-row blocks ------------------------------------------------------
+// ---- grouped MLP + max over ragged 8-row blocks -------------------------------------------------------
 struct GroupArgs {
     const float* xyz;        // (B,N,ldx) member coordinates (first 3 floats of each row)
     int ldx;
@@ -177,31 +179,36 @@ __device__ __forceinline__ void merge_max(float* addr, float v) {
     atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));  // v >= +0: float order == int order
 }
 
-__device__ __forceinline__ float max8(f32x16 c, int half) {
-    return half == 0 ? fmaxf(fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])), fmaxf(fmaxf(c[4], c[5]), fmaxf(c[6], c[7])))
-                     : fmaxf(fmaxf(fmaxf(c[8], c[9]), fmaxf(c[10], c[11])), fmaxf(fmaxf(c[12], c[13]), fmaxf(c[14], c[15])));
-}
-
-// column max of the two 16-row halves of a 32x32 accumulator tile (valid on the lower half-wave), bias + ReLU applied
-struct TileMax { float lo, hi; };
+// column max of the four 8-row quarters of a 32x32 accumulator tile (valid on the lower half-wave), bias + ReLU applied:
+// rows 8 q .. 8 q + 7 live in registers 4 q .. 4 q + 3 of both half-waves
+struct TileMax { float v[4]; };
 __device__ __forceinline__ TileMax reduce_tile(f32x16 acc, float bias) {
-    float lo = max8(acc, 0), hi = max8(acc, 1);   // rows 0-15 live in registers 0-7, rows 16-31 in 8-15
-    lo = fmaxf(lo, __shfl_xor(lo, 32));
-    hi = fmaxf(hi, __shfl_xor(hi, 32));
-    return {fmaxf(lo + bias, 0.f), fmaxf(hi + bias, 0.f)};
-}
-// ... merged into the groups that own the two halves
-__device__ __forceinline__ void merge_tile(TileMax m, int g_lo, int g_hi, float* orow, int ldo, int fh) {
-    if (fh != 0) return;
-    if (g_lo == g_hi) {
-        if (g_lo >= 0) merge_max(orow + (size_t)g_lo * ldo, fmaxf(m.lo, m.hi));
-    } else {
-        if (g_lo >= 0) merge_max(orow + (size_t)g_lo * ldo, m.lo);
-        if (g_hi >= 0) merge_max(orow + (size_t)g_hi * ldo, m.hi);
+    TileMax m;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x = fmaxf(fmaxf(acc[4 * q], acc[4 * q + 1]), fmaxf(acc[4 * q + 2], acc[4 * q + 3]));
+        x = fmaxf(x, __shfl_xor(x, 32));
+        m.v[q] = fmaxf(x + bias, 0.f);
     }
+    return m;
 }
-__device__ __forceinline__ void emit_tile(f32x16 acc, float bias, int g_lo, int g_hi, float* orow, int ldo, int fh) {
-    merge_tile(reduce_tile(acc, bias), g_lo, g_hi, orow, ldo, fh);
+// ... merged into the groups that own the quarters (consecutive quarters of one group first combined)
+__device__ __forceinline__ void emit_tile(f32x16 acc, float bias, const int* g, float* orow, int ldo, int fh) {
+    const TileMax m = reduce_tile(acc, bias);
+    if (fh != 0) return;
+    int run = g[0];
+    float v = m.v[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        if (g[q] == run) {
+            v = fmaxf(v, m.v[q]);
+        } else {
+            if (run >= 0) merge_max(orow + (size_t)run * ldo, v);
+            run = g[q];
+            v = m.v[q];
+        }
+    }
+    if (run >= 0) merge_max(orow + (size_t)run * ldo, v);
 }
 
 // MC = rows per chunk: 64 (two 32-row MFMA tiles per weight fragment) or 32 (one tile: half the LDS and far fewer
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(kThreads, WPS) void pn2_group_kernel(GroupArgs a) {
     __shared__ __attribute__((aligned(16))) float act1[kMC * LD1];
     __shared__ __attribute__((aligned(16))) float act2[kMC * LD2];
     __shared__ __attribute__((aligned(16))) float rel[2 * kMC * 4];  // dx,dy,dz, member index (bits); double-buffered
-    __shared__ int blk_group[2 * (kMC / kBlk)];                      // owner group of a chunk's 4 blocks (-1 = none)
+    __shared__ int blk_group[2 * (kMC / kBlk)];                      // owner group of a chunk's blocks (-1 = none)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 1-D grid, workgroups round-robin over the 8 XCDs: all workgroups of a cloud on one XCD (its U rows, coordinates and
@@ -316,10 +323,11 @@ __global__ __launch_bounds__(kThreads, WPS) void pn2_group_kernel(GroupArgs a) {
     const WBuf w2b = wbuf_make(a.w2, lane), w3b = wbuf_make(a.w3, lane);
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1, nxt = cur ^ 1;
-        const int mts = (MC == 64 && (jend - (j0 + ch * (kMC / kBlk))) > 2) ? 2 : 1;  // second m-tile holds live blocks?
-        constexpr int BPC = kMC / kBlk;            // 16-row blocks per chunk
-        const int ga = blk_group[cur * BPC], gb = blk_group[cur * BPC + 1];
-        const int gc = MC == 64 ? blk_group[cur * BPC + (BPC - 2)] : -1, gd = MC == 64 ? blk_group[cur * BPC + (BPC - 1)] : -1;
+        constexpr int BPC = kMC / kBlk;            // 8-row blocks per chunk (4 per MFMA tile)
+        const int mts = (MC == 64 && (jend - (j0 + ch * BPC)) > BPC / 2) ? 2 : 1;  // second m-tile holds live blocks?
+        int gq[BPC];                               // owner groups of the chunk's blocks (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < BPC; ++i) gq[i] = blk_group[cur * BPC + i];
         if (NT2 >= 4) wring_prime(ring2, w2b, wave_s * KB1 * kFragBytes);  // in flight across stage 0b
         // ---- stage 0b: layer 1 -> act1 -------------------------------------------------------------
 #pragma unroll
@@ -381,12 +389,12 @@ __global__ __launch_bounds__(kThreads, WPS) void pn2_group_kernel(GroupArgs a) {
                 else                      mfma_ntile<LD2, KB2, 1>(a2base, w3b, wq, wn, ring3, acc0, acc1);
                 const float bias = a.b3[nt * 32 + fl];
                 const TileMax m0 = reduce_tile(acc0, bias);
-                feed(q, ga, m0.lo);
-                feed(q, gb, m0.hi);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) feed(q, gq[i], m0.v[i]);
                 if (MC == 64 && mts == 2) {
                     const TileMax m1 = reduce_tile(acc1, bias);
-                    feed(q, gc, m1.lo);
-                    feed(q, gd, m1.hi);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) feed(q, gq[(BPC - 4) + i], m1.v[i]);
                 }
             }
         } else {
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(kThreads, WPS) void pn2_group_kernel(GroupArgs a) {
                     acc = mfma4(lds_frag<LD2>(a2base + mt * 32 * LD2, 0, kb), wbuf_load(w3b, wq + kb * kFragBytes), acc);
                 const float bias = a.b3[nt * 32 + fl];
                 float* orow = a.out + (size_t)b * a.S * a.ldo + nt * 32 + fl;
-                emit_tile(acc, bias, mt == 0 ? ga : gc, mt == 0 ? gb : gd, orow, a.ldo, fh);
+                emit_tile(acc, bias, gq + (mt == 0 ? 0 : BPC - 4), orow, a.ldo, fh);
             }
         }
     }
@@ -445,7 +453,7 @@ int launch_group_t(GroupArgs a, int B, hipStream_t st) {
 }
 
 // FLOP the MFMA tiles of pn2_group_kernel execute for the block table just built (profiling only: reads the per-cloud block
-// counts back, one sync).  A workgroup owns blocks_per_wg 16-row blocks; every pair of blocks (or a last single one) is one
+// counts back, one sync).  A workgroup owns blocks_per_wg 8-row blocks; every four blocks (or a last partial set) are one
 // 32-row MFMA tile, whatever the chunk size.
 double group_work(const GroupArgs& a, int B, int c1, int c2, int c3, hipStream_t st) {
     std::vector<int32_t> nb((size_t)B);
@@ -456,7 +464,7 @@ double group_work(const GroupArgs& a, int B, int c1, int c2, int c3, hipStream_t
     for (int b = 0; b < B; ++b) {
         for (int j0 = 0; j0 < nb[b]; j0 += a.blocks_per_wg) {
             const int jend = std::min(nb[b], j0 + a.blocks_per_wg);
-            rows += 32.0 * ((jend - j0 + 1) / 2);
+            rows += 32.0 * ((jend - j0 + 3) / 4);
         }
     }
     return rows * 2.0 * ((double)c1 * c2 + (double)c2 * c3);
@@ -467,13 +475,14 @@ int launch_group(const iq_pn2_scale& sc, GroupArgs a, const int32_t* n_unique, i
     a.w2 = sc.l2.w; a.b2 = sc.l2.b;
     a.w3 = sc.l3.w; a.b3 = sc.l3.b;
     a.K = sc.nsample;
-    // 12 blocks = 3 chunks of 64 rows per workgroup: enough to amortise the prologue, small enough for an even tail
-    // (32: -4 %, 128: -18 %); tuning key 6 overrides for experiments
-    a.blocks_per_wg = iq::tuning(iq::kTuneGroupBlocks) > 0 ? iq::tuning(iq::kTuneGroupBlocks) : 12;
+    // 24 blocks = 192 rows = 3 chunks of 64 rows per workgroup: enough to amortise the prologue, small enough for an even
+    // tail (512 rows: -4 %, 2048: -18 %); tuning key 6 overrides for experiments (a multiple of 8: whole chunks)
+    a.blocks_per_wg = iq::tuning(iq::kTuneGroupBlocks) > 0 ? (iq::tuning(iq::kTuneGroupBlocks) + 7) / 8 * 8 : 24;
     a.maxblocks = a.S * ((a.K + kBlk - 1) / kBlk);
     const int c1 = sc.l2.cin, c2 = sc.l2.cout, c3 = sc.l3.cout;
     IQ_REQUIRE(sc.l3.cin == c2, "pointnet2 scale: layer sizes do not chain");
     IQ_REQUIRE(a.S <= 4 * kThreads, "pointnet2: S=%d too large for the block scan", a.S);
+    IQ_REQUIRE(a.maxblocks <= 8192, "pointnet2: %d groups x %d samples exceed the block table", a.S, a.K);
     hipLaunchKernelGGL(pn2_blocks_kernel, dim3(B), dim3(kThreads), 0, st, a.cnt, n_unique, const_cast<int32_t*>(a.block_start),
                        const_cast<uint16_t*>(a.blockmap), a.S, a.maxblocks);
     int rc = iq::check_launch("pn2_blocks_kernel");
@@ -656,7 +665,7 @@ struct GatherArgs {
 // members to table rows (member index -> region bit -> row map: three dependent loads, now side by side over the lanes
 // instead of one after the other per member) and appends the rows of kept members to a compact list in LDS; masked
 // members are all the same point (the centre), whose row is appended once.  Pass 2: every lane walks the compact list
-// with four row loads in flight.  (The single loop - index, bit, map, row per member, one member at a time - was bound by
+// with eight row loads in flight.  (The single loop - index, bit, map, row per member, one member at a time - was bound by
 // the latency of that chain: 8.2 ms per 3300-coalition step for the three scales.)
 __global__ __launch_bounds__(kThreads) void pt_gather_kernel(GatherArgs a) {
     __shared__ int32_t rows[kThreads / 16][128 + 4];   // per group: compact row list (K <= 128), padded to a multiple of 4
@@ -713,15 +722,16 @@ __global__ __launch_bounds__(kThreads) void pt_gather_kernel(GatherArgs a) {
     // ---- pass 2 ----
     const f32x4* F = reinterpret_cast<const f32x4*>(a.feat);
     f32x4 m = {0.f, 0.f, 0.f, 0.f};                 // rows are post-ReLU (>= 0) and every group has >= 1 member
-    for (int j = 0; j < count; j += 4) {
-        int r[4];
+    constexpr int U = 8;
+    for (int j = 0; j < count; j += U) {
+        int r[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) r[u] = list[min(j + u, count - 1)];   // the tail repeats the last row (max is idempotent)
-        f32x4 v[4];
+        for (int u = 0; u < U; ++u) r[u] = list[min(j + u, count - 1)];   // the tail repeats the last row (max is idempotent)
+        f32x4 v[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = F[(size_t)r[u] * per + c4];
+        for (int u = 0; u < U; ++u) v[u] = F[(size_t)r[u] * per + c4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             m[0] = fmaxf(m[0], v[u][0]); m[1] = fmaxf(m[1], v[u][1]); m[2] = fmaxf(m[2], v[u][2]); m[3] = fmaxf(m[3], v[u][3]);
         }
     }
@@ -736,7 +746,7 @@ struct Ws2 {
     int32_t* cnt1[3];      // (B,512)
     int32_t* cnt2[3];      // (B,128)
     int32_t* bstart;       // (B,513) block table of the scale being processed
-    uint16_t* bmap;        // (B,4096)
+    uint16_t* bmap;        // (B,8192): 512 groups x 128 / 8 blocks at most
     float* l1;             // (B,512,320)
     float* U;              // (B,512,320)
     int16_t* idx2[3];      // (B,128,K)
@@ -761,7 +771,7 @@ Ws2 carve2(void* base, int B, const iq_pointnet2_weights* w) {
     for (int q = 0; q < 3; ++q) s.idx1[q] = (int16_t*)take(b * 512 * (w ? w->sa1[q].nsample : 128) * 2);
     for (int q = 0; q < 3; ++q) { s.cnt1[q] = (int32_t*)take(b * 512 * 4); s.cnt2[q] = (int32_t*)take(b * 128 * 4); }
     s.bstart = (int32_t*)take(b * 513 * 4);
-    s.bmap = (uint16_t*)take(b * 4096 * 2);
+    s.bmap = (uint16_t*)take(b * 8192 * 2);
     s.l1 = (float*)take(b * 512 * 320 * 4);
     s.U = (float*)take(b * 512 * 320 * 4);
     for (int q = 0; q < 3; ++q) s.idx2[q] = (int16_t*)take(b * 128 * (w ? w->sa2[q].nsample : 128) * 2);
@@ -809,7 +819,9 @@ int run_pn2(const iq_pointnet2_weights* w, const float* xyz, float* logits, cons
     hipLaunchKernelGGL(gather_xyz_kernel, dim3((B * S1 + 255) / 256), dim3(256), 0, st, xyz, s.fps1, s.nx1, 3, N, S1, B * S1);
     if ((rc = iq::check_launch("gather_xyz_kernel"))) return rc;
     if ((rc = launch_ball(xyz, s.nx1, 3, w->sa1, 3, s.idx1, s.cnt1, nullptr, B, N, S1, st))) return rc;
-    if (hipMemsetAsync(s.l1, 0, (size_t)B * S1 * F1 * sizeof(float), st) != hipSuccess)
+    // the grouped kernel merges straddling groups with an atomic max (zero-initialised output); the table gather stores
+    const bool all_tables = tab && tab->use[0] && tab->use[1] && tab->use[2];
+    if (!all_tables && hipMemsetAsync(s.l1, 0, (size_t)B * S1 * F1 * sizeof(float), st) != hipSuccess)
         return iq::fail(IQ_ELAUNCH, "iq_pointnet2_forward: memset failed");
     int col = 0;
     for (int q = 0; q < 3; ++q) {

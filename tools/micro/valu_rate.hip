@@ -51,8 +51,8 @@ __global__ __launch_bounds__(64) void k(double* out, unsigned long long* cyc, in
 int main() {
     double* out;
     unsigned long long* cyc;
-    hipMalloc(&out, 1024 * 64 * 8);
-    hipMalloc(&cyc, 1024 * 8);
+    hipMalloc(&out, 2048 * 64 * 8);
+    hipMalloc(&cyc, 2048 * 8);
     const int iters = 20000;
     const char* names[3] = {"fp64 insert (20 x v_min_f64 + v_max_f64)", "fp32 med3 + cmp + 2 cndmask per slot", "fp32 med3 only"};
     for (int waves = 1; waves <= 2; ++waves)
