@@ -203,7 +203,7 @@ template <int C>
 __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ xx,
                                                  int16_t* __restrict__ idx, Ragged rg, int B, int tiles_per_cloud, int dbg) {
     constexpr int KB = C / 8;
-    __shared__ double queue[16 * 64];
+    __shared__ double queue[17 * 64];                              // 16 slots per lane + the overflow slot of push()
     __shared__ __attribute__((aligned(16))) float kxs[2 * 64];   // |key|^2 of two pairs of key tiles (double-buffered)
     const int lane = threadIdx.x;
     // workgroups go round-robin over the 8 XCDs: give each XCD whole clouds, so that the ~17 waves which stream the same
@@ -282,8 +282,9 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float inner = -2.f * acc[r];                              // -2 * matmul
-                d[r] = ((-kx[r >> 2][r & 3]) - inner) - xxq;                    // -xx - inner - xx^T (models/dgcnn.py:15)
+                // -xx - inner - xx^T with inner = -2 * matmul (models/dgcnn.py:13-15).  -2 * acc is exact, so (-xx) - inner rounds
+                // once, exactly like the fused form 2 * acc + (-xx): one instruction instead of two
+                d[r] = __builtin_fmaf(2.f, acc[r], -kx[r >> 2][r & 3]) - xxq;
             }
             half = 0;
             ++t;
@@ -295,10 +296,7 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const float v = half ? d[8 + rr] : d[rr];
-            if (v > thr_f) {
-                top.q[top.cnt * 64 + lane] = top.pack(v, ib + (rr & 3) + 8 * (rr >> 2));
-                ++top.cnt;
-            }
+            top.push(v, ib + (rr & 3) + 8 * (rr >> 2), thr_f, lane);
         }
         ++half;
         if ((dbg & 3) == 1) top.cnt = 0;

@@ -68,9 +68,23 @@ struct QueuedTopK {
         const float b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32), b3 = __shfl_xor(a3, 32), b4 = __shfl_xor(a4, 32);
         return fmaxf(fmaxf(a4, b4), fmaxf(fminf(a2, b2), fmaxf(fminf(a1, b3), fminf(a3, b1))));
     }
+    // A queued candidate is the raw pair {key index, fp32 distance} (8 bytes); it becomes the packed double when it is
+    // popped (one conversion per round instead of one per candidate).  push() is branch-free: the pair is always written
+    // to the lane's next free slot and the slot is kept only if the candidate beats the threshold (a rejected one is
+    // overwritten by the next push) - five instructions per candidate where the branchy form (compare, save exec,
+    // branch, convert, two ORs, address, store, count, restore) issued twelve plus two branches, 16 times per key tile.
+    // The queue must hold CAP + 1 slots per lane (the slot behind a full queue takes the rejected writes).
+    __device__ __forceinline__ void push(float d, int idx, float thr_f, int lane) {
+        int2* slot = reinterpret_cast<int2*>(q) + cnt * 64 + lane;
+        *slot = make_int2(idx, __float_as_int(d));
+        cnt += d > thr_f ? 1 : 0;
+    }
     __device__ __forceinline__ void round(int lane) {
         double c = -INFINITY;
-        if (cnt > 0) c = q[(--cnt) * 64 + lane];
+        if (cnt > 0) {
+            const int2 e = reinterpret_cast<const int2*>(q)[(--cnt) * 64 + lane];
+            c = pack(__int_as_float(e.y), e.x);
+        }
         insert(c);
     }
     // make room for `need` more candidates per lane, and use rounds that are well filled anyway
@@ -95,10 +109,7 @@ struct QueuedTopK {
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
                 const int r = half * 8 + rr;
-                if (d[r] > thr_f) {
-                    q[cnt * 64 + lane] = pack(d[r], idx_base + (r & 3) + 8 * (r >> 2) + 4 * fh);
-                    ++cnt;
-                }
+                push(d[r], idx_base + (r & 3) + 8 * (r >> 2) + 4 * fh, thr_f, lane);
             }
         }
     }
