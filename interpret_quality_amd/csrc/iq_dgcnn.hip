@@ -472,11 +472,10 @@ __global__ __launch_bounds__(kGlThreads, 4) void gather_lds_kernel(const float* 
 // takes the maxima of its point's 20 neighbours from LDS (two 16-byte reads per neighbour) and writes 2 x 16 bytes.
 // Two workgroups per CU: the MFMA phase of one runs under the LDS phase of the other.
 //
-// Operand traffic.  The 32 x Cin weight slice of the workgroup (<= 16 KB) is staged in LDS once and read from there
-// as fragments.  A wave works through its point tiles one after the other; the x fragments of FOUR k-blocks - the
-// 128-byte line of every row - are requested back to back, one group ahead of the MFMAs, so each line of x is fetched
-// from L2 once (requested k-block by k-block with MFMAs of four tiles in between, the 32-byte pieces of a line arrived
-// in an L1 that 16 waves had long flushed: four L2 fetches per line, 4.2 ms for the 128 -> 256 layer instead of 2.x).
+// Operands.  The 32 x Cin weight slice of the workgroup (<= 16 KB) is staged in LDS once and read from there as
+// fragments.  A wave works through its point tiles one after the other, a stage = the four k-blocks of a 128-byte line
+// of x; the x fragments (global) and weight fragments (LDS) of stage q + 1 are requested before the MFMAs of stage q.
+// (Measured and of no effect: perfectly coalesced fake x addresses, x groups 2-4 stages ahead.)
 __device__ unsigned long long g_edge_dbg[8];   // tuning key 5 = 10: shader cycles per phase summed over workgroups (wave 0), count
 __global__ void edge_dbg_print_kernel(int layer) {
     const double n = (double)g_edge_dbg[5];
@@ -570,7 +569,7 @@ __global__ __launch_bounds__(kGlThreads, 4) void edge_fused_kernel(const float* 
 
     // The slice is XOR-swizzled: float4 column c of row r sits at r * 4 + (c ^ ((r >> 2) & 3)).  Unswizzled, the 16 lanes
     // of a ds_read_b128 lane group (same h, random rows) all read column h: 16 of the 64 banks, a 4-way conflict at best.
-    // With the swizzle a row's column lands in one of 16 slots (SQ_LDS_BANK_CONFLICT per LDS instruction 17 -> 7 cycles).
+    // With the swizzle a row's column lands in one of 16 slots (measured: 7 conflict cycles per LDS instruction).
     f32x4 q0[4], q1[4];                                       // Q of this lane's channels, per tile
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
