@@ -27,6 +27,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kK = 20;  // K_FOR_DGCNN, tools/final_util.py:19
+constexpr int kRoundLanes = 32;  // an insert round of the kNN selection runs once this many lanes have a queued candidate
 
 // ---- pad xyz (B,N,3) -> (B,N,8) -------------------------------------------------------------------
 // (B,N,3) -> (B,Np,8), Np = N rounded up to 32; rows N..Np-1 of a cloud are dead (zero; rownorm gives them +inf)
@@ -245,29 +246,46 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
         const int row = min(64 * tp + lane, N - 1);
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(kx_buf.rsrc, row * 4, 0, 0));
     };
-    f32x4 an = key_frag(0, 0);
-    kxs[lane] = kx_pair(0);                                        // wave-private: no barrier (one wave per workgroup)
-    float kx_next = kx_pair(1 < (ntiles + 1) / 2 ? 1 : 0);
+    // Key tiles are taken in PAIRS (one |key|^2 strip per pair), the pairs in zigzag order around the query tile's own pair:
+    // p0, p0 + 1, p0 - 1, p0 + 2, ... and straight on once one side is used up.  Whatever locality the row order has (the
+    // compact layout of a coalition keeps its points in the source cloud's Morton order) then brings a query's near keys
+    // first: the filter threshold is tight after a few tiles and most later candidates never reach the queue.  On rows in
+    // random order the statistics are those of any fixed order.
+    const int npairs = (ntiles + 1) >> 1;
+    const int p0 = (q0 >> 5) >> 1;
+    const int side = min(p0, npairs - 1 - p0);                     // pairs available on both sides
+    auto pair_at = [&](int k) {                                    // k-th pair of the order (k clamped to the last)
+        k = min(k, npairs - 1);
+        if (k <= 2 * side) return (k & 1) ? p0 + ((k + 1) >> 1) : p0 - (k >> 1);
+        return (npairs - 1 - p0 > p0) ? p0 + (k - side) : p0 - (k - side);
+    };
+    int k = 0, pcur = p0, j = 0;                                    // pair number in the order, its index, tile within the pair
+    f32x4 an = key_frag(2 * p0, 0);
+    kxs[lane] = kx_pair(p0);                                       // wave-private: no barrier (one wave per workgroup)
+    float kx_next = kx_pair(pair_at(1));
     // ONE loop (a small state machine) instead of rounds nested in the tile loop: the 20-entry list is then carried
     // by a single loop and stays in 40 registers; nested, the allocator kept copies per loop level (300 registers).
     float d[16];
     int dbg_rounds = 0, dbg_work = 0;
-    int t = 0, half = 2;  // half == 2: the current tile is used up
+    int tcur = 0, half = 2;  // half == 2: the current tile is used up
     for (;;) {
         const unsigned long long busy = __ballot(top.cnt > 0);
-        const bool last = half == 2 && t == ntiles;
-        if (busy != 0 && (last || __popcll(busy) >= 16 || __any(top.cnt > 8))) {
+        const bool last = half == 2 && k == npairs;
+        if (busy != 0 && (last || __popcll(busy) >= kRoundLanes || __any(top.cnt > 8))) {
             if ((dbg & 3) == 3) { ++dbg_rounds; dbg_work += __popcll(busy); }
             top.round(lane);
             continue;
         }
         if (last) break;
-        if (half == 2) {  // distances of key tile t
+        if (half == 2) {  // distances of key tile t = 2 pcur + j
+            const int t = 2 * pcur + j;
             f32x4 kx[4];
-            const float* ks = kxs + 64 * ((t >> 1) & 1) + 32 * (t & 1) + 4 * fh;   // rows 8 j + 4 fh + (0..3) of this tile
+            const float* ks = kxs + 64 * (k & 1) + 32 * j + 4 * fh;   // rows 8 i + 4 fh + (0..3) of this tile
 #pragma unroll
-            for (int j = 0; j < 4; ++j) kx[j] = *reinterpret_cast<const f32x4*>(ks + 8 * j);
-            const int tn = min(t + 1, ntiles - 1);
+            for (int i = 0; i < 4; ++i) kx[i] = *reinterpret_cast<const f32x4*>(ks + 8 * i);
+            const bool pair_done = j == 1 || t + 1 >= ntiles;
+            const int pnext = pair_at(k + 1);
+            const int tn = pair_done ? 2 * pnext : t + 1;              // (after the last tile: a valid tile, unused)
             f32x16 acc = {0};
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
@@ -275,24 +293,26 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
                 an = kb + 1 < KB ? key_frag(t, kb + 1) : key_frag(tn, 0);
                 acc = mfma4(a, qf[kb], acc);
             }
-            if (t & 1) {   // both tiles of the pair are used up: publish the next pair's strip, request the one after it
-                const int tp = (t >> 1) + 1;
-                kxs[64 * (tp & 1) + lane] = kx_next;
-                kx_next = kx_pair(min(tp + 1, (ntiles - 1) >> 1));
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 // -xx - inner - xx^T with inner = -2 * matmul (models/dgcnn.py:13-15).  -2 * acc is exact, so (-xx) - inner rounds
                 // once, exactly like the fused form 2 * acc + (-xx): one instruction instead of two
                 d[r] = __builtin_fmaf(2.f, acc[r], -kx[r >> 2][r & 3]) - xxq;
             }
+            tcur = t;
+            if (pair_done) {   // the pair is used up: publish the next pair's strip, request the one after it
+                kxs[64 * ((k + 1) & 1) + lane] = kx_next;
+                kx_next = kx_pair(pair_at(k + 2));
+                ++k; pcur = pnext; j = 0;
+            } else {
+                j = 1;
+            }
             half = 0;
-            ++t;
             if ((dbg & 3) == 2) { half = 2; continue; }
         }
         const float thr_f = top.union_threshold();   // bound on the 20th largest of both half-waves' keys (iq_topk.h)
         // queue the candidates of this half of the tile (accumulator registers 8 half .. 8 half + 7)
-        const int ib = (t - 1) * 32 + 4 * fh + 16 * half;
+        const int ib = tcur * 32 + 4 * fh + 16 * half;
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const float v = half ? d[8 + rr] : d[rr];

@@ -12,7 +12,7 @@
 //    fp32 precision.  Order by value (ties: by index), conversion back to fp32 is exact, and a sorted insert is
 //    v[q] = max(min(c, v[q-1]), v[q]) - two full-rate fp64 ops per slot, no index array, no minimum search;
 //  * candidates that beat the lane's threshold are appended to a small per-lane LDS queue and inserted in rounds that
-//    only run while at least a quarter of the lanes have work (or a queue could overflow), so the rounds per wave
+//    only run while at least half of the lanes have work (or a queue could overflow), so the rounds per wave
 //    approach the busiest lane's total instead of the sum over tiles of the per-tile maximum.
 // A candidate may wait while the threshold rises; inserting it late is then a no-op, never an error.
 template <int K, int CAP = 16>
@@ -92,7 +92,7 @@ struct QueuedTopK {
         for (;;) {
             const unsigned long long busy = __ballot(cnt > 0);
             if (busy == 0) break;
-            if (__popcll(busy) < 16 && !__any(cnt > CAP - need)) break;
+            if (__popcll(busy) < 32 && !__any(cnt > CAP - need)) break;
             round(lane);
         }
     }

@@ -30,6 +30,7 @@ ap.add_argument("--dedup", action="store_true", help="let the drivers evaluate e
                 "is a forward pass, so the figure is kernel throughput)")
 ap.add_argument("--tune", default="", help="iq_set_tuning pairs, e.g. 3=1 (no LDS GEMM)")
 ap.add_argument("--dense", action="store_true", help="materialise the masked clouds even if the model has a coalition path")
+ap.add_argument("--morton", action="store_true", help="experiment: hand the model the cloud with its points sorted along a Morton curve")
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -63,6 +64,15 @@ if a.dense and hasattr(model, "coalition_logits"):
             return self.m(x)
     model = DenseOnly(model)
 pts, label = synth.make_cloud(0)
+if a.morton:
+    q = ((pts - pts.min(0)) / (pts.max(0) - pts.min(0) + 1e-9) * 1023).astype(np.int64)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        return (v | (v << 2)) & 0x09249249
+    pts = np.ascontiguousarray(pts[np.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), kind="stable")])
 data = torch.from_numpy(pts).unsqueeze(0).to(dev)
 lbl = torch.tensor([label], device=dev)
 R, S = a.regions, a.perms
