@@ -54,6 +54,11 @@ __global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __rest
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x16){0};
+    // the epilogue's bias values, requested now: loaded after the K loop they cost every wave a full memory round trip
+    // (behind whatever operand loads are still in flight) with nothing left to hide it
+    float breg[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) breg[j] = bias[min((nt0 + j) * 32 + (lane & 31), Nout - 1)];
 
     f32x4 av[MT], bv[NT];
 #pragma unroll
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __rest
     for (int j = 0; j < NT; ++j) {
         const int col = (nt0 + j) * 32 + (lane & 31);
         if (nt0 + j >= ntiles || col >= Nout) continue;
-        const float b = split ? 0.f : bias[col];
+        const float b = split ? 0.f : breg[j];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
                                                                   const int32_t* __restrict__ tile_nu, int rows_per_cloud) {
     constexpr int KC = 32, LDA = KC + 4;
     __shared__ __attribute__((aligned(16))) float As[2][128 * LDA];
+    __shared__ float wrow[POOL ? 128 : 1];       // pooling weights of the tile's rows (read in the epilogue)
     if (m_dev) M = min(M, *m_dev);
     const int m0 = blockIdx.x * 128;
     if (m0 >= M) return;
@@ -127,6 +133,7 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    if (POOL && tid < 128) wrow[tid] = m0 + tid < M ? row_w[m0 + tid] : 0.f;   // visible after the K loop's barriers
     const int KB = K >> 3, nchunks = K / KC;
     const int ntiles = (Nout + 31) >> 5;
     const int nt0 = (blockIdx.y * 2 + wn) * NT;
@@ -171,6 +178,9 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x16){0};
+    float breg[NT];                               // bias of this wave's columns, for the epilogue (see pn_linear_kernel)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) breg[j] = bias[min((nt0 + j) * 32 + (lane & 31), Nout - 1)];
 
     load_chunk(0);
     store_chunk(0);
@@ -220,15 +230,12 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
             if (trow >= M) continue;
             float w[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = trow + c_row(r, lane);
-                w[r] = row < M ? row_w[row] : 0.f;
-            }
+            for (int r = 0; r < 16; ++r) w[r] = wrow[wm * 64 + i * 32 + c_row(r, lane)];
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int col = (nt0 + j) * 32 + (lane & 31);
                 const bool ok = nt0 + j < ntiles && col < Nout;
-                const float b = ok ? bias[col] : 0.f;
+                const float b = ok ? breg[j] : 0.f;
                 float mx = -INFINITY, sm = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
     for (int j = 0; j < NT; ++j) {
         const int col = (nt0 + j) * 32 + (lane & 31);
         if (nt0 + j >= ntiles || col >= Nout) continue;
-        const float b = bias[col];
+        const float b = breg[j];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
