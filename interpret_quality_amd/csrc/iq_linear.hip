@@ -279,149 +279,6 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
     }
 }
 
-
-// ---- dense layer + pooling with the A tile stationary in LDS -----------------------------------------------------------
-// The pooled layers (DGCNN conv5: 512 -> 1024 over millions of rows) as pn_gemm_lds_kernel<4, POOL> are 86 % MFMA-busy:
-// a barrier per 32-deep K chunk and a prologue / pooling epilogue per 128 x 256 tile remain.  Here a workgroup takes 64
-// rows and ALL columns: its 64 x K slice of A is copied to LDS once (K = 512: 129 KB, one workgroup per CU), then the 8
-// waves run barrier-free - wave w owns n-tiles w, w + 8, ... and streams their weight fragments through an 8-deep
-// register ring that rolls from one n-tile into the next, A fragments come from LDS one k-block ahead (the structure of
-// the PointNet chain kernel's third layer).  A is read from memory once instead of once per 256 columns.  Same MFMA
-// order over k and the same pooling arithmetic as pn_gemm_lds_kernel<4, POOL>: bit-identical partials.
-constexpr int kAsThreads = 512;
-
-// one n-tile: K-blocks in groups of 8 (the ring's depth); wq / wn = scalar byte offsets of this and the next n-tile's fragments
-template <int LD, int KB, int MTS>
-__device__ __forceinline__ void astat_ntile(const float* abase, const WBuf& wb, int wq, int wn, f32x4 (&ring)[8], f32x16& acc0,
-                                            f32x16& acc1) {
-    f32x4 a0n = lds_frag<LD>(abase, 0, 0), a1n = a0n;
-    if (MTS == 2) a1n = lds_frag<LD>(abase, 1, 0);
-#pragma unroll 1
-    for (int kb0 = 0; kb0 < KB; kb0 += 8) {
-        const int refill = kb0 + 8 < KB ? wq + (kb0 + 8) * kFragBytes : wn;   // fragments 8 k-blocks ahead: this n-tile, then the next
-#pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) {
-            const int kb = kb0 + k8;
-            const f32x4 a0 = a0n, a1 = a1n;
-            const int kn = min(kb + 1, KB - 1);
-            a0n = lds_frag<LD>(abase, 0, kn);
-            if (MTS == 2) a1n = lds_frag<LD>(abase, 1, kn);
-            const f32x4 bk = ring[k8];
-            acc0 = mfma4(a0, bk, acc0);
-            if (MTS == 2) acc1 = mfma4(a1, bk, acc1);
-            ring[k8] = wbuf_load(wb, refill + k8 * kFragBytes);
-            __builtin_amdgcn_sched_group_barrier(0x100, MTS, 0);       // DS reads of k-block kb + 1
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * MTS, 0);   // MFMAs of k-block kb
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // ring refill
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-template <int K>
-__global__ __launch_bounds__(kAsThreads, 2) void pn_pool_astat_kernel(const float* __restrict__ A, int lda,
-                                                                      const float* __restrict__ wp,
-                                                                      const float* __restrict__ bias, float* __restrict__ out,
-                                                                      int M, int Nout, int relu,
-                                                                      const int32_t* __restrict__ m_dev,
-                                                                      const float* __restrict__ row_w) {
-    constexpr int LD = K + 4, KB = K / 8, Q4 = K / 4;
-    __shared__ __attribute__((aligned(16))) float As[64 * LD];
-    if (m_dev) M = min(M, *m_dev);
-    const int m0 = blockIdx.x * 64;
-    if (m0 >= M) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-    const int mts = (m0 + 32 < M) ? 2 : 1;          // M is a multiple of 32 on the ragged layouts; rows >= M are clamped
-    // ---- A slice -> LDS: 64 x K floats, 16 float4 per thread at K = 512, all requested before the first is stored
-    {
-        const WBuf ab = wbuf_make(A + (size_t)m0 * lda, lane);
-        constexpr int PER = 64 * Q4 / kAsThreads;
-        f32x4 v[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e = tid + kAsThreads * i, row = e / Q4, c4 = e - row * Q4;
-            v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ab.rsrc, (min(row, M - 1 - m0) * lda + c4 * 4) * 4, 0, 0));
-        }
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e = tid + kAsThreads * i, row = e / Q4, c4 = e - row * Q4;
-            *reinterpret_cast<f32x4*>(&As[row * LD + c4 * 4]) = v[i];
-        }
-    }
-    const int ntiles = Nout >> 5;
-    const WBuf wb = wbuf_make(wp, lane);
-    // pooling weights of this lane's accumulator rows (the same for every n-tile)
-    float w[2][16];
-    bool unit[2];                                   // all 32 rows of the m-tile have pooling weight 1 (wave-uniform)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        bool u = true;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + i * 32 + c_row(r, lane);
-            w[i][r] = row < M ? row_w[row] : 0.f;
-            u = u && w[i][r] == 1.f;
-        }
-        unit[i] = __all(u);
-    }
-    f32x4 ring[8];
-    int wq = uniform(min(wave, ntiles - 1)) * KB * kFragBytes;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ring[i] = wbuf_load(wb, wq + i * kFragBytes);
-    float b_next = bias[min(wave, ntiles - 1) * 32 + (lane & 31)];
-    __syncthreads();
-    const float* abase = As + (lane & 31) * LD + 4 * (lane >> 5);
-    for (int nt = wave; nt < ntiles; nt += kAsThreads / 64) {
-        const int ntn = min(nt + kAsThreads / 64, ntiles - 1);                 // next n-tile of this wave (or any valid one)
-        const int wn = uniform(ntn) * KB * kFragBytes;
-        // this n-tile's bias arrived during the previous one; the next one's is requested now, in front of the MFMAs (asked for
-        // in the epilogue it cost a memory round trip behind the eight ring loads in flight: 18 k cycles per epilogue measured)
-        const float b = b_next;
-        b_next = bias[ntn * 32 + (lane & 31)];
-        f32x16 acc0 = {0}, acc1 = {0};
-        if (mts == 2) astat_ntile<LD, KB, 2>(abase, wb, wq, wn, ring, acc0, acc1);
-        else          astat_ntile<LD, KB, 1>(abase, wb, wq, wn, ring, acc0, acc1);
-        wq = wn;
-        // pooling epilogue (pn_gemm_lds_kernel<., POOL>'s arithmetic)
-        const int col = nt * 32 + (lane & 31);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int trow = m0 + i * 32;
-            if (trow >= M) continue;
-            const f32x16& acc = i == 0 ? acc0 : acc1;
-            float mx = -INFINITY, sm = 0.f;
-            if (unit[i]) {                          // interior tile: 1 * v == v, every row counts
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[r] + b;
-                    if (relu == 1) v = fmaxf(v, 0.f);
-                    else if (relu == 2) v = v > 0.f ? v : 0.2f * v;
-                    mx = fmaxf(mx, v);
-                    sm += v;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[r] + b;
-                    if (relu == 1) v = fmaxf(v, 0.f);
-                    else if (relu == 2) v = v > 0.f ? v : 0.2f * v;
-                    if (w[i][r] > 0.f) {
-                        mx = fmaxf(mx, v);
-                        sm += w[i][r] * v;
-                    }
-                }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            sm += __shfl_xor(sm, 32);
-            if (lane < 32) {
-                float* o = out + (size_t)(trow >> 5) * 2 * Nout;
-                o[col] = mx;
-                o[Nout + col] = sm;
-            }
-        }
-    }
-}
-
 }  // namespace
 
 int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,
@@ -500,11 +357,6 @@ int iq::launch_linear_pool(const float* A, int lda, const iq_dense_layer& L, flo
     const int ntiles = (L.cout + 31) / 32;
     if (L.cin % 32 != 0 || ntiles < 8 || L.cout % 32 != 0)
         return iq::fail(IQ_EUNSUPPORTED, "dense layer + pool: cin=%d cout=%d", L.cin, L.cout);
-    if (L.cin == 512 && M >= 4096 && iq::tuning(iq::kTuneNoLdsGemm) != 2) {   // tuning key 3 = 2: the tiled kernel (A/B runs, tests)
-        hipLaunchKernelGGL((pn_pool_astat_kernel<512>), dim3((M + 63) / 64), dim3(kAsThreads), 0, st, A, lda, L.w, L.b, partial, M,
-                           L.cout, relu, m_dev, row_w);
-        return iq::check_launch("pn_pool_astat_kernel");
-    }
     dim3 grid((M + 127) / 128, (ntiles + 7) / 8);
     hipLaunchKernelGGL((pn_gemm_lds_kernel<4, true>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, partial, 0, M, L.cin, L.cout,
                        relu, m_dev, row_w, nullptr, 0);
