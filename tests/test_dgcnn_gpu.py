@@ -251,27 +251,3 @@ def test_forward_on_clouds_of_more_than_1024_points(oracle):
     got = make(DGCNN_cls).forward_points(x.to(dev()))
     assert_close_elementwise(got.cpu().numpy(), want.numpy())
 
-
-def test_a_stationary_conv5_is_bitwise_the_tiled_gemm():
-    """pn_pool_astat_kernel (64 rows x all columns per workgroup, A slice resident in LDS) against pn_gemm_lds_kernel<4, pool>
-    (tuning key 3 = 2): same MFMA order over k, same pooling arithmetic - bit-identical logits on ragged coalition batches
-    (row counts that are odd multiples of 32, so the last workgroup holds a single 32-row tile)."""
-    from interpret_quality_amd import _lib
-    lib = _lib.load()
-    model = make(DGCNN_cls)
-    d = dev()
-    rng = np.random.default_rng(9)
-    clouds = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in (0, 1)]).to(d)
-    rid = torch.from_numpy(rng.integers(0, 32, size=(2, 1024)).astype(np.int32)).to(d)
-    centers = clouds.mean(dim=1)
-    keep = [int(x) for x in rng.integers(0, 1 << 32, size=40)] + [(1 << 32) - 1, 0, 1]
-    cloud_of = [i % 2 for i in range(len(keep))]
-    keep_t = hip_ops.masks_to_tensor(keep, d)
-    co_t = torch.tensor(cloud_of, dtype=torch.int32, device=d)
-    fast = model.coalition_logits(clouds, centers, rid, keep_t, co_t, num_regions=32).clone()
-    lib.iq_set_tuning(3, 2)
-    try:
-        tiled = model.coalition_logits(clouds, centers, rid, keep_t, co_t, num_regions=32).clone()
-    finally:
-        lib.iq_set_tuning(3, 0)
-    assert torch.equal(fast, tiled)
