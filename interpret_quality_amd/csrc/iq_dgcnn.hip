@@ -13,9 +13,10 @@
 //
 // Ragged batches.  A masked cloud holds its kept points plus M copies of the centre, and every copy sees the same
 // neighbourhoods and produces the same features in every layer.  iq_dgcnn_coalitions therefore never materialises the
-// N rows: cloud b becomes D_b = kept + min(M, 20) rows (20 copies are all a top-20 can ever select), padded to a
-// multiple of 32 with dead rows whose |x|^2 is +inf so that no query selects them.  Max-pooling and the neighbourhood
-// max are set operations, so they are unchanged; the mean pool weights the centre by M.  Exact, and the kNN work drops
+// N rows: cloud b becomes D_b = kept + 1 rows - the centre once, carrying the multiplicity min(M, 20) with which it can
+// appear in a top-20 (applied when knn_kernel writes the neighbour lists) - padded to a multiple of 32 with dead rows
+// whose |x|^2 is +inf so that no query selects them.  Max-pooling and the neighbourhood max are set operations, so they
+// are unchanged; the mean pool weights the centre by M.  Exact, and the kNN work drops
 // with the square of the kept fraction.  All kernels below run on the ragged layout (row offsets per cloud); the dense
 // forward is the special case D_b = N.
 #include "iq_common.h"
@@ -49,9 +50,9 @@ __global__ void pad_xyz_kernel(const float* __restrict__ xyz, float* __restrict_
 struct Ragged {
     const int32_t* roff;       // (B+1) first row of cloud b; roff[B] = total rows (all multiples of 32)
     const int32_t* nkept;      // (B) kept points = rows [0, nkept)
-    const int32_t* ncopy;      // (B) centre copies = rows [nkept, nkept + ncopy)
+    const int32_t* ncopy;      // (B) min(masked points, 20): multiplicity of the centre row (row nkept) in a top-20; 0 = no centre row
     const int32_t* row_cloud;  // (rows) cloud of a row
-    float* row_w;              // (rows) pooling weight: kept 1, first centre copy M, other copies and dead rows 0
+    float* row_w;              // (rows) pooling weight: kept 1, the centre row M, dead rows 0
 };
 
 // dense forward: D_b = N
@@ -76,10 +77,10 @@ __global__ __launch_bounds__(64) void dg_count_kernel(const int32_t* __restrict_
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
     if (lane == 0) {
-        const int copies = min(N - n, kK);
+        const int copies = min(N - n, kK);        // multiplicity of the centre row in a top-20 (0: nothing masked)
         nkept[b] = n;
         ncopy[b] = copies;
-        dpad[b] = (n + copies + 31) & ~31;
+        dpad[b] = (n + (copies > 0 ? 1 : 0) + 31) & ~31;
     }
 }
 
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(1024) void dg_scan_kernel(const int32_t* __restrict
     if (t == 1023) roff[B] = part[1023];
 }
 
-// rows of coalition b: kept points in index order, then the centre copies, then dead rows; (.,8) padded xyz
+// rows of coalition b: kept points in index order, then the centre (once), then dead rows; (.,8) padded xyz
 __global__ __launch_bounds__(64) void dg_compact_kernel(const float* __restrict__ clouds, const float* __restrict__ centers,
                                                         const int32_t* __restrict__ region_id, const uint64_t* __restrict__ keep,
                                                         const int32_t* __restrict__ cloud_of, const int32_t* __restrict__ roff,
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(64) void dg_compact_kernel(const float* __restrict_
         }
         pos += __popcll(m);
     }
-    const int live = nkept[b] + ncopy[b];
+    const int live = nkept[b] + (ncopy[b] > 0 ? 1 : 0);   // ONE centre row; its multiplicity is applied by knn_kernel
     const f32x4 ctr = {centers[c * 3], centers[c * 3 + 1], centers[c * 3 + 2], 0.f};
     for (int row = base + nkept[b] + lane; row < end; row += 64) {
         reinterpret_cast<f32x4*>(x0)[(size_t)row * 2] = (row < base + live) ? ctr : z;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void rownorm_kernel(const float* __restri
     const int r = r0 + tid;
     if (tid >= 64 || r >= rows) return;
     const int b = rg.row_cloud[r];
-    xx[r] = (r - rg.roff[b] < rg.nkept[b] + rg.ncopy[b]) ? s : INFINITY;
+    xx[r] = (r - rg.roff[b] < rg.nkept[b] + (rg.ncopy[b] > 0 ? 1 : 0)) ? s : INFINITY;
 }
 
 // ---- kNN ------------------------------------------------------------------------------------------
@@ -327,10 +328,39 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
         atomicAdd(&g_knn_dbg[2], 1ull);
     }
     top.merge_halves();  // each half-wave saw half of the keys of every tile
+    // The masked points of a coalition are ONE row (index nkept) that stands for `mult` = min(M, 20) identical points.  The
+    // list holds the 20 nearest DISTINCT rows; of those, a row farther than the centre with `rank` rows ahead of it sits
+    // at position rank - 1 + mult of the reference's top-k, so it is a neighbour only if rank <= 20 - mult.  Rows that
+    // fall out are replaced by the centre (a duplicate neighbour does not change a max).  mult == 20, the usual case:
+    // every row behind the centre falls out.  Rows filled from the dead padding (fewer than 20 live rows) are behind the
+    // centre and fall out the same way.
+    const int centre = rg.nkept[b], mult = rg.ncopy[b];
+    bool drop[kK];
+#pragma unroll
+    for (int q = 0; q < kK; ++q) drop[q] = false;
+    if (mult > 0) {
+        double vc = 0.0;
+        bool has = false;
+#pragma unroll
+        for (int q = 0; q < kK; ++q)
+            if (top.index(q) == centre) { vc = top.v[q]; has = true; }
+        if (mult >= kK) {
+#pragma unroll
+            for (int q = 0; q < kK; ++q) drop[q] = has && top.v[q] < vc;
+        } else if (__any(has)) {   // fewer than 20 masked points: ranks among the 20 (400 comparisons, rare)
+#pragma unroll
+            for (int q = 0; q < kK; ++q) {
+                int rank = 0;
+#pragma unroll
+                for (int j = 0; j < kK; ++j) rank += top.v[j] > top.v[q] ? 1 : 0;
+                drop[q] = has && top.v[q] < vc && rank > kK - mult;
+            }
+        }
+    }
     if (fh == 0) {
         int16_t* o = idx + ((size_t)base + q0 + fl) * kK;
 #pragma unroll
-        for (int q = 0; q < kK; ++q) o[q] = (int16_t)top.index(q);
+        for (int q = 0; q < kK; ++q) o[q] = (int16_t)(drop[q] ? centre : top.index(q));
     }
 }
 
