@@ -358,9 +358,15 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
         }
     }
     if (fh == 0) {
+        // dbg & 8: the consumer is edge_fused_kernel, which wants the byte address of the row's (swizzled) first float4 in
+        // its LDS slice instead of the row index: row * 64 + ((row >> 2) & 3) * 16 (< 65536 for rows < 1024)
+        const bool as_addr = (dbg & 8) != 0;
         int16_t* o = idx + ((size_t)base + q0 + fl) * kK;
 #pragma unroll
-        for (int q = 0; q < kK; ++q) o[q] = (int16_t)(drop[q] ? centre : top.index(q));
+        for (int q = 0; q < kK; ++q) {
+            const int row = drop[q] ? centre : top.index(q);
+            o[q] = (int16_t)(as_addr ? (row << 6) | (((row >> 2) & 3) << 4) : row);
+        }
     }
 }
 
@@ -659,13 +665,16 @@ __global__ __launch_bounds__(kGlThreads, 4) void edge_fused_kernel(const float* 
     if (stamps) ts[2] = edge_clock();
     __syncthreads();                                          // slice complete
     if (stamps) ts[3] = edge_clock();
-    const unsigned last = (unsigned)D - 1u;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         if (u < nv) {
             const Nb it = cur;
             if (u + 1 < nv) cur = fetch_nb(u + 1);
             const int r = (wave + 8 * u) * 32 + p;
+            // the neighbour lists hold LDS byte addresses (knn_kernel, dbg & 8): row * 64 + swizzle(row) * 16 for h = 0; this
+            // lane's two float4 are at (address ^ 16 h) and 32 bytes across.  (Row indices cost 10 VALU instructions per
+            // neighbour to unpack, clamp and swizzle - 200 per tile against 96 for the maxima themselves.)  Any 16-bit
+            // address lies inside this workgroup's own LDS allocation.
             unsigned nb[kK];
 #pragma unroll
             for (int w = 0; w < kK / 4; ++w) {
@@ -673,12 +682,14 @@ __global__ __launch_bounds__(kGlThreads, 4) void edge_fused_kernel(const float* 
                 nb[4 * w] = v.x & 0xffffu; nb[4 * w + 1] = v.x >> 16;
                 nb[4 * w + 2] = v.y & 0xffffu; nb[4 * w + 3] = v.y >> 16;
             }
-            auto at = [&](unsigned row) { const unsigned rr = min(row, last); return rr * 4 + (h ^ ((rr >> 2) & 3)); };   // min: rows outside the slice are never addressed
-            f32x4 m0 = slice[at(nb[0])], m1 = slice[at(nb[0]) ^ 2];
+            const char* sb = reinterpret_cast<const char*>(slice);
+            const unsigned hx = (unsigned)h << 4;
+            auto rd = [&](unsigned a) { return *reinterpret_cast<const f32x4*>(sb + a); };
+            f32x4 m0 = rd(nb[0] ^ hx), m1 = rd(nb[0] ^ hx ^ 32u);
 #pragma unroll
             for (int j = 1; j < kK; ++j) {
-                const unsigned a = at(nb[j]);
-                const f32x4 v0 = slice[a], v1 = slice[a ^ 2];
+                const unsigned a = nb[j] ^ hx;
+                const f32x4 v0 = rd(a), v1 = rd(a ^ 32u);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { m0[e] = fmaxf(m0[e], v0[e]); m1[e] = fmaxf(m1[e], v1[e]); }
             }
@@ -721,13 +732,15 @@ __global__ __launch_bounds__(kThreads) void pool_reduce_kernel(const float* __re
     out[(size_t)b * 2 * C + C + c] = s / (float)N;
 }
 
+// slice_addr: write the neighbours as LDS addresses for edge_fused_kernel (rows < 1024) instead of row indices
 int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, int B, int N, const Ragged& rg,
-               hipStream_t st) {
+               hipStream_t st, bool slice_addr = false) {
     const int tiles = (N + 31) / 32;
     dim3 grid((unsigned)((B + 7) / 8 * 8 * tiles));
-    if (C == 8) hipLaunchKernelGGL(knn_kernel<8>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, iq::tuning(iq::kTuneKnnDebug));
-    else if (C == 64) hipLaunchKernelGGL(knn_kernel<64>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, iq::tuning(iq::kTuneKnnDebug));
-    else if (C == 128) hipLaunchKernelGGL(knn_kernel<128>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, iq::tuning(iq::kTuneKnnDebug));
+    const int dbg = (iq::tuning(iq::kTuneKnnDebug) & 7) | (slice_addr ? 8 : 0);
+    if (C == 8) hipLaunchKernelGGL(knn_kernel<8>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, dbg);
+    else if (C == 64) hipLaunchKernelGGL(knn_kernel<64>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, dbg);
+    else if (C == 128) hipLaunchKernelGGL(knn_kernel<128>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, dbg);
     else return iq::fail(IQ_EUNSUPPORTED, "knn: C=%d has no kernel instantiation (8, 64, 128)", C);
     return iq::check_launch("knn_kernel");
 }
@@ -834,21 +847,31 @@ int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, i
     int rc;
     const float* src = s.x0;
     int ld = 8, cin = 8, creal = 3, col = 0;
+    const int Np = (N + 31) / 32 * 32;
+    const int knob = iq::tuning(iq::kTuneExperiment);   // 7: GEMM + L2 gather, 8: GEMM + LDS gather (A/B and tests)
+    // edge_fused_kernel for every layer or for none: the kNN kernel writes the neighbour lists in the form the consumer reads
+    // (LDS addresses for the fused kernel, row indices otherwise), and GCNN's one list serves all four layers
+    bool fused = Np <= kGlMaxRows && knob != 7 && knob != 8;
+    {
+        int ci = 8;
+        for (int l = 0; l < 4; ++l) {
+            const int co = w->pq[l].cout / 2;
+            fused = fused && co % 16 == 0 && (ci == 8 || ci == 64 || ci == 128) && w->pq[l].cin == ci;
+            ci = co;
+        }
+    }
     for (int l = 0; l < 4; ++l) {
         const int co = w->pq[l].cout / 2;
         IQ_REQUIRE(w->pq[l].cin == cin, "iq_dgcnn: layer %d expects %d inputs, got %d", l, cin, w->pq[l].cin);
         if (l == 0 || !fixed_graph) {
             iq::ProfileSpan span(iq::kSlotPrepool, st);
             hipLaunchKernelGGL(rownorm_kernel, dim3((rows + 63) / 64), dim3(kThreads), 0, st, src, ld, creal, s.xx, rg, B);
-            if ((rc = launch_knn(src, ld, cin, s.xx, s.idx, B, N, rg, st))) return rc;
+            if ((rc = launch_knn(src, ld, cin, s.xx, s.idx, B, N, rg, st, fused))) return rc;
         }
         {
             iq::ProfileSpan span(iq::kSlotFstn, st);
-            const int Np = (N + 31) / 32 * 32;
-            const int knob = iq::tuning(iq::kTuneExperiment);   // 7: GEMM + L2 gather, 8: GEMM + LDS gather (A/B and tests)
             const bool fits = Np <= kGlMaxRows && co % 16 == 0;
-            if (fits && knob != 7 && knob != 8 && (cin == 8 || cin == 64 || cin == 128) &&
-                reinterpret_cast<uintptr_t>(w->pq[l].b) % 16 == 0) {
+            if (fused) {
                 // the whole layer in one kernel: co / 16 workgroups per cloud
                 const int wgs_per_cloud = co / 16;
                 const dim3 grid((unsigned)((B + 7) / 8 * 8 * wgs_per_cloud));
