@@ -251,3 +251,33 @@ def test_forward_on_clouds_of_more_than_1024_points(oracle):
     got = make(DGCNN_cls).forward_points(x.to(dev()))
     assert_close_elementwise(got.cpu().numpy(), want.numpy())
 
+
+
+@pytest.mark.parametrize("cls", [DGCNN_cls, GCNN_cls])
+def test_centre_multiplicity_around_k(cls):
+    """The compact layout keeps the masked points as ONE centre row whose multiplicity min(M, 20) is applied when the kNN
+    kernel writes the neighbour lists.  Coalitions with M = 1, 2, 19, 20, 21, 39, 41 and 1003 masked points (either side of
+    k = 20, where the rule changes from "ranks among the 20" to "everything behind the centre falls out") against the
+    dense forward on the materialised masked clouds."""
+    model = make(cls)
+    d = dev()
+    cloud = torch.from_numpy(synth.make_cloud(2)[0]).to(d)                                            # (1024,3)
+    sizes = [1, 1, 19, 20, 21]                                                                        # regions 0..4; region 5 = the rest
+    rid = torch.full((1024,), 5, dtype=torch.int32)
+    pos = 0
+    perm = np.random.default_rng(4).permutation(1024)
+    for r, n in enumerate(sizes):
+        rid[perm[pos:pos + n]] = r
+        pos += n
+    full = (1 << 6) - 1
+    masked_regions = [[0], [0, 1], [2], [3], [4], [2, 3], [3, 4], [0, 1, 2, 3, 4], [5], [5, 2]]       # M = 1, 2, 19, 20, 21, 39, 41, 62, 962, 981
+    keep = [full ^ sum(1 << r for r in regs) for regs in masked_regions]
+    clouds = cloud.unsqueeze(0)
+    centers = clouds.mean(dim=1)
+    rid_d = rid.unsqueeze(0).to(d)
+    keep_t = hip_ops.masks_to_tensor(keep, d)
+    got = model.coalition_logits(clouds, centers, rid_d, keep_t, None, num_regions=6)
+    dense = torch.stack([hip_ops.mask_coalitions(cloud, rid.to(d), hip_ops.masks_to_tensor([k], d), centers[0].contiguous())[0]
+                         for k in keep])
+    want = model.forward_points(dense)
+    assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-5
