@@ -288,7 +288,7 @@ int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* o
     const int ntiles = (L.cout + 31) / 32;
     if (tile_nu && (rows_per_cloud <= 0 || rows_per_cloud % 128 != 0)) tile_nu = nullptr;   // tiles must not straddle clouds
     if (M >= 2048 && ntiles >= 4 && L.cin % 32 == 0 && iq::tuning(iq::kTuneNoLdsGemm) == 0) {
-        if (ntiles >= 16 && (long long)((M + 127) / 128) * ((ntiles + 7) / 8) >= 2048) {
+        if (ntiles >= 8 && (long long)((M + 127) / 128) * ((ntiles + 7) / 8) >= 2048) {
             dim3 grid((M + 127) / 128, (ntiles + 7) / 8);
             hipLaunchKernelGGL((pn_gemm_lds_kernel<4, false>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
                                L.cout, relu, m_dev, nullptr, tile_nu, rows_per_cloud);
