@@ -111,7 +111,8 @@ __global__ __launch_bounds__(64) void dg_compact_kernel(const float* __restrict_
                                                         const int32_t* __restrict__ cloud_of, const int32_t* __restrict__ roff,
                                                         const int32_t* __restrict__ nkept, const int32_t* __restrict__ ncopy,
                                                         float* __restrict__ x0, int32_t* __restrict__ row_cloud,
-                                                        float* __restrict__ row_w, int N, int nclouds) {
+                                                        float* __restrict__ row_w, int N, int nclouds,
+                                                        int16_t* __restrict__ src /*(B,Np) source point of a row, or null*/, int Np) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int c = cloud_of ? cloud_of[b] : (nclouds == 1 ? 0 : b);
     const uint64_t k = keep[b];
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(64) void dg_compact_kernel(const float* __restrict_
             const f32x4 a = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2], 0.f};
             reinterpret_cast<f32x4*>(x0)[(size_t)row * 2] = a;
             reinterpret_cast<f32x4*>(x0)[(size_t)row * 2 + 1] = z;
+            if (src) src[(size_t)b * Np + (row - base)] = (int16_t)i;
         }
         pos += __popcll(m);
     }
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(64) void dg_compact_kernel(const float* __restrict_
         reinterpret_cast<f32x4*>(x0)[(size_t)row * 2 + 1] = z;
     }
     const int nk = nkept[b];
+    if (src && lane == 0 && ncopy[b] > 0) src[(size_t)b * Np + nk] = (int16_t)N;   // the centre row
     for (int row = base + lane; row < end; row += 64) {
         row_cloud[row] = b;
         const int rl = row - base;
@@ -186,6 +189,162 @@ __global__ __launch_bounds__(kThreads) void rownorm_kernel(const float* __restri
     if (tid >= 64 || r >= rows) return;
     const int b = rg.row_cloud[r];
     xx[r] = (r - rg.roff[b] < rg.nkept[b] + (rg.ncopy[b] > 0 ? 1 : 0)) ? s : INFINITY;
+}
+
+// ---- layer-1 graph of a coalition from the SOURCE cloud's sorted neighbour lists ---------------------------------------
+// In xyz space the distance between two kept points does not depend on the coalition, and neither does the centre (the mean
+// of the whole cloud): only the SET of candidates does.  So per source cloud (a few per call, against thousands of
+// coalitions) every point's complete neighbour list - all other points and the centre, nearest first, by the very
+// distances knn_kernel<8> computes - is built once (dg_src_rows -> dg_src_dist -> dg_src_sort), and the 20 nearest of a
+// coalition's query are the first entries of its source point's list that the coalition keeps, the centre entry counting
+// min(M, 20) times (dg_walk_kernel: a few dozen 2-byte entries per query instead of a D x D distance matrix and a top-k).
+// The same neighbours as knn_kernel<8> on the compact rows (same arithmetic for every distance, ties by point index).
+constexpr int kWalkMaxN = 1024;   // source cloud points (the per-row sort holds 2048 entries)
+
+// rows of source cloud c: its N points, the centre (row N), zero padding with |x|^2 = +inf
+__global__ void dg_src_rows_kernel(const float* __restrict__ clouds, const float* __restrict__ centers, float* __restrict__ xs,
+                                   float* __restrict__ xxs, int N, int Nsp) {
+    const int c = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nsp) return;
+    const float* src = i < N ? clouds + ((size_t)c * N + i) * 3 : centers + (size_t)c * 3;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    float s = INFINITY;
+    if (i <= N) {
+        a = (f32x4){src[0], src[1], src[2], 0.f};
+        s = 0.f;                      // rownorm_kernel's order: ((0 + x^2) + y^2) + z^2
+        s += a[0] * a[0];
+        s += a[1] * a[1];
+        s += a[2] * a[2];
+    }
+    float* o = xs + ((size_t)c * Nsp + i) * 8;
+    *reinterpret_cast<f32x4*>(o) = a;
+    *reinterpret_cast<f32x4*>(o + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    xxs[(size_t)c * Nsp + i] = s;
+}
+
+// dmat[c][q][k] = knn_kernel<8>'s distance of query row q and key row k (one wave = 32 queries, all key tiles)
+__global__ __launch_bounds__(64) void dg_src_dist_kernel(const float* __restrict__ xs, const float* __restrict__ xxs,
+                                                         float* __restrict__ dmat, int Nsp) {
+    const int c = blockIdx.y, q0 = blockIdx.x * 32, lane = threadIdx.x;
+    const int fl = lane & 31, fh = lane >> 5;
+    const float* xb = xs + (size_t)c * Nsp * 8;
+    const float* xxb = xxs + (size_t)c * Nsp;
+    const f32x4 qf = *reinterpret_cast<const f32x4*>(xb + (size_t)(q0 + fl) * 8 + 4 * fh);
+    const float xxq = xxb[q0 + fl];
+    float* drow = dmat + ((size_t)c * Nsp + q0 + fl) * Nsp;
+    for (int t = 0; t < Nsp / 32; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xb + (size_t)(t * 32 + fl) * 8 + 4 * fh);
+        f32x16 acc = {0};
+        acc = mfma4(a, qf, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = t * 32 + c_row(r, lane);
+            drow[key] = __builtin_fmaf(2.f, acc[r], -xxb[key]) - xxq;   // knn_kernel's expression
+        }
+    }
+}
+
+// sorted[c][q][.] = the rows 0..N of source cloud c, nearest to row q first (larger distance value first; ties: lower index)
+__global__ __launch_bounds__(256) void dg_src_sort_kernel(const float* __restrict__ dmat, int16_t* __restrict__ sorted, int N,
+                                                          int Nsp, int Nsl) {
+    __shared__ unsigned long long e[2048];
+    const int c = blockIdx.y, q = blockIdx.x, t = threadIdx.x;
+    const float* drow = dmat + ((size_t)c * Nsp + q) * Nsp;
+    for (int j = t; j < 2048; j += 256) {
+        unsigned long long key = ~0ull;
+        if (j <= N) {
+            const unsigned o = __float_as_uint(-drow[j]);                       // ascending in -d = descending in d
+            const unsigned u = (o & 0x80000000u) ? ~o : (o | 0x80000000u);      // order-preserving map of a float to an unsigned
+            key = ((unsigned long long)u << 16) | (unsigned)j;
+        }
+        e[j] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= 2048; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < 2048; i += 256) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long a = e[i], b = e[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { e[i] = b; e[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    int16_t* o = sorted + ((size_t)c * (N + 1) + q) * Nsl;
+    for (int j = t; j <= N; j += 256) o[j] = (int16_t)(e[j] & 0xffffu);
+}
+
+// neighbour lists of the rows of coalition b from the sorted lists of its source cloud.  One wave = 64 query rows of one
+// coalition.  The wave first builds the coalition's kept-point bitmap (N bits) and the prefix counts of its 32-bit words in
+// LDS, so that "is point p kept" and "which compact row is it" (= the number of kept points before p) are two LDS reads
+// and a popcount; the only global reads of the walk are the list entries themselves, eight per 16-byte load.
+__global__ __launch_bounds__(64) void dg_walk_kernel(const int16_t* __restrict__ sorted, const int16_t* __restrict__ src,
+                                                     const int32_t* __restrict__ region_id, const uint64_t* __restrict__ keep,
+                                                     const int32_t* __restrict__ cloud_of, int16_t* __restrict__ idx, Ragged rg,
+                                                     int N, int Np, int Nsl, int nclouds, int as_addr) {
+    __shared__ unsigned bits[kWalkMaxN / 32];
+    __shared__ int pre[kWalkMaxN / 32];
+    const int b = blockIdx.y, lane = threadIdx.x, r = blockIdx.x * 64 + lane;
+    const int base = rg.roff[b], D = rg.roff[b + 1] - base;
+    if (blockIdx.x * 64 >= D) return;                 // wave-uniform
+    const int c = cloud_of ? cloud_of[b] : (nclouds == 1 ? 0 : b);
+    const uint64_t k = keep[b];
+    const int32_t* rid = region_id + (size_t)c * N;
+    for (int i0 = 0; i0 < kWalkMaxN; i0 += 64) {      // kept bitmap, 64 points per step
+        const int i = i0 + lane;
+        const unsigned long long m = __ballot(i < N && iq::keep_bit(k, rid[min(i, N - 1)]));
+        if (lane == 0) { bits[i0 >> 5] = (unsigned)m; bits[(i0 >> 5) + 1] = (unsigned)(m >> 32); }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < kWalkMaxN / 32) {                      // exclusive prefix of the word popcounts (32 words: a wave scan)
+        const int cnt = __popc(bits[lane]);
+        int run = cnt;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const int v = __shfl_up(run, o, 64);
+            if (lane >= o) run += v;
+        }
+        pre[lane] = run - cnt;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (r >= D) return;
+    const int nk = rg.nkept[b], mult = rg.ncopy[b];
+    const int live = nk + (mult > 0 ? 1 : 0);
+    auto code = [&](int row) { return (int16_t)(as_addr ? (row << 6) | (((row >> 2) & 3) << 4) : row); };
+    int16_t* o = idx + ((size_t)base + r) * kK;
+    if (r >= live) {   // dead padding row: never read as a neighbour list that matters; keep it valid
+#pragma unroll
+        for (int q = 0; q < kK; ++q) o[q] = code(0);
+        return;
+    }
+    const int16_t* list = sorted + ((size_t)c * (N + 1) + src[(size_t)b * Np + r]) * Nsl;
+    int weight = 0, n = 0;
+    for (int j0 = 0; j0 <= N && weight < kK; j0 += 8) {
+        const uint4 chunk = *reinterpret_cast<const uint4*>(list + j0);   // Nsl is a multiple of 8: whole chunks
+        const unsigned wds[4] = {chunk.x, chunk.y, chunk.z, chunk.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int p = (int)((wds[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+            if (j0 + e > N || weight >= kK) continue;
+            if (p == N) {
+                if (mult > 0) { o[n++] = code(nk); weight += mult; }     // the centre stands for min(M, 20) identical points
+            } else {
+                const unsigned wbits = bits[p >> 5];
+                if ((wbits >> (p & 31)) & 1u) {
+                    o[n++] = code(pre[p >> 5] + __popc(wbits & ((1u << (p & 31)) - 1u)));
+                    ++weight;
+                }
+            }
+        }
+    }
+    const int16_t fill = code(mult > 0 ? nk : r);   // (only a cloud with fewer than 20 distinct rows gets here: it has a centre)
+    for (; n < kK; ++n) o[n] = fill;
 }
 
 // ---- kNN ------------------------------------------------------------------------------------------
@@ -840,8 +999,31 @@ namespace {
 
 // The network on the ragged rows described by s.roff / s.nkept / s.ncopy / s.row_cloud; s.x0 holds the padded xyz rows.
 // `rows` = upper bound of the row count (grid sizes); the live count is roff[B], on the device.
+// Layer-1 graph from the source clouds' sorted neighbour lists (dg_walk_kernel) instead of rownorm + knn_kernel<8>
+struct WalkCtx {
+    const int16_t* sorted;   // (nclouds, N+1, Nsl)
+    const int16_t* src;      // (B, Np)
+    const int32_t* region_id;
+    const uint64_t* keep;
+    const int32_t* cloud_of;
+    int nclouds, Nsl;
+};
+
+// does run_network take the fused EdgeConv path?  (the walk tables live in the P/Q buffer that only the other path uses)
+bool fused_path(const iq_dgcnn_weights* w, int N) {
+    const int knob = iq::tuning(iq::kTuneExperiment);   // 7: GEMM + L2 gather, 8: GEMM + LDS gather (A/B and tests)
+    bool fused = (N + 31) / 32 * 32 <= kGlMaxRows && knob != 7 && knob != 8;
+    int ci = 8;
+    for (int l = 0; l < 4; ++l) {
+        const int co = w->pq[l].cout / 2;
+        fused = fused && co % 16 == 0 && (ci == 8 || ci == 64 || ci == 128) && w->pq[l].cin == ci;
+        ci = co;
+    }
+    return fused;
+}
+
 int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, int N, int rows, int fixed_graph,
-                hipStream_t st) {
+                hipStream_t st, const WalkCtx* walk = nullptr) {
     const Ragged rg{s.roff, s.nkept, s.ncopy, s.row_cloud, s.row_w};
     const int32_t* live = s.roff + B;
     int rc;
@@ -851,19 +1033,16 @@ int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, i
     const int knob = iq::tuning(iq::kTuneExperiment);   // 7: GEMM + L2 gather, 8: GEMM + LDS gather (A/B and tests)
     // edge_fused_kernel for every layer or for none: the kNN kernel writes the neighbour lists in the form the consumer reads
     // (LDS addresses for the fused kernel, row indices otherwise), and GCNN's one list serves all four layers
-    bool fused = Np <= kGlMaxRows && knob != 7 && knob != 8;
-    {
-        int ci = 8;
-        for (int l = 0; l < 4; ++l) {
-            const int co = w->pq[l].cout / 2;
-            fused = fused && co % 16 == 0 && (ci == 8 || ci == 64 || ci == 128) && w->pq[l].cin == ci;
-            ci = co;
-        }
-    }
+    const bool fused = fused_path(w, N);
     for (int l = 0; l < 4; ++l) {
         const int co = w->pq[l].cout / 2;
         IQ_REQUIRE(w->pq[l].cin == cin, "iq_dgcnn: layer %d expects %d inputs, got %d", l, cin, w->pq[l].cin);
-        if (l == 0 || !fixed_graph) {
+        if (l == 0 && walk) {
+            iq::ProfileSpan span(iq::kSlotPrepool, st);
+            hipLaunchKernelGGL(dg_walk_kernel, dim3((Np + 63) / 64, B), dim3(64), 0, st, walk->sorted, walk->src, walk->region_id,
+                               walk->keep, walk->cloud_of, s.idx, rg, N, Np, walk->Nsl, walk->nclouds, fused ? 1 : 0);
+            if ((rc = iq::check_launch("dg_walk_kernel"))) return rc;
+        } else if (l == 0 || !fixed_graph) {
             iq::ProfileSpan span(iq::kSlotPrepool, st);
             hipLaunchKernelGGL(rownorm_kernel, dim3((rows + 63) / 64), dim3(kThreads), 0, st, src, ld, creal, s.xx, rg, B);
             if ((rc = launch_knn(src, ld, cin, s.xx, s.idx, B, N, rg, st, fused))) return rc;
@@ -968,10 +1147,33 @@ extern "C" int iq_dgcnn_coalitions(const iq_dgcnn_weights* w, const float* cloud
     hipStream_t st = iq::as_stream(stream);
     int rc;
     iq::ProfileSpan call_span(iq::kSlotCall, st);
+    // Layer-1 graph from the source clouds' sorted neighbour lists when a few source clouds serve many coalitions.  The
+    // tables are carved from the P/Q buffer, which the fused EdgeConv path does not touch (tuning key 5 = 12: knn_kernel<8>).
+    const int Np = (N + 31) / 32 * 32, Nsp = (N + 1 + 31) / 32 * 32, Nsl = (N + 1 + 7) / 8 * 8;
+    WalkCtx walk{};
+    bool use_walk = false;
+    {
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off = iq::align_up(off + bytes, 256); return reinterpret_cast<char*>(s.pq) + o; };
+        float* xs = (float*)take((size_t)nclouds * Nsp * 8 * 4);
+        float* xxs = (float*)take((size_t)nclouds * Nsp * 4);
+        float* dmat = (float*)take((size_t)nclouds * Nsp * Nsp * 4);
+        int16_t* sorted = (int16_t*)take((size_t)nclouds * (N + 1) * Nsl * 2);
+        int16_t* srcrow = (int16_t*)take((size_t)B * Np * 2);
+        use_walk = N <= kWalkMaxN && (long long)nclouds * 8 <= B && fused_path(w, N) && iq::tuning(iq::kTuneExperiment) != 12 &&
+                   off <= (size_t)B * Np * 512 * 4;
+        if (use_walk) {
+            hipLaunchKernelGGL(dg_src_rows_kernel, dim3((Nsp + 255) / 256, nclouds), dim3(256), 0, st, clouds, centers, xs, xxs, N, Nsp);
+            hipLaunchKernelGGL(dg_src_dist_kernel, dim3(Nsp / 32, nclouds), dim3(64), 0, st, xs, xxs, dmat, Nsp);
+            hipLaunchKernelGGL(dg_src_sort_kernel, dim3(N + 1, nclouds), dim3(256), 0, st, dmat, sorted, N, Nsp, Nsl);
+            if ((rc = iq::check_launch("dg_src_sort_kernel"))) return rc;
+            walk = WalkCtx{sorted, srcrow, region_id, keep, cloud_of, nclouds, Nsl};
+        }
+    }
     hipLaunchKernelGGL(dg_count_kernel, dim3(B), dim3(64), 0, st, region_id, keep, cloud_of, s.nkept, s.ncopy, s.dpad, N, nclouds);
     hipLaunchKernelGGL(dg_scan_kernel, dim3(1), dim3(1024), 0, st, s.dpad, s.roff, B);
     hipLaunchKernelGGL(dg_compact_kernel, dim3(B), dim3(64), 0, st, clouds, centers, region_id, keep, cloud_of, s.roff, s.nkept,
-                       s.ncopy, s.x0, s.row_cloud, s.row_w, N, nclouds);
+                       s.ncopy, s.x0, s.row_cloud, s.row_w, N, nclouds, use_walk ? const_cast<int16_t*>(walk.src) : (int16_t*)nullptr, Np);
     if ((rc = iq::check_launch("dg_compact_kernel"))) return rc;
-    return run_network(w, s, logits, B, N, B * ((N + 31) / 32 * 32), fixed_graph, st);
+    return run_network(w, s, logits, B, N, B * Np, fixed_graph, st, use_walk ? &walk : nullptr);
 }

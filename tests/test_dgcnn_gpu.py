@@ -281,3 +281,32 @@ def test_centre_multiplicity_around_k(cls):
                          for k in keep])
     want = model.forward_points(dense)
     assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("cls", [DGCNN_cls, GCNN_cls])
+def test_layer1_graph_from_source_lists_is_bitwise_the_knn_kernel(cls):
+    """dg_walk_kernel (layer-1 neighbours of a coalition = the first kept entries of its source point's sorted neighbour list,
+    the centre counting min(M, 20) times) against knn_kernel<8> on the compact rows (tuning key 5 = 12): the same
+    neighbour sets, so bit-identical logits - two source clouds, coalitions from empty to full."""
+    from interpret_quality_amd import _lib
+    lib = _lib.load()
+    model = make(cls)
+    d = dev()
+    rng = np.random.default_rng(21)
+    clouds = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in (3, 4)]).to(d)
+    rid = torch.from_numpy(rng.integers(0, 32, size=(2, 1024)).astype(np.int32))
+    rid[1, :7] = 33                                                     # a 7-point region: M < 20 when only it is masked
+    rid = rid.to(d)
+    centers = clouds.mean(dim=1)
+    full = (1 << 34) - 1
+    keep = [int(x) | (1 << 33) for x in rng.integers(0, 1 << 32, size=44)] + [full, 0, full ^ (1 << 33), 1 << 33, 1, full ^ 1]
+    cloud_of = [i % 2 for i in range(len(keep))]
+    keep_t = hip_ops.masks_to_tensor(keep, d)
+    co_t = torch.tensor(cloud_of, dtype=torch.int32, device=d)
+    walk = model.coalition_logits(clouds, centers, rid, keep_t, co_t, num_regions=34).clone()
+    lib.iq_set_tuning(5, 12)
+    try:
+        knn = model.coalition_logits(clouds, centers, rid, keep_t, co_t, num_regions=34).clone()
+    finally:
+        lib.iq_set_tuning(5, 0)
+    assert torch.equal(walk, knn)
