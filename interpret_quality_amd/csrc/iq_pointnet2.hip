@@ -527,6 +527,10 @@ struct PairTabs {
     const float* feat[3];    // (rows, C3)
     int c3[3];
     bool use[3];
+    // ball query of sa1 by bit operations (all three scales on tables, N <= 1024): per (cloud, centroid point, scale) the
+    // members inside the radius as a bit mask over the points (bit N, word 32: the centre), and per coalition its kept points
+    const uint32_t* ball_bits[3];   // (nc, N+1, 33) each, or null
+    const uint32_t* kept_bits;      // (B, 32)
 };
 
 __device__ __forceinline__ float pt_dist(const float* c, const float* v) {  // ball_query_kernel's expression
@@ -536,6 +540,86 @@ __device__ __forceinline__ float pt_dist(const float* c, const float* v) {  // b
     dot = __fmaf_rn(c[1], v[1], dot);
     dot = __fmaf_rn(c[2], v[2], dot);
     return __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), sc), sv);
+}
+
+// ---- sa1 ball query by bit operations ----------------------------------------------------------------------------------
+// Which source points lie inside a radius of a source point (or of the centre) does not depend on the coalition - the pair
+// table's row map already says so (row >= 0) - only which of them exist does.  ball_query_kernel walks the 1024 points of
+// every masked cloud for each of its 512 centroids; here the members of a ball are the set bits, lowest index first, of
+//     (inside[centroid] & kept) | (centre inside ? masked : 0)
+// over 32 words: the K lowest indices inside the radius of the masked cloud, masked points (all at the centre) included -
+// the lists ball_query_kernel writes, minus the padding that nothing on this path reads.
+constexpr int kBallWords = 33;   // 1024 point bits + the centre's
+
+// bits[c][centroid][w] from the row map of a scale: bit j of word w = pair (centroid, 32 w + j) has a row
+__global__ __launch_bounds__(64) void pt_bits_kernel(const int32_t* __restrict__ map, uint32_t* __restrict__ bits, int n1) {
+    const int c = blockIdx.y, ci = blockIdx.x, w = threadIdx.x;
+    if (w >= kBallWords) return;
+    const int32_t* mrow = map + ((size_t)c * n1 + ci) * n1;
+    uint32_t v = 0;
+    for (int j = 0; j < 32; ++j) {
+        const int e = w * 32 + j;
+        if (e < n1 && mrow[e] >= 0) v |= 1u << j;
+    }
+    bits[((size_t)c * n1 + ci) * kBallWords + w] = v;
+}
+
+// kept[b][w]: bit j = point 32 w + j of coalition b's cloud is kept (N <= 1024)
+__global__ __launch_bounds__(64) void pn2_kept_bits_kernel(const int32_t* __restrict__ region_id, const uint64_t* __restrict__ keep,
+                                                           const int32_t* __restrict__ cloud_of, uint32_t* __restrict__ kept, int N,
+                                                           int nclouds) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int c = cloud_of ? cloud_of[b] : (nclouds == 1 ? 0 : b);
+    const uint64_t k = keep[b];
+    const int32_t* rid = region_id + (size_t)c * N;
+    for (int i0 = 0; i0 < 1024; i0 += 64) {
+        const int i = i0 + lane;
+        const unsigned long long m = __ballot(i < N && iq::keep_bit(k, rid[min(i, N - 1)]));
+        if (lane == 0) { kept[(size_t)b * 32 + (i0 >> 5)] = (uint32_t)m; kept[(size_t)b * 32 + (i0 >> 5) + 1] = (uint32_t)(m >> 32); }
+    }
+}
+
+struct BitBallArgs {
+    const uint32_t* bits[3];
+    const uint32_t* kept;
+    const int32_t* fps;        // (B,S) centroid indices into the masked cloud
+    const int32_t* n_unique;   // (B)
+    const int32_t* cloud_of;
+    int16_t* idx[3];
+    int32_t* cnt[3];
+    int K[3];
+    int N, S, B, nclouds;
+};
+
+__global__ __launch_bounds__(kThreads) void pn2_bitball_kernel(BitBallArgs a) {
+    const int b = blockIdx.y, s = blockIdx.x * kThreads + threadIdx.x;
+    if (s >= a.S || s >= a.n_unique[b]) return;           // duplicate centroids are filled from group 0 afterwards
+    const int c = a.cloud_of ? a.cloud_of[b] : (a.nclouds == 1 ? 0 : b);
+    const uint32_t* kept = a.kept + (size_t)b * 32;
+    const int pi = a.fps[(size_t)b * a.S + s];
+    const int ci = (kept[pi >> 5] >> (pi & 31)) & 1u ? pi : a.N;   // a masked centroid sits at the centre
+    const int n1 = a.N + 1;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const uint32_t* wb = a.bits[q] + ((size_t)c * n1 + ci) * kBallWords;
+        const bool centre_in = (wb[a.N >> 5] >> (a.N & 31)) & 1u;     // the centre as a member: bit N
+        int16_t* out = a.idx[q] + ((size_t)b * a.S + s) * a.K[q];
+        const int K = a.K[q];
+        int cnt = 0;
+        for (int w = 0; w < 32 && cnt < K; ++w) {
+            const int lo = w * 32;
+            if (lo >= a.N) break;
+            const uint32_t valid = a.N - lo >= 32 ? 0xffffffffu : (1u << (a.N - lo)) - 1u;
+            const uint32_t kw = kept[w];
+            uint32_t cand = (wb[w] & kw) | (centre_in ? (~kw & valid) : 0u);
+            if (w == (a.N >> 5)) cand &= valid;                        // bit N itself is not a point
+            while (cand && cnt < K) {
+                out[cnt++] = (int16_t)(lo + __builtin_ctz(cand));
+                cand &= cand - 1;
+            }
+        }
+        a.cnt[q][(size_t)b * a.S + s] = cnt;
+    }
 }
 
 // masked clouds: X[b][i] = kept ? clouds[c][i] : centers[c]
@@ -818,7 +902,16 @@ int run_pn2(const iq_pointnet2_weights* w, const float* xyz, float* logits, cons
     if ((rc = iq::launch_fps(xyz, s.fps1, s.nu1, B, N, S1, st))) return rc;
     hipLaunchKernelGGL(gather_xyz_kernel, dim3((B * S1 + 255) / 256), dim3(256), 0, st, xyz, s.fps1, s.nx1, 3, N, S1, B * S1);
     if ((rc = iq::check_launch("gather_xyz_kernel"))) return rc;
-    if ((rc = launch_ball(xyz, s.nx1, 3, w->sa1, 3, s.idx1, s.cnt1, nullptr, B, N, S1, st))) return rc;
+    if (tab && tab->ball_bits[0]) {
+        BitBallArgs ba{};
+        for (int q = 0; q < 3; ++q) { ba.bits[q] = tab->ball_bits[q]; ba.idx[q] = s.idx1[q]; ba.cnt[q] = s.cnt1[q]; ba.K[q] = w->sa1[q].nsample; }
+        ba.kept = tab->kept_bits; ba.fps = s.fps1; ba.n_unique = s.nu1; ba.cloud_of = gat->cloud_of;
+        ba.N = N; ba.S = S1; ba.B = B; ba.nclouds = gat->nclouds;
+        hipLaunchKernelGGL(pn2_bitball_kernel, dim3((S1 + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st, ba);
+        if ((rc = iq::check_launch("pn2_bitball_kernel"))) return rc;
+    } else if ((rc = launch_ball(xyz, s.nx1, 3, w->sa1, 3, s.idx1, s.cnt1, nullptr, B, N, S1, st))) {
+        return rc;
+    }
     // the grouped kernel merges straddling groups with an atomic max (zero-initialised output); the table gather stores
     const bool all_tables = tab && tab->use[0] && tab->use[1] && tab->use[2];
     if (!all_tables && hipMemsetAsync(s.l1, 0, (size_t)B * S1 * F1 * sizeof(float), st) != hipSuccess)
@@ -920,6 +1013,8 @@ struct WsC {
     uint32_t* pairs;   // (cap) of the scale being built
     float *h1, *h2;    // (cap, C1 / C2) of the scale being built
     float* feat[3];    // (cap, C3)
+    uint32_t* ball_bits[3];   // (nc, N+1, 33)
+    uint32_t* kept_bits;      // (B, 32)
     size_t bytes;
 };
 
@@ -943,6 +1038,8 @@ WsC carve_c(void* base, int B, int nc, int N) {
     s.h2 = (float*)take(cap * 96 * 4);
     const int c3[3] = {64, 128, 128};
     for (int q = 0; q < 3; ++q) s.feat[q] = (float*)take(cap * c3[q] * 4);
+    for (int q = 0; q < 3; ++q) s.ball_bits[q] = (uint32_t*)take((size_t)nc * n1 * kBallWords * 4);
+    s.kept_bits = (uint32_t*)take((size_t)B * 32 * 4);
     s.bytes = off;
     return s;
 }
@@ -1014,6 +1111,16 @@ extern "C" int iq_pointnet2_coalitions(const iq_pointnet2_weights* w, const floa
             if ((rc = iq::launch_linear(t.h1, sc.l2.cin, sc.l2, t.h2, sc.l2.cout, row0, 1, st))) return rc;
             if ((rc = iq::launch_linear(t.h2, sc.l2.cout, sc.l3, t.feat[q], sc.l3.cout, row0, 1, st))) return rc;
         }
+    }
+    if (tab.use[0] && tab.use[1] && tab.use[2] && N <= 1024 && iq::tuning(iq::kTuneExperiment) != 13) {
+        // sa1's ball query by bit operations on the row maps just built (tuning key 5 = 13: ball_query_kernel)
+        for (int q = 0; q < 3; ++q) {
+            hipLaunchKernelGGL(pt_bits_kernel, dim3(n1, nclouds), dim3(64), 0, st, t.map[q], t.ball_bits[q], n1);
+            tab.ball_bits[q] = t.ball_bits[q];
+        }
+        hipLaunchKernelGGL(pn2_kept_bits_kernel, dim3(B), dim3(64), 0, st, region_id, keep, cloud_of, t.kept_bits, N, nclouds);
+        if ((rc = iq::check_launch("pn2_kept_bits_kernel"))) return rc;
+        tab.kept_bits = t.kept_bits;
     }
     GatherArgs g{};
     g.region_id = region_id; g.keep = keep; g.cloud_of = cloud_of; g.nclouds = nclouds;
