@@ -351,6 +351,19 @@ int iq_pointconv_forward(const iq_pointconv_weights* w /*host struct of device p
                          float* logits, void* workspace, size_t workspace_bytes, int B, int N,
                          iq_stream_t stream);
 
+/* Logits of B coalitions given as region bit masks over nclouds source clouds - the same call as
+ * iq_pointnet2_coalitions / iq_dgcnn_coalitions; replaces mask_data_batch + model(...) of tools/final_common.py:46-61,
+ * 26-43 and final_point_binary_interaction_logits.py:45-60 for PointConv.  The masked clouds are written into the
+ * workspace and run through the forward of iq_pointconv_forward.  When a few source clouds serve many coalitions
+ * (nclouds <= 8, or nclouds * 8 <= B) the K-nearest groups of sa1 and sa2 (models/pointconv.py:103-114) are read off per-source-cloud
+ * sorted neighbour lists, built once per call with the kNN kernel's own distance expression: in xyz space neither the
+ * distance between two points nor the centre depends on the coalition, only the candidate set does (the same point
+ * sets as the kNN kernel up to ties; masked points are interchangeable).  512 <= N <= 1024.  Asynchronous on `stream`. */
+size_t iq_pointconv_coalitions_workspace_bytes(int B, int nclouds, int N);
+int iq_pointconv_coalitions(const iq_pointconv_weights* w, const float* clouds, const float* centers,
+                            const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of, float* logits,
+                            void* workspace, size_t workspace_bytes, int B, int nclouds, int N, iq_stream_t stream);
+
 /* Optional HIP-event profiler (bench.py's roofline leg).  While enabled, iq_pointnet_coalitions
  * brackets its chain-kernel launches with hipEvents recorded on the launch stream.
  * iq_profile_read(slot) synchronises on the recorded events of that slot, returns their summed

@@ -22,6 +22,7 @@
 #include "iq_common.h"
 #include "iq_mfma.h"
 #include "iq_profile.h"
+#include "iq_srclist.h"
 #include "iq_topk.h"
 
 namespace {
@@ -195,87 +196,10 @@ __global__ __launch_bounds__(kThreads) void rownorm_kernel(const float* __restri
 // In xyz space the distance between two kept points does not depend on the coalition, and neither does the centre (the mean
 // of the whole cloud): only the SET of candidates does.  So per source cloud (a few per call, against thousands of
 // coalitions) every point's complete neighbour list - all other points and the centre, nearest first, by the very
-// distances knn_kernel<8> computes - is built once (dg_src_rows -> dg_src_dist -> dg_src_sort), and the 20 nearest of a
+// distances knn_kernel<8> computes - is built once (iq_srclist.h: sl_rows -> sl_dist -> sl_sort), and the 20 nearest of a
 // coalition's query are the first entries of its source point's list that the coalition keeps, the centre entry counting
 // min(M, 20) times (dg_walk_kernel: a few dozen 2-byte entries per query instead of a D x D distance matrix and a top-k).
 // The same neighbours as knn_kernel<8> on the compact rows (same arithmetic for every distance, ties by point index).
-constexpr int kWalkMaxN = 1024;   // source cloud points (the per-row sort holds 2048 entries)
-
-// rows of source cloud c: its N points, the centre (row N), zero padding with |x|^2 = +inf
-__global__ void dg_src_rows_kernel(const float* __restrict__ clouds, const float* __restrict__ centers, float* __restrict__ xs,
-                                   float* __restrict__ xxs, int N, int Nsp) {
-    const int c = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Nsp) return;
-    const float* src = i < N ? clouds + ((size_t)c * N + i) * 3 : centers + (size_t)c * 3;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    float s = INFINITY;
-    if (i <= N) {
-        a = (f32x4){src[0], src[1], src[2], 0.f};
-        s = 0.f;                      // rownorm_kernel's order: ((0 + x^2) + y^2) + z^2
-        s += a[0] * a[0];
-        s += a[1] * a[1];
-        s += a[2] * a[2];
-    }
-    float* o = xs + ((size_t)c * Nsp + i) * 8;
-    *reinterpret_cast<f32x4*>(o) = a;
-    *reinterpret_cast<f32x4*>(o + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    xxs[(size_t)c * Nsp + i] = s;
-}
-
-// dmat[c][q][k] = knn_kernel<8>'s distance of query row q and key row k (one wave = 32 queries, all key tiles)
-__global__ __launch_bounds__(64) void dg_src_dist_kernel(const float* __restrict__ xs, const float* __restrict__ xxs,
-                                                         float* __restrict__ dmat, int Nsp) {
-    const int c = blockIdx.y, q0 = blockIdx.x * 32, lane = threadIdx.x;
-    const int fl = lane & 31, fh = lane >> 5;
-    const float* xb = xs + (size_t)c * Nsp * 8;
-    const float* xxb = xxs + (size_t)c * Nsp;
-    const f32x4 qf = *reinterpret_cast<const f32x4*>(xb + (size_t)(q0 + fl) * 8 + 4 * fh);
-    const float xxq = xxb[q0 + fl];
-    float* drow = dmat + ((size_t)c * Nsp + q0 + fl) * Nsp;
-    for (int t = 0; t < Nsp / 32; ++t) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(xb + (size_t)(t * 32 + fl) * 8 + 4 * fh);
-        f32x16 acc = {0};
-        acc = mfma4(a, qf, acc);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = t * 32 + c_row(r, lane);
-            drow[key] = __builtin_fmaf(2.f, acc[r], -xxb[key]) - xxq;   // knn_kernel's expression
-        }
-    }
-}
-
-// sorted[c][q][.] = the rows 0..N of source cloud c, nearest to row q first (larger distance value first; ties: lower index)
-__global__ __launch_bounds__(256) void dg_src_sort_kernel(const float* __restrict__ dmat, int16_t* __restrict__ sorted, int N,
-                                                          int Nsp, int Nsl) {
-    __shared__ unsigned long long e[2048];
-    const int c = blockIdx.y, q = blockIdx.x, t = threadIdx.x;
-    const float* drow = dmat + ((size_t)c * Nsp + q) * Nsp;
-    for (int j = t; j < 2048; j += 256) {
-        unsigned long long key = ~0ull;
-        if (j <= N) {
-            const unsigned o = __float_as_uint(-drow[j]);                       // ascending in -d = descending in d
-            const unsigned u = (o & 0x80000000u) ? ~o : (o | 0x80000000u);      // order-preserving map of a float to an unsigned
-            key = ((unsigned long long)u << 16) | (unsigned)j;
-        }
-        e[j] = key;
-    }
-    __syncthreads();
-    for (int k = 2; k <= 2048; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = t; i < 2048; i += 256) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const unsigned long long a = e[i], b = e[p];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { e[i] = b; e[p] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    int16_t* o = sorted + ((size_t)c * (N + 1) + q) * Nsl;
-    for (int j = t; j <= N; j += 256) o[j] = (int16_t)(e[j] & 0xffffu);
-}
-
 // neighbour lists of the rows of coalition b from the sorted lists of its source cloud.  One wave = 64 query rows of one
 // coalition.  The wave first builds the coalition's kept-point bitmap (N bits) and the prefix counts of its 32-bit words in
 // LDS, so that "is point p kept" and "which compact row is it" (= the number of kept points before p) are two LDS reads
@@ -1163,10 +1087,10 @@ extern "C" int iq_dgcnn_coalitions(const iq_dgcnn_weights* w, const float* cloud
         use_walk = N <= kWalkMaxN && (long long)nclouds * 8 <= B && fused_path(w, N) && iq::tuning(iq::kTuneExperiment) != 12 &&
                    off <= (size_t)B * Np * 512 * 4;
         if (use_walk) {
-            hipLaunchKernelGGL(dg_src_rows_kernel, dim3((Nsp + 255) / 256, nclouds), dim3(256), 0, st, clouds, centers, xs, xxs, N, Nsp);
-            hipLaunchKernelGGL(dg_src_dist_kernel, dim3(Nsp / 32, nclouds), dim3(64), 0, st, xs, xxs, dmat, Nsp);
-            hipLaunchKernelGGL(dg_src_sort_kernel, dim3(N + 1, nclouds), dim3(256), 0, st, dmat, sorted, N, Nsp, Nsl);
-            if ((rc = iq::check_launch("dg_src_sort_kernel"))) return rc;
+            hipLaunchKernelGGL(sl_rows_kernel, dim3((Nsp + 255) / 256, nclouds), dim3(256), 0, st, clouds, centers, xs, xxs, N, Nsp);
+            hipLaunchKernelGGL(sl_dist_kernel<0>, dim3(Nsp / 32, nclouds), dim3(64), 0, st, xs, xxs, dmat, Nsp);
+            hipLaunchKernelGGL(sl_sort_kernel, dim3(N + 1, nclouds), dim3(256), 0, st, dmat, sorted, N, Nsp, Nsl);
+            if ((rc = iq::check_launch("sl_sort_kernel"))) return rc;
             walk = WalkCtx{sorted, srcrow, region_id, keep, cloud_of, nclouds, Nsl};
         }
     }

@@ -12,6 +12,7 @@
 #include "iq_common.h"
 #include "iq_mfma.h"
 #include "iq_profile.h"
+#include "iq_srclist.h"
 #include "iq_topk.h"
 
 namespace {
@@ -488,6 +489,137 @@ __global__ void pc_fill_dup_rows_kernel(float* __restrict__ out, int S, int C, c
     for (int c = threadIdx.x; c < C; c += blockDim.x) dst[c] = src[c];
 }
 
+// ==== coalitions: the K-nearest groups of sa1 / sa2 from the source cloud's sorted neighbour lists (iq_srclist.h) ==========
+// All coalitions of a call are masked copies of a few source clouds.  In xyz space the distance between two source points
+// (or a point and the centre, where all masked points sit) does not depend on the coalition, so the K nearest points of a
+// centroid are the first entries of its source point's sorted list that exist in the coalition:
+//   sa1 (keys = the N points of the masked cloud): a kept point is itself; the centre entry stands for ALL masked points
+//       (identical coordinates and densities, so which of them fill the group does not matter to the sum over members);
+//   sa2 (keys = the 512 sa1 centroids): a source point exists if sa1's FPS picked it (position < n_unique); the location of
+//       position 0 also owns the 512 - n_unique duplicate positions that FPS returns once the distinct locations are used up.
+// The distances are pc_knn_kernel's own (sl_dist_kernel<1>), so the groups are the same point sets up to ties.
+
+// per coalition: kept-point bitmap (32 words), the first 64 masked point indices and their number
+__global__ __launch_bounds__(64) void pc_coal_prep_kernel(const int32_t* __restrict__ region_id, const uint64_t* __restrict__ keep,
+                                                          const int32_t* __restrict__ cloud_of, uint32_t* __restrict__ kept,
+                                                          int16_t* __restrict__ mfirst, int32_t* __restrict__ mcount, int N,
+                                                          int nclouds) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int c = cloud_of ? cloud_of[b] : (nclouds == 1 ? 0 : b);
+    const uint64_t k = keep[b];
+    const int32_t* rid = region_id + (size_t)c * N;
+    int nm = 0;
+    for (int i0 = 0; i0 < kWalkMaxN; i0 += 64) {
+        const int i = i0 + lane;
+        const bool in = i < N;
+        const bool kp = in && iq::keep_bit(k, rid[min(i, N - 1)]);
+        const unsigned long long m = __ballot(kp), mm = __ballot(in && !kp);
+        if (lane == 0) { kept[(size_t)b * 32 + (i0 >> 5)] = (uint32_t)m; kept[(size_t)b * 32 + (i0 >> 5) + 1] = (uint32_t)(m >> 32); }
+        if (in && !kp) {
+            const int pos = nm + __popcll(mm & ((1ull << lane) - 1ull));
+            if (pos < 64) mfirst[(size_t)b * 64 + pos] = (int16_t)i;
+        }
+        nm += __popcll(mm);
+    }
+    if (lane == 0) mcount[b] = nm;
+}
+
+// sa1 groups: thread = centroid position s of coalition b; idx (B,S,K) indices into the masked cloud
+template <int K>
+__global__ __launch_bounds__(64) void pc_walk1_kernel(const int16_t* __restrict__ sorted, const uint32_t* __restrict__ kept,
+                                                      const int16_t* __restrict__ mfirst, const int32_t* __restrict__ mcount,
+                                                      const int32_t* __restrict__ fps, const int32_t* __restrict__ n_unique,
+                                                      const int32_t* __restrict__ cloud_of, int16_t* __restrict__ idx, int N, int S,
+                                                      int Nsl, int nclouds) {
+    __shared__ uint32_t bits[32];
+    const int b = blockIdx.y, lane = threadIdx.x, s = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= n_unique[b]) return;        // wave-uniform: duplicate centroids are filled afterwards
+    if (lane < 32) bits[lane] = kept[(size_t)b * 32 + lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (s >= S || s >= n_unique[b]) return;
+    const int c = cloud_of ? cloud_of[b] : (nclouds == 1 ? 0 : b);
+    const int pi = fps[(size_t)b * S + s];
+    const int ci = (bits[pi >> 5] >> (pi & 31)) & 1u ? pi : N;       // a masked centroid sits at the centre
+    const int16_t* list = sorted + ((size_t)c * (N + 1) + ci) * Nsl;
+    const int16_t* mf = mfirst + (size_t)b * 64;
+    const int M = mcount[b];
+    int16_t* o = idx + ((size_t)b * S + s) * K;
+    int n = 0;
+    for (int j0 = 0; j0 <= N && n < K; j0 += 8) {
+        const uint4 chunk = *reinterpret_cast<const uint4*>(list + j0);
+        const unsigned wds[4] = {chunk.x, chunk.y, chunk.z, chunk.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int p = (int)((wds[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+            if (j0 + e > N || n >= K) continue;
+            if (p == N) {                                            // the centre: every masked point is here
+                const int t = min(M, K - n);
+                for (int u = 0; u < t; ++u) o[n++] = mf[u];
+            } else if ((bits[p >> 5] >> (p & 31)) & 1u) {
+                o[n++] = (int16_t)p;
+            }
+        }
+    }
+}
+
+// per coalition: which source point each sa1 position stands for, and the position of each picked source point
+__global__ __launch_bounds__(64) void pc_pos_kernel(const uint32_t* __restrict__ kept, const int32_t* __restrict__ fps1,
+                                                    const int32_t* __restrict__ n_unique, int16_t* __restrict__ src1 /*(B,S1)*/,
+                                                    int16_t* __restrict__ pos /*(B,Npos)*/, int N, int S1, int Npos) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t* kb = kept + (size_t)b * 32;
+    const int nu = n_unique[b];
+    for (int i = lane; i < Npos; i += 64) pos[(size_t)b * Npos + i] = -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int p0 = fps1[(size_t)b * S1];
+    const int e0 = (kb[p0 >> 5] >> (p0 & 31)) & 1u ? p0 : N;
+    for (int j = lane; j < S1; j += 64) {
+        const int pi = fps1[(size_t)b * S1 + j];
+        const int sp = j < nu ? ((kb[pi >> 5] >> (pi & 31)) & 1u ? pi : N) : e0;   // positions >= n_unique repeat position 0
+        src1[(size_t)b * S1 + j] = (int16_t)sp;
+        if (j < nu) pos[(size_t)b * Npos + sp] = (int16_t)j;
+    }
+}
+
+// sa2 groups: thread = sa2 centroid s2 of coalition b; idx (B,S2,K) positions in the sa1 point list
+template <int K>
+__global__ __launch_bounds__(64) void pc_walk2_kernel(const int16_t* __restrict__ sorted, const int16_t* __restrict__ src1,
+                                                      const int16_t* __restrict__ pos, const int32_t* __restrict__ fps2,
+                                                      const int32_t* __restrict__ n_unique, const int32_t* __restrict__ cloud_of,
+                                                      int16_t* __restrict__ idx, int N, int S1, int S2, int Nsl, int Npos,
+                                                      int nclouds) {
+    const int b = blockIdx.y, s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= S2) return;
+    const int c = cloud_of ? cloud_of[b] : (nclouds == 1 ? 0 : b);
+    const int nu = n_unique[b];
+    const int16_t* ps = pos + (size_t)b * Npos;
+    const int ci = src1[(size_t)b * S1 + fps2[(size_t)b * S2 + s]];
+    const int e0 = src1[(size_t)b * S1];                             // the location that owns the duplicate positions nu .. S1-1
+    const int16_t* list = sorted + ((size_t)c * (N + 1) + ci) * Nsl;
+    int16_t* o = idx + ((size_t)b * S2 + s) * K;
+    int n = 0;
+    for (int j0 = 0; j0 <= N && n < K; j0 += 8) {
+        const uint4 chunk = *reinterpret_cast<const uint4*>(list + j0);
+        const unsigned wds[4] = {chunk.x, chunk.y, chunk.z, chunk.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int p = (int)((wds[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+            if (j0 + e > N || n >= K) continue;
+            const int j = ps[p];
+            if (j < 0) continue;
+            o[n++] = (int16_t)j;
+            if (p == e0) {
+                const int t = min(S1 - nu, K - n);
+                for (int u = 0; u < t; ++u) o[n++] = (int16_t)(nu + u);
+            }
+        }
+    }
+}
+
 struct WsC {
     float *inv1, *inv2, *inv3;
     int32_t *fps1, *fps2, *nu1;
@@ -579,19 +711,24 @@ extern "C" size_t iq_pointconv_workspace_bytes(int B, int N) {
     return carve_c(nullptr, B, N).bytes;
 }
 
-extern "C" int iq_pointconv_forward(const iq_pointconv_weights* w, const float* xyz, float* logits, void* workspace,
-                                    size_t workspace_bytes, int B, int N, iq_stream_t stream) {
-    IQ_REQUIRE(w && xyz && logits, "iq_pointconv_forward: null pointer");
-    IQ_REQUIRE(B >= 0 && N >= 512 && N <= 4096, "iq_pointconv_forward: N=%d not in [512, 4096]", N);
-    IQ_REQUIRE(w->sa[0].nsample == 32 && w->sa[1].nsample == 64, "iq_pointconv_forward: nsample must be 32 / 64");
-    if (B == 0) return IQ_OK;
-    const size_t need = carve_c(nullptr, B, N).bytes;
-    if (!workspace || workspace_bytes < need)
-        return iq::fail(IQ_EWORKSPACE, "iq_pointconv_forward: workspace %zu < %zu bytes", workspace_bytes, need);
-    WsC s = carve_c(workspace, B, N);
-    hipStream_t st = iq::as_stream(stream);
+namespace {
+
+// groups from the source clouds' sorted neighbour lists instead of pc_knn_kernel (iq_pointconv_coalitions)
+struct PcWalk {
+    const int16_t* sorted;     // (nclouds, N+1, Nsl)
+    const uint32_t* kept;      // (B, 32)
+    const int16_t* mfirst;     // (B, 64)
+    const int32_t* mcount;     // (B)
+    int16_t* src1;             // (B, 512)
+    int16_t* pos;              // (B, Npos)
+    const int32_t* cloud_of;
+    int nclouds, Nsl, Npos;
+};
+
+// the network on B materialised clouds xyz (B,N,3)
+int run_pointconv(const iq_pointconv_weights* w, const float* xyz, float* logits, WsC& s, int B, int N, hipStream_t st,
+                  const PcWalk* walk) {
     int rc;
-    iq::ProfileSpan call_span(iq::kSlotCall, st);
     constexpr int S1 = 512, S2 = 128;
 
     // ---- sa1: 1024 -> 512 points, K = 32, 3 -> 64 -> 64 -> 128 ---------------------------------------------------
@@ -603,7 +740,13 @@ extern "C" int iq_pointconv_forward(const iq_pointconv_weights* w, const float* 
         hipLaunchKernelGGL(pc_gather_xyz_kernel, dim3((B * S1 + 255) / 256), dim3(256), 0, st, xyz, 3, s.fps1, s.nx1, N, S1, B * S1);
         // a masked cloud has at most kept + 1 distinct locations: once FPS has used them up it returns index 0, so centroids
         // s >= nu1 are copies of centroid 0 and their groups (kNN, members, MLP, contraction, linear layer) are not computed
-        if ((rc = launch_pc_knn<32>(xyz, N, s.nx1, S1, s, s.idx1, B, st, s.nu1))) return rc;
+        if (walk) {
+            hipLaunchKernelGGL(pc_walk1_kernel<32>, dim3(S1 / 64, B), dim3(64), 0, st, walk->sorted, walk->kept, walk->mfirst,
+                               walk->mcount, s.fps1, s.nu1, walk->cloud_of, s.idx1, N, S1, walk->Nsl, walk->nclouds);
+            if ((rc = iq::check_launch("pc_walk1_kernel"))) return rc;
+        } else if ((rc = launch_pc_knn<32>(xyz, N, s.nx1, S1, s, s.idx1, B, st, s.nu1))) {
+            return rc;
+        }
         if ((rc = launch_pc_group(w->sa[0], xyz, s.nx1, s.idx1, s.inv1, nullptr, 0, s.g1, s, N, S1, 32, B, st, s.nu1))) return rc;
         if ((rc = iq::launch_linear(s.g1, 2048, w->sa[0].linear, s.l1, 128, B * S1, 1, st, nullptr, s.nu1, S1))) return rc;
         hipLaunchKernelGGL(pc_fill_dup_rows_kernel, dim3(S1, B), dim3(64), 0, st, s.l1, S1, 128, s.nu1);
@@ -616,7 +759,14 @@ extern "C" int iq_pointconv_forward(const iq_pointconv_weights* w, const float* 
                            w->sa[1].bandwidth, s.inv2, S1);
         if ((rc = iq::launch_fps(s.nx1, s.fps2, nullptr, B, S1, S2, st))) return rc;
         hipLaunchKernelGGL(pc_gather_xyz_kernel, dim3((B * S2 + 255) / 256), dim3(256), 0, st, s.nx1, 3, s.fps2, s.nx2, S1, S2, B * S2);
-        if ((rc = launch_pc_knn<64>(s.nx1, S1, s.nx2, S2, s, s.idx2, B, st))) return rc;
+        if (walk) {
+            hipLaunchKernelGGL(pc_pos_kernel, dim3(B), dim3(64), 0, st, walk->kept, s.fps1, s.nu1, walk->src1, walk->pos, N, S1, walk->Npos);
+            hipLaunchKernelGGL(pc_walk2_kernel<64>, dim3(S2 / 64, B), dim3(64), 0, st, walk->sorted, walk->src1, walk->pos, s.fps2, s.nu1,
+                               walk->cloud_of, s.idx2, N, S1, S2, walk->Nsl, walk->Npos, walk->nclouds);
+            if ((rc = iq::check_launch("pc_walk2_kernel"))) return rc;
+        } else if ((rc = launch_pc_knn<64>(s.nx1, S1, s.nx2, S2, s, s.idx2, B, st))) {
+            return rc;
+        }
         if ((rc = iq::launch_linear(s.l1, 128, w->sa[1].u, s.u2, 128, B * S1, 0, st))) return rc;
         if ((rc = launch_pc_group(w->sa[1], s.nx1, s.nx2, s.idx2, s.inv2, s.u2, 128, s.g2, s, S1, S2, 64, B, st))) return rc;
         if ((rc = iq::launch_linear(s.g2, 4096, w->sa[1].linear, s.l2, 256, B * S2, 1, st))) return rc;
@@ -641,4 +791,112 @@ extern "C" int iq_pointconv_forward(const iq_pointconv_weights* w, const float* 
     if ((rc = iq::launch_linear(s.f1, 512, w->fc2, s.f2, 256, B, 1, st))) return rc;
     if ((rc = iq::launch_linear(s.f2, 256, w->fc3, logits, w->fc3.cout, B, 0, st))) return rc;
     return IQ_OK;
+}
+
+// masked clouds: X[b][i] = kept ? clouds[c][i] : centers[c]   (models see what mask_data_batch would write)
+__global__ void pc_mask_kernel(const float* __restrict__ clouds, const float* __restrict__ centers, const uint32_t* __restrict__ kept,
+                               const int32_t* __restrict__ cloud_of, float* __restrict__ out, int N, int B, int nclouds) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * N) return;
+    const int b = t / N, i = t - b * N;
+    const int c = cloud_of ? cloud_of[b] : (nclouds == 1 ? 0 : b);
+    const bool kp = (kept[(size_t)b * 32 + (i >> 5)] >> (i & 31)) & 1u;
+    const float* src = kp ? clouds + ((size_t)c * N + i) * 3 : centers + (size_t)c * 3;
+    out[(size_t)t * 3] = src[0]; out[(size_t)t * 3 + 1] = src[1]; out[(size_t)t * 3 + 2] = src[2];
+}
+
+struct WsW {   // coalition extras behind the forward's workspace
+    float* X;            // (B,N,3)
+    float *xs, *xxs, *dmat;
+    int16_t* sorted;
+    uint32_t* kept;
+    int16_t* mfirst;
+    int32_t* mcount;
+    int16_t *src1, *pos;
+    size_t bytes;
+};
+
+WsW carve_w(void* base, int B, int nc, int N) {
+    WsW s{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = iq::align_up(off + bytes, 256);
+        return reinterpret_cast<char*>(base) + o;
+    };
+    const size_t Nsp = (size_t)(N + 1 + 31) / 32 * 32, Nsl = (size_t)(N + 1 + 7) / 8 * 8;
+    s.X = (float*)take((size_t)B * N * 3 * 4);
+    s.xs = (float*)take((size_t)nc * Nsp * 8 * 4);
+    s.xxs = (float*)take((size_t)nc * Nsp * 4);
+    s.dmat = (float*)take((size_t)nc * Nsp * Nsp * 4);
+    s.sorted = (int16_t*)take((size_t)nc * (N + 1) * Nsl * 2);
+    s.kept = (uint32_t*)take((size_t)B * 32 * 4);
+    s.mfirst = (int16_t*)take((size_t)B * 64 * 2);
+    s.mcount = (int32_t*)take((size_t)B * 4);
+    s.src1 = (int16_t*)take((size_t)B * 512 * 2);
+    s.pos = (int16_t*)take((size_t)B * Nsl * 2);
+    s.bytes = off;
+    return s;
+}
+
+}  // namespace
+
+extern "C" int iq_pointconv_forward(const iq_pointconv_weights* w, const float* xyz, float* logits, void* workspace,
+                                    size_t workspace_bytes, int B, int N, iq_stream_t stream) {
+    IQ_REQUIRE(w && xyz && logits, "iq_pointconv_forward: null pointer");
+    IQ_REQUIRE(B >= 0 && N >= 512 && N <= 4096, "iq_pointconv_forward: N=%d not in [512, 4096]", N);
+    IQ_REQUIRE(w->sa[0].nsample == 32 && w->sa[1].nsample == 64, "iq_pointconv_forward: nsample must be 32 / 64");
+    if (B == 0) return IQ_OK;
+    const size_t need = carve_c(nullptr, B, N).bytes;
+    if (!workspace || workspace_bytes < need)
+        return iq::fail(IQ_EWORKSPACE, "iq_pointconv_forward: workspace %zu < %zu bytes", workspace_bytes, need);
+    WsC s = carve_c(workspace, B, N);
+    hipStream_t st = iq::as_stream(stream);
+    iq::ProfileSpan call_span(iq::kSlotCall, st);
+    return run_pointconv(w, xyz, logits, s, B, N, st, nullptr);
+}
+
+extern "C" size_t iq_pointconv_coalitions_workspace_bytes(int B, int nclouds, int N) {
+    if (B < 0 || nclouds < 1 || N < 1) return 0;
+    return iq::align_up(carve_c(nullptr, B, N).bytes, 256) + carve_w(nullptr, B, nclouds, N).bytes;
+}
+
+// Logits of B coalitions given as region bit masks over nclouds source clouds (same call as iq_pointnet2_coalitions): the
+// masked clouds are written into the workspace and run through the forward; when a few source clouds serve many coalitions
+// (nclouds * 8 <= B, N <= 1024) the K-nearest groups of sa1 / sa2 come from the source clouds' sorted neighbour lists.
+extern "C" int iq_pointconv_coalitions(const iq_pointconv_weights* w, const float* clouds, const float* centers,
+                                       const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of, float* logits,
+                                       void* workspace, size_t workspace_bytes, int B, int nclouds, int N, iq_stream_t stream) {
+    IQ_REQUIRE(B >= 0 && nclouds >= 1, "iq_pointconv_coalitions: B=%d nclouds=%d", B, nclouds);
+    IQ_REQUIRE(w && clouds && centers && region_id && (B == 0 || (keep && logits)), "iq_pointconv_coalitions: null pointer");
+    IQ_REQUIRE(N >= 512 && N <= kWalkMaxN, "iq_pointconv_coalitions: N=%d not in [512, %d]", N, kWalkMaxN);
+    IQ_REQUIRE(cloud_of || nclouds == 1 || nclouds == B, "iq_pointconv_coalitions: cloud_of required when 1 < nclouds != B");
+    IQ_REQUIRE(w->sa[0].nsample == 32 && w->sa[1].nsample == 64, "iq_pointconv_coalitions: nsample must be 32 / 64");
+    if (B == 0) return IQ_OK;
+    const size_t base_bytes = iq::align_up(carve_c(nullptr, B, N).bytes, 256);
+    const size_t need = base_bytes + carve_w(nullptr, B, nclouds, N).bytes;
+    if (!workspace || workspace_bytes < need)
+        return iq::fail(IQ_EWORKSPACE, "iq_pointconv_coalitions: workspace %zu < %zu bytes", workspace_bytes, need);
+    WsC s = carve_c(workspace, B, N);
+    WsW t = carve_w(reinterpret_cast<char*>(workspace) + base_bytes, B, nclouds, N);
+    hipStream_t st = iq::as_stream(stream);
+    int rc;
+    iq::ProfileSpan call_span(iq::kSlotCall, st);
+    const int Nsp = (N + 1 + 31) / 32 * 32, Nsl = (N + 1 + 7) / 8 * 8;
+    hipLaunchKernelGGL(pc_coal_prep_kernel, dim3(B), dim3(64), 0, st, region_id, keep, cloud_of, t.kept, t.mfirst, t.mcount, N, nclouds);
+    hipLaunchKernelGGL(pc_mask_kernel, dim3((unsigned)(((size_t)B * N + 255) / 256)), dim3(256), 0, st, clouds, centers, t.kept, cloud_of,
+                       t.X, N, B, nclouds);
+    if ((rc = iq::check_launch("pc_mask_kernel"))) return rc;
+    // the lists for up to 8 source clouds whatever B is: the two ways of forming a group differ in the order of the sum over its
+    // members, and a coalition's logits must not depend on how many others share its launch (5 = 14: pc_knn_kernel)
+    const bool use_walk = (nclouds <= 8 || (long long)nclouds * 8 <= B) && iq::tuning(iq::kTuneExperiment) != 14;
+    PcWalk walk{};
+    if (use_walk) {
+        hipLaunchKernelGGL(sl_rows_kernel, dim3((Nsp + 255) / 256, nclouds), dim3(256), 0, st, clouds, centers, t.xs, t.xxs, N, Nsp);
+        hipLaunchKernelGGL(sl_dist_kernel<1>, dim3(Nsp / 32, nclouds), dim3(64), 0, st, t.xs, t.xxs, t.dmat, Nsp);
+        hipLaunchKernelGGL(sl_sort_kernel, dim3(N + 1, nclouds), dim3(256), 0, st, t.dmat, t.sorted, N, Nsp, Nsl);
+        if ((rc = iq::check_launch("sl_sort_kernel"))) return rc;
+        walk = PcWalk{t.sorted, t.kept, t.mfirst, t.mcount, t.src1, t.pos, cloud_of, nclouds, Nsl, Nsl};
+    }
+    return run_pointconv(w, t.X, logits, s, B, N, st, use_walk ? &walk : nullptr);
 }

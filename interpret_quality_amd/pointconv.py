@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, hip_ops
 from .pointnet2 import fold_conv_bn
 
 SA = [dict(npoint=512, nsample=32, in_channel=3, mlp=[64, 64, 128], bandwidth=0.1),          # models/pointconv.py:403
@@ -92,6 +92,28 @@ class PointConvEngine:
         _lib.check(rc, "iq_pointconv_forward")
         return logits
 
+    def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None):
+        """iq_pointconv_coalitions: clouds (nc,N,3), centers (nc,3), region_id (nc,N) i32, keep (B,) i64 bit masks,
+        cloud_of (B,) i32 or None -> logits (B,C)."""
+        for t, dt, nm in ((clouds, torch.float32, "clouds"), (centers, torch.float32, "centers"), (region_id, torch.int32, "region_id"),
+                          (keep, torch.int64, "keep"), (cloud_of, torch.int32, "cloud_of")):
+            if t is None and nm == "cloud_of":
+                continue
+            if t is None or not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+                raise _lib.IqError("%s must be a contiguous %s GPU tensor" % (nm, dt))
+        nc, n, _ = clouds.shape
+        b = keep.shape[0]
+        need = self.lib.iq_pointconv_coalitions_workspace_bytes(b, nc, n)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        logits = torch.empty((b, self.weights.num_classes), dtype=torch.float32, device=self.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+        rc = self.lib.iq_pointconv_coalitions(ctypes.byref(self.weights.struct), p(clouds), p(centers), p(region_id), p(keep),
+                                              p(cloud_of), p(logits), p(self._ws), self._ws.numel(), b, nc, n,
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "iq_pointconv_coalitions")
+        return logits
+
 
 def _tiny_holder(dims):
     m = nn.Module()
@@ -158,3 +180,34 @@ class PointConvDensityClsSsg(nn.Module):
     def forward(self, xyz):
         """xyz (B,3,N) as in the reference -> logits (B,10)."""
         return self.forward_points(xyz.permute(0, 2, 1).contiguous())
+
+    def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None, num_regions=None, validate=True):
+        """Same call as PointNetCls.coalition_logits: logits of B coalitions given as region bit masks (the masked clouds are
+        written inside the library; sa1 / sa2 groups from the source clouds' sorted neighbour lists, csrc/iq_pointconv.hip).
+        Clouds of other sizes than 512..1024 points go through mask kernel + forward_points in the drivers."""
+        if validate:
+            hip_ops.check_index_range(region_id, 0, int(num_regions) if num_regions else 64, "region_id")
+        eng = self.engine()
+        step = self.max_clouds_per_call
+        nc, b = clouds.shape[0], keep.shape[0]
+        if cloud_of is None and nc not in (1, b):
+            raise _lib.IqError("cloud_of is required when 1 < number of clouds != number of coalitions")
+        if clouds.shape[1] > 1024:   # beyond the library's coalition entry: mask kernel + forward, source cloud by source cloud
+            which = cloud_of if cloud_of is not None else (torch.zeros(b, dtype=torch.int32, device=keep.device) if nc == 1
+                                                          else torch.arange(b, dtype=torch.int32, device=keep.device))
+            out = torch.empty((b, self.output_channels), dtype=torch.float32, device=keep.device)
+            for c in range(nc):
+                sel = torch.nonzero(which == c).flatten()
+                if sel.numel():
+                    x = hip_ops.mask_coalitions(clouds[c].contiguous(), region_id[c].contiguous(), keep[sel].contiguous(),
+                                                centers[c].contiguous())
+                    out[sel] = self.forward_points(x)
+            return out
+        if b <= step:
+            return eng.coalition_logits(clouds, centers, region_id, keep, cloud_of)
+        if cloud_of is None and nc == b:
+            cloud_of = torch.arange(b, dtype=torch.int32, device=keep.device)
+        out = [eng.coalition_logits(clouds, centers, region_id, keep[i:i + step].contiguous(),
+                                    cloud_of[i:i + step].contiguous() if cloud_of is not None else None)
+               for i in range(0, b, step)]
+        return torch.cat(out, dim=0)
