@@ -620,6 +620,80 @@ __global__ __launch_bounds__(64) void pc_walk2_kernel(const int16_t* __restrict_
     }
 }
 
+// ---- sa1 from a pair table -----------------------------------------------------------------------------------------------
+// sa1 has no input features: a member's row after the 3 -> 64 -> 64 -> 128 MLP is a function of (member point, centroid
+// point) only, and both are source points or the centre.  Per source cloud the rows of ALL (N+1)^2 pairs are computed once
+// per call (layer 1 by the grouped kernel's own expression, layers 2 / 3 by the shared dense layer, whose MFMA order over
+// k is the grouped kernel's: the same rows), and a group is 32 table rows contracted with the members' density x WeightNet
+// weights (pc_member_kernel) - no MLP per coalition.  One wave per group: lane l holds channels 2l, 2l+1 against the 16
+// WeightNet outputs (32 accumulators), a member costs one 8-byte load per lane (a coalesced 512-byte row) and 16 scalar
+// weights.  (The sum over the members runs sequentially here and in 4-member MFMA steps in pc_group_kernel: equal up to
+// rounding.)
+__global__ void pc_tab_l1_kernel(const float* __restrict__ xs /*(n1p,8) source points + centre*/, const float* __restrict__ w1x,
+                                 float* __restrict__ h1 /*(n1*n1, 64)*/, int n1) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // (row, channel quad)
+    const size_t rows = (size_t)n1 * n1;
+    if (t >= rows * 16) return;
+    const size_t row = t >> 4;
+    const int c4 = (int)(t & 15);
+    const int q = (int)(row / n1), p = (int)(row - (size_t)q * n1);      // centroid q, member p
+    const float* xp = xs + (size_t)p * 8;
+    const float* xq = xs + (size_t)q * 8;
+    const float v0 = xp[0] - xq[0], v1 = xp[1] - xq[1], v2 = xp[2] - xq[2];
+    f32x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(w1x + (c4 * 4 + e) * 4);
+        const float tt = fmaf(w[2], v2, fmaf(w[1], v1, w[0] * v0)) + w[3];   // pc_group_kernel's stage 0b
+        h[e] = fmaxf(tt, 0.f);
+    }
+    *reinterpret_cast<f32x4*>(h1 + row * 64 + c4 * 4) = h;
+}
+
+__global__ __launch_bounds__(kThreads) void pc_tab_group_kernel(const float* __restrict__ feat /*(nc, n1*n1, 128)*/,
+                                                                const float* __restrict__ msw /*(B,S,32,16)*/,
+                                                                const int16_t* __restrict__ idx /*(B,S,32)*/,
+                                                                const int32_t* __restrict__ fps /*(B,S)*/,
+                                                                const uint32_t* __restrict__ kept /*(B,32)*/,
+                                                                const int32_t* __restrict__ n_unique, const int32_t* __restrict__ cloud_of,
+                                                                float* __restrict__ out /*(B,S,2048)*/, int N, int S, int B, int nclouds) {
+    const int lane = threadIdx.x & 63;
+    const int g = uniform((int)(blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)));   // group = b * S + s
+    if (g >= B * S) return;
+    const int b = g / S, s = g - b * S;
+    if (s >= n_unique[b]) return;                          // duplicate centroids are filled afterwards
+    const int c = cloud_of ? cloud_of[b] : (nclouds == 1 ? 0 : b);
+    const uint32_t* kb = kept + (size_t)b * 32;
+    const int n1 = N + 1;
+    const int pi = fps[g];
+    const int q = (kb[pi >> 5] >> (pi & 31)) & 1u ? pi : N;
+    const float* tab = feat + ((size_t)c * n1 * n1 + (size_t)q * n1) * 128;
+    const int16_t* mem = idx + (size_t)g * 32;
+    const float* sw = msw + (size_t)g * 32 * 16;
+    float acc[2][16];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { acc[0][w] = 0.f; acc[1][w] = 0.f; }
+#pragma unroll 4
+    for (int k = 0; k < 32; ++k) {
+        const int p = mem[k];
+        const int ps = (kb[p >> 5] >> (p & 31)) & 1u ? p : N;
+        const float2 f = *reinterpret_cast<const float2*>(tab + (size_t)ps * 128 + 2 * lane);
+        const float* swk = sw + k * 16;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const float sv = swk[w];                       // wave-uniform: a scalar load
+            acc[0][w] = fmaf(f.x, sv, acc[0][w]);
+            acc[1][w] = fmaf(f.y, sv, acc[1][w]);
+        }
+    }
+    float* o = out + (size_t)g * 2048 + (size_t)(2 * lane) * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4)
+            *reinterpret_cast<f32x4*>(o + i * 16 + w4 * 4) = (f32x4){acc[i][w4 * 4], acc[i][w4 * 4 + 1], acc[i][w4 * 4 + 2], acc[i][w4 * 4 + 3]};
+}
+
 struct WsC {
     float *inv1, *inv2, *inv3;
     int32_t *fps1, *fps2, *nu1;
@@ -723,6 +797,7 @@ struct PcWalk {
     int16_t* pos;              // (B, Npos)
     const int32_t* cloud_of;
     int nclouds, Nsl, Npos;
+    const float* feat_tab;     // (nclouds, (N+1)^2, 128) sa1 pair table, or null
 };
 
 // the network on B materialised clouds xyz (B,N,3)
@@ -747,7 +822,17 @@ int run_pointconv(const iq_pointconv_weights* w, const float* xyz, float* logits
         } else if ((rc = launch_pc_knn<32>(xyz, N, s.nx1, S1, s, s.idx1, B, st, s.nu1))) {
             return rc;
         }
-        if ((rc = launch_pc_group(w->sa[0], xyz, s.nx1, s.idx1, s.inv1, nullptr, 0, s.g1, s, N, S1, 32, B, st, s.nu1))) return rc;
+        if (walk && walk->feat_tab) {   // members' weights as usual, the MLP rows from the pair table
+            const size_t total = (size_t)B * S1 * 32;
+            const TinyNets nets{w->sa[0].densitynet, w->sa[0].weightnet};
+            hipLaunchKernelGGL(pc_member_kernel<32>, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, xyz, s.nx1,
+                               s.idx1, s.inv1, nets, s.mrel, s.msw, N, S1, total, s.nu1);
+            hipLaunchKernelGGL(pc_tab_group_kernel, dim3((unsigned)(((size_t)B * S1 + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0,
+                               st, walk->feat_tab, s.msw, s.idx1, s.fps1, walk->kept, s.nu1, walk->cloud_of, s.g1, N, S1, B, walk->nclouds);
+            if ((rc = iq::check_launch("pc_tab_group_kernel"))) return rc;
+        } else if ((rc = launch_pc_group(w->sa[0], xyz, s.nx1, s.idx1, s.inv1, nullptr, 0, s.g1, s, N, S1, 32, B, st, s.nu1))) {
+            return rc;
+        }
         if ((rc = iq::launch_linear(s.g1, 2048, w->sa[0].linear, s.l1, 128, B * S1, 1, st, nullptr, s.nu1, S1))) return rc;
         hipLaunchKernelGGL(pc_fill_dup_rows_kernel, dim3(S1, B), dim3(64), 0, st, s.l1, S1, 128, s.nu1);
         if ((rc = iq::check_launch("pc_fill_dup_rows_kernel"))) return rc;
@@ -813,8 +898,11 @@ struct WsW {   // coalition extras behind the forward's workspace
     int16_t* mfirst;
     int32_t* mcount;
     int16_t *src1, *pos;
+    float *th1, *th2, *feat;   // pair table of sa1 (nc <= kTabClouds): layer outputs (n1^2, 64) x 2 of ONE cloud, rows (nc, n1^2, 128)
     size_t bytes;
 };
+
+constexpr int kTabClouds = 2;   // the pair table takes 0.54 GB per source cloud (+ 0.54 GB of layer outputs while it is built)
 
 WsW carve_w(void* base, int B, int nc, int N) {
     WsW s{};
@@ -835,6 +923,12 @@ WsW carve_w(void* base, int B, int nc, int N) {
     s.mcount = (int32_t*)take((size_t)B * 4);
     s.src1 = (int16_t*)take((size_t)B * 512 * 2);
     s.pos = (int16_t*)take((size_t)B * Nsl * 2);
+    if (nc <= kTabClouds) {
+        const size_t rows = (size_t)(N + 1) * (N + 1);
+        s.th1 = (float*)take(rows * 64 * 4);
+        s.th2 = (float*)take(rows * 64 * 4);
+        s.feat = (float*)take((size_t)nc * rows * 128 * 4);
+    }
     s.bytes = off;
     return s;
 }
@@ -896,7 +990,22 @@ extern "C" int iq_pointconv_coalitions(const iq_pointconv_weights* w, const floa
         hipLaunchKernelGGL(sl_dist_kernel<1>, dim3(Nsp / 32, nclouds), dim3(64), 0, st, t.xs, t.xxs, t.dmat, Nsp);
         hipLaunchKernelGGL(sl_sort_kernel, dim3(N + 1, nclouds), dim3(256), 0, st, t.dmat, t.sorted, N, Nsp, Nsl);
         if ((rc = iq::check_launch("sl_sort_kernel"))) return rc;
-        walk = PcWalk{t.sorted, t.kept, t.mfirst, t.mcount, t.src1, t.pos, cloud_of, nclouds, Nsl, Nsl};
+        walk = PcWalk{t.sorted, t.kept, t.mfirst, t.mcount, t.src1, t.pos, cloud_of, nclouds, Nsl, Nsl, nullptr};
+        const iq_pointconv_sa& sa = w->sa[0];
+        // (whatever B is: a coalition's logits must not depend on how many others share its launch)
+        if (nclouds <= kTabClouds && sa.l2.cin == 64 && sa.l2.cout == 64 && sa.l3.cout == 128 &&
+            iq::tuning(iq::kTuneExperiment) != 15) {   // 5 = 15: the grouped MLP (A/B runs, tests)
+            const int n1 = N + 1;
+            const size_t rows = (size_t)n1 * n1;
+            for (int c = 0; c < nclouds; ++c) {
+                hipLaunchKernelGGL(pc_tab_l1_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, t.xs + (size_t)c * Nsp * 8,
+                                   sa.w1x, t.th1, n1);
+                if ((rc = iq::check_launch("pc_tab_l1_kernel"))) return rc;
+                if ((rc = iq::launch_linear(t.th1, 64, sa.l2, t.th2, 64, (int)rows, 1, st))) return rc;
+                if ((rc = iq::launch_linear(t.th2, 64, sa.l3, t.feat + (size_t)c * rows * 128, 128, (int)rows, 1, st))) return rc;
+            }
+            walk.feat_tab = t.feat;
+        }
     }
     return run_pointconv(w, t.X, logits, s, B, N, st, use_walk ? &walk : nullptr);
 }

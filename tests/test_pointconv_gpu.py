@@ -70,7 +70,8 @@ def test_pointconv_raw_clouds_vs_oracle(model):
 
 def test_coalitions_from_source_lists_equal_the_forward_on_masked_clouds(model):
     """iq_pointconv_coalitions (masked clouds written inside; sa1 / sa2 groups from the source clouds' sorted neighbour
-    lists) against iq_pointconv_forward on the materialised masked clouds (pc_knn_kernel): the same groups up to ties
+    lists, sa1's MLP rows from the per-cloud pair table) against iq_pointconv_forward on the materialised masked clouds
+    (pc_knn_kernel, grouped MLP): the same groups up to ties
     and the choice among interchangeable masked points, so the logits agree to summation-order rounding - and the
     kNN-kernel path of the same entry point (tuning key 5 = 14) does too.  Nothing / few / many / everything masked, two
     source clouds; 40 coalitions so that the lists are used (clouds * 8 <= coalitions)."""
@@ -94,6 +95,12 @@ def test_coalitions_from_source_lists_equal_the_forward_on_masked_clouds(model):
              for k, c in zip(keep, cloud_of)]
     want = model.forward_points(torch.stack(dense))
     assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 2e-5
+    lib.iq_set_tuning(5, 15)       # lists, but sa1's rows from the grouped MLP instead of the pair table
+    try:
+        grouped = model.coalition_logits(clouds, centers, rid.to(d), keep_t, co_t, num_regions=32)
+    finally:
+        lib.iq_set_tuning(5, 0)
+    assert rel_err(got.cpu().numpy(), grouped.cpu().numpy()) < 2e-5 and rel_err(grouped.cpu().numpy(), want.cpu().numpy()) < 2e-5
     lib.iq_set_tuning(5, 14)
     try:
         knn = model.coalition_logits(clouds, centers, rid.to(d), keep_t, co_t, num_regions=32)
