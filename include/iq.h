@@ -358,7 +358,10 @@ int iq_pointconv_forward(const iq_pointconv_weights* w /*host struct of device p
  * (nclouds <= 8, or nclouds * 8 <= B) the K-nearest groups of sa1 and sa2 (models/pointconv.py:103-114) are read off per-source-cloud
  * sorted neighbour lists, built once per call with the kNN kernel's own distance expression: in xyz space neither the
  * distance between two points nor the centre depends on the coalition, only the candidate set does (the same point
- * sets as the kNN kernel up to ties; masked points are interchangeable).  512 <= N <= 1024.  Asynchronous on `stream`. */
+ * sets as the kNN kernel up to ties; masked points are interchangeable).  With at most two source clouds sa1's MLP rows
+ * - functions of (member point, centroid point) only, sa1 having no input features - come from a table of all (N+1)^2
+ * pairs built once per call (1.1 GB of workspace per source cloud) and a group is 32 table rows contracted with the
+ * members' density x WeightNet weights.  512 <= N <= 1024.  Asynchronous on `stream`. */
 size_t iq_pointconv_coalitions_workspace_bytes(int B, int nclouds, int N);
 int iq_pointconv_coalitions(const iq_pointconv_weights* w, const float* clouds, const float* centers,
                             const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of, float* logits,
