@@ -673,10 +673,16 @@ __global__ __launch_bounds__(kThreads) void pc_tab_group_kernel(const float* __r
     float acc[2][16];
 #pragma unroll
     for (int w = 0; w < 16; ++w) { acc[0][w] = 0.f; acc[1][w] = 0.f; }
-#pragma unroll 4
+    // lane k resolves member k to its table row; the loop then reads the row numbers back as scalars (v_readlane), so the 32
+    // row loads do not depend on one another and are all in flight
+    int myrow = 0;
+    if (lane < 32) {
+        const int p = mem[lane];
+        myrow = (kb[p >> 5] >> (p & 31)) & 1u ? p : N;
+    }
+#pragma unroll
     for (int k = 0; k < 32; ++k) {
-        const int p = mem[k];
-        const int ps = (kb[p >> 5] >> (p & 31)) & 1u ? p : N;
+        const int ps = __builtin_amdgcn_readlane(myrow, k);
         const float2 f = *reinterpret_cast<const float2*>(tab + (size_t)ps * 128 + 2 * lane);
         const float* swk = sw + k * 16;
 #pragma unroll
