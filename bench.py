@@ -104,7 +104,7 @@ def gpu_eager_baseline(num_regions):
     """SURVEY §8d baseline (ii): the reference's Shapley loop restated with stock PyTorch-ROCm eager ops on this GPU
     (index-put masking storm, one batched forward, one host sync per permutation; config.py's bs = 50 for PointNet)."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("iq_eager_gpu_baseline", os.path.join(REPO, "tests", "eager_gpu_baseline.py"))
+    spec = importlib.util.spec_from_file_location("iq_eager_gpu_baseline", os.path.join(REPO, "oracle", "eager_gpu_baseline.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod.run_eager(perms=100, bs=50, regions=num_regions)

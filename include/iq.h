@@ -82,6 +82,27 @@ int iq_check_index_range(const int32_t* idx, size_t count, int lo, int hi, uint3
                          iq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Coalition sampling (on the device)
+ * ------------------------------------------------------------------------------------------- */
+
+/* final_shapley_value.py:59-72 (generate_all_orders): S permutations of 0..R-1 drawn from NumPy's legacy global
+ * generator, i.e. MT19937 + RandomState.shuffle's back-to-front Fisher-Yates with masked rejection sampling, CONTINUED
+ * ON THE DEVICE: mt_state is the generator's state as np.random.get_state() returns it - 624 key words followed by the
+ * position (625 uint32, device memory) - and is advanced in place, so permutations and every later host draw (after
+ * np.random.set_state with the returned words) are bit-identical to the reference's stream for the same seed.
+ * One workgroup (the stream is sequential); ~0.2 ms for 1000 permutations of 32 regions. */
+int iq_sample_permutations(uint32_t* mt_state /*625*/, int32_t* orders /*S,R*/, int S, int R, iq_stream_t stream);
+
+/* tools/final_common.py:56-60 as bit masks: keep[s*(R+1) + i] = the regions orders[s][0..i-1]
+ * (row 0 = nothing kept = all-centre cloud, row R = the unmodified cloud). */
+int iq_prefix_keep_masks(const int32_t* orders /*S,R*/, uint64_t* keep /*S*(R+1)*/, int S, int R, iq_stream_t stream);
+
+/* final_point_binary_interaction_logits.py:45-52 as bit masks: for pair p = (i, j) and its context c = contexts[p][c][0..m-1]
+ * (np.in1d(region_id, context)): keep[4(pC + c) + 0..3] = S+{i,j}, S+{i}, S+{j}, S.  m = 0: the empty context. */
+int iq_context_keep_masks(const int32_t* pairs /*P,2*/, const int32_t* contexts /*P,C,m*/, uint64_t* keep /*4PC*/,
+                          int P, int C, int m, iq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Reward and reductions
  * ------------------------------------------------------------------------------------------- */
 
@@ -285,7 +306,11 @@ int iq_pointnet2_coalitions(const iq_pointnet2_weights* w, const float* clouds, 
 
 /* models/dgcnn.py:12-18 (knn): the k = 20 largest of -|x_i|^2 - (-2 x_i.x_j) - |x_j|^2 per row, self
  * included, as an (unordered) index set.  x (B,N,C) row-major with C in {3, 64, 128}; idx (B,N,20)
- * int32; tmp = scratch of at least B*N*80 + 16*B + 4096 bytes. */
+ * int32; tmp = scratch of at least B*N*84 + 16*B + 8192 bytes.
+ * Feature-space graphs (C = 64, 128): where the float32 expanded form cannot separate the 20th from the 21st nearest
+ * (gap below 1e-5 of the magnitude of the summed terms: rounding noise decides for the reference's float32 path too), the
+ * query is re-ranked by -sum (x_i - x_j)^2 accumulated in float64, i.e. the order the reference finds in float64
+ * (csrc/iq_dgcnn.hip: knn_refine_kernel; iq_set_tuning(5, 13) keeps the float32 ranking, for A/B runs). */
 int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes, int B, int N, int C, int k,
            iq_stream_t stream);
 

@@ -79,6 +79,9 @@ SIGNATURES = {
     "iq_mask_interaction": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "iq_mask_coalitions": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "iq_check_index_range": (_I, [_P, _SZ, _I, _I, _P, _P]),
+    "iq_sample_permutations": (_I, [_P, _P, _I, _I, _P]),
+    "iq_prefix_keep_masks": (_I, [_P, _P, _I, _I, _P]),
+    "iq_context_keep_masks": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "iq_reward": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "iq_shapley_accum": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P]),
     "iq_interaction_reduce": (_I, [_P, _P, _I, _P]),

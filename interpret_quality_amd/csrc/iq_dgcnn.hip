@@ -29,6 +29,8 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kK = 20;  // K_FOR_DGCNN, tools/final_util.py:19
+constexpr float kNearTie = 1e-5f;  // a boundary gap below this fraction of the summed terms' magnitude is re-ranked exactly
+constexpr int kRefineMaxRows = 2048;  // rows of one cloud whose exact distances fit the refinement kernel's LDS
 constexpr int kRoundLanes = 32;  // an insert round of the kNN selection runs once this many lanes have a queued candidate
 
 // ---- pad xyz (B,N,3) -> (B,N,8) -------------------------------------------------------------------
@@ -284,10 +286,16 @@ __global__ void knn_dbg_fetch_kernel(unsigned long long* dst) {
 // between waves, so there is no barrier in the loop and waves drift freely past each other's selection rounds.  (The
 // first version staged key tiles through LDS for 4 waves: with a barrier per 32-key tile and 2 workgroups per CU the
 // MFMA + staging skeleton alone took 53 of the 91 ms of DGCNN's kNN.)
-template <int C>
+// REFINE (the feature-space graphs, C = 64 / 128): the list holds kK + 1 entries.  The 21st nearest tells how well the fp32
+// expanded-form distances separate the neighbourhood from the rest: a query whose boundary gap (or, in a coalition's compact
+// layout, the gap between the weighted centre row and a row next to it) is below kNearTie of the magnitude of the summed terms
+// is FLAGGED (near_tie[row] = 1) and knn_refine_kernel re-ranks it in exact arithmetic.
+template <int C, bool REFINE>
 __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ xx,
-                                                 int16_t* __restrict__ idx, Ragged rg, int B, int tiles_per_cloud, int dbg) {
+                                                 int16_t* __restrict__ idx, uint8_t* __restrict__ near_tie, Ragged rg, int B,
+                                                 int tiles_per_cloud, int dbg) {
     constexpr int KB = C / 8;
+    constexpr int KL = REFINE ? kK + 1 : kK;   // list length
     __shared__ double queue[17 * 64];                              // 16 slots per lane + the overflow slot of push()
     __shared__ __attribute__((aligned(16))) float kxs[2 * 64];   // |key|^2 of two pairs of key tiles (double-buffered)
     const int lane = threadIdx.x;
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
         qf[kb] = *reinterpret_cast<const f32x4*>(xb + (size_t)(q0 + fl) * ldx + 8 * kb + 4 * fh);
     const float xxq = xxb[q0 + fl];
 
-    QueuedTopK<kK, 16> top;
+    QueuedTopK<KL, 16> top;
     top.init(queue);
     const int ntiles = N / 32;
     // Key fragments by raw buffer loads (iq_mfma.h: WBuf): resource on this cloud's rows, ONE loop-invariant per-lane offset
@@ -411,13 +419,32 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
         atomicAdd(&g_knn_dbg[2], 1ull);
     }
     top.merge_halves();  // each half-wave saw half of the keys of every tile
+    const int centre = rg.nkept[b], mult = rg.ncopy[b];
+    bool flagged = false;
+    float margin = 0.f;
+    if constexpr (REFINE) {
+        // the smallest of the 21 (the 21st nearest) goes to slot kK; slots 0..kK-1 are the (unordered) approximate top-20
+        double v21 = top.v[0];
+#pragma unroll
+        for (int q = 1; q <= kK; ++q) v21 = fmin(v21, top.v[q]);
+        const double last = top.v[kK];
+#pragma unroll
+        for (int q = 0; q < kK; ++q) top.v[q] = top.v[q] == v21 ? last : top.v[q];
+        top.v[kK] = v21;
+        double t20 = top.v[0];
+#pragma unroll
+        for (int q = 1; q < kK; ++q) t20 = fmin(t20, top.v[q]);
+        // magnitude of the terms the expanded form sums: |q|^2 + |k|^2 + 2 |q.k| <= 2 (|q|^2 + |k|^2), |k|^2 <= 2 (|q|^2 + |q - k|^2)
+        margin = kNearTie * 2.f * (xxq + fmaxf(-(float)t20, 0.f));
+        const bool live_q = q0 + fl < centre + (mult > 0 ? 1 : 0);
+        flagged = live_q && (float)(t20 - v21) < margin;   // fewer than 21 live rows: v21 = -inf, never flagged by this rule
+    }
     // The masked points of a coalition are ONE row (index nkept) that stands for `mult` = min(M, 20) identical points.  The
     // list holds the 20 nearest DISTINCT rows; of those, a row farther than the centre with `rank` rows ahead of it sits
     // at position rank - 1 + mult of the reference's top-k, so it is a neighbour only if rank <= 20 - mult.  Rows that
     // fall out are replaced by the centre (a duplicate neighbour does not change a max).  mult == 20, the usual case:
     // every row behind the centre falls out.  Rows filled from the dead padding (fewer than 20 live rows) are behind the
     // centre and fall out the same way.
-    const int centre = rg.nkept[b], mult = rg.ncopy[b];
     bool drop[kK];
 #pragma unroll
     for (int q = 0; q < kK; ++q) drop[q] = false;
@@ -427,6 +454,16 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
 #pragma unroll
         for (int q = 0; q < kK; ++q)
             if (top.index(q) == centre) { vc = top.v[q]; has = true; }
+        if constexpr (REFINE) {
+            // which side of the weighted centre row a row lies on decides whether it is a neighbour at all
+            if (has) {
+                bool close = false;
+#pragma unroll
+                for (int q = 0; q < kK; ++q) close = close || (top.index(q) != centre && fabsf((float)(top.v[q] - vc)) < margin);
+                const bool live_q = q0 + fl < centre + 1;
+                flagged = (mult >= kK ? false : flagged) || (live_q && close);
+            }
+        }
         if (mult >= kK) {
 #pragma unroll
             for (int q = 0; q < kK; ++q) drop[q] = has && top.v[q] < vc;
@@ -440,6 +477,7 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
             }
         }
     }
+    if (REFINE && fh == 0) near_tie[(size_t)base + q0 + fl] = flagged ? 1 : 0;
     if (fh == 0) {
         // dbg & 8: the consumer is edge_fused_kernel, which wants the byte address of the row's (swizzled) first float4 in
         // its LDS slice instead of the row index: row * 64 + ((row >> 2) & 3) * 16 (< 65536 for rows < 1024)
@@ -450,6 +488,91 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
             const int row = drop[q] ? centre : top.index(q);
             o[q] = (int16_t)(as_addr ? (row << 6) | (((row >> 2) & 3) << 4) : row);
         }
+    }
+}
+
+// ---- exact re-ranking of the queries knn_kernel flagged ---------------------------------------------------------------------
+// -|q|^2 + 2 q.k - |k|^2 in float32 carries a rounding error of ~1e-6 of |q|^2 + |k|^2, far above the distance itself for
+// near neighbours; where the 20th and 21st nearest are closer than that, which of them is a neighbour is decided by
+// rounding noise - for the reference's float32 path exactly as for this one, and a flipped neighbour moves a DGCNN logit
+// at the 1e-3 level.  Flagged queries are therefore ranked again by -sum_c (q_c - k_c)^2 with the differences in float32
+// (relative error 6e-8 of the DIFFERENCE) squared and summed in float64: the order the reference's float64 run finds,
+// except where two distances agree to ~1e-7 of themselves.  One wave per group of 64 consecutive rows; the few flagged
+// rows of the group are handled one after the other by the whole wave: lane l owns rows l, l + 64, ... of the cloud.
+// Same weighted selection as knn_kernel's epilogue (the centre row of a compact coalition counts mult times).
+template <int C>
+__global__ __launch_bounds__(64) void knn_refine_kernel(const float* __restrict__ x, int ldx, const uint8_t* __restrict__ near_tie,
+                                                        int16_t* __restrict__ idx, Ragged rg, int B, int as_addr) {
+    __shared__ __attribute__((aligned(16))) float qs[C];
+    __shared__ double dist[kRefineMaxRows];
+    const int lane = threadIdx.x;
+    const int rows = rg.roff[B];
+    const int r0 = blockIdx.x * 64;
+    if (r0 >= rows) return;
+    unsigned long long todo = __ballot(r0 + lane < rows && near_tie[r0 + lane] != 0);
+    while (todo) {
+        const int bit = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int row = r0 + bit;
+        const int b = rg.row_cloud[row];
+        const int base = rg.roff[b], centre = rg.nkept[b], mult = rg.ncopy[b];
+        const int live = centre + (mult > 0 ? 1 : 0);
+        if (live > kRefineMaxRows) continue;   // (wave-uniform) larger clouds keep the float32 ranking
+        const float* xb = x + (size_t)base * ldx;
+        if (lane < C / 4) reinterpret_cast<f32x4*>(qs)[lane] = *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + 4 * lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int j = lane; j < live; j += 64) {
+            const f32x4* kr = reinterpret_cast<const f32x4*>(xb + (size_t)j * ldx);
+            double acc = 0.0;
+#pragma unroll 4
+            for (int c4 = 0; c4 < C / 4; ++c4) {
+                const f32x4 kv = kr[c4], qv = reinterpret_cast<const f32x4*>(qs)[c4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double df = (double)(qv[e] - kv[e]);
+                    acc = __builtin_fma(df, df, acc);
+                }
+            }
+            dist[j] = -acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // best first: the next row in order of (distance, then index) until the neighbourhood holds kK points
+        int mine = centre, n_out = 0, pos = 0;   // lane n holds the n-th neighbour; pos = points taken so far (the centre counts mult)
+        while (pos < kK && n_out < kK) {
+            double bv = -INFINITY;
+            int bj = 0x7fffffff;
+            for (int j = lane; j < live; j += 64) {
+                const double d = dist[j];
+                if (d > bv) { bv = d; bj = j; }   // ascending j: the first of equal values stays
+            }
+            double m = bv;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const long long mb = __double_as_longlong(m);
+                const int lo = __shfl_xor((int)(mb & 0xffffffffll), o), hi = __shfl_xor((int)(mb >> 32), o);
+                m = fmax(m, __longlong_as_double(((long long)hi << 32) | (unsigned int)lo));
+            }
+            if (!(m > -INFINITY)) break;          // the cloud has fewer live rows than slots: the rest stays the centre
+            int cand = bv == m ? bj : 0x7fffffff;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+            if ((cand & 63) == lane) dist[cand] = -INFINITY;
+            if (lane == n_out) mine = cand;
+            ++n_out;
+            pos += (cand == centre && mult > 0) ? mult : 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (lane < kK) {
+            const int r = lane < n_out ? mine : centre;
+            idx[(size_t)row * kK + lane] = (int16_t)(as_addr ? (r << 6) | (((r >> 2) & 3) << 4) : r);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -815,16 +938,25 @@ __global__ __launch_bounds__(kThreads) void pool_reduce_kernel(const float* __re
     out[(size_t)b * 2 * C + C + c] = s / (float)N;
 }
 
-// slice_addr: write the neighbours as LDS addresses for edge_fused_kernel (rows < 1024) instead of row indices
-int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, int B, int N, const Ragged& rg,
+// slice_addr: write the neighbours as LDS addresses for edge_fused_kernel (rows < 1024) instead of row indices.
+// near_tie: one byte per row (rows = upper bound of the row count), scratch of the exact re-ranking (C = 64 / 128).
+int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, uint8_t* near_tie, int B, int N, int rows, const Ragged& rg,
                hipStream_t st, bool slice_addr = false) {
     const int tiles = (N + 31) / 32;
     dim3 grid((unsigned)((B + 7) / 8 * 8 * tiles));
     const int dbg = (iq::tuning(iq::kTuneKnnDebug) & 7) | (slice_addr ? 8 : 0);
-    if (C == 8) hipLaunchKernelGGL(knn_kernel<8>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, dbg);
-    else if (C == 64) hipLaunchKernelGGL(knn_kernel<64>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, dbg);
-    else if (C == 128) hipLaunchKernelGGL(knn_kernel<128>, grid, dim3(64), 0, st, x, ldx, xx, idx, rg, B, tiles, dbg);
-    else return iq::fail(IQ_EUNSUPPORTED, "knn: C=%d has no kernel instantiation (8, 64, 128)", C);
+    const bool refine = iq::tuning(iq::kTuneExperiment) != 13;   // 13: float32 ranking only (A/B and tests)
+    const dim3 rgrid((unsigned)((rows + 63) / 64));
+    if (C == 8) hipLaunchKernelGGL((knn_kernel<8, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
+    else if (C == 64 && !refine) hipLaunchKernelGGL((knn_kernel<64, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
+    else if (C == 128 && !refine) hipLaunchKernelGGL((knn_kernel<128, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
+    else if (C == 64) {
+        hipLaunchKernelGGL((knn_kernel<64, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
+        hipLaunchKernelGGL(knn_refine_kernel<64>, rgrid, dim3(64), 0, st, x, ldx, near_tie, idx, rg, B, slice_addr ? 1 : 0);
+    } else if (C == 128) {
+        hipLaunchKernelGGL((knn_kernel<128, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
+        hipLaunchKernelGGL(knn_refine_kernel<128>, rgrid, dim3(64), 0, st, x, ldx, near_tie, idx, rg, B, slice_addr ? 1 : 0);
+    } else return iq::fail(IQ_EUNSUPPORTED, "knn: C=%d has no kernel instantiation (8, 64, 128)", C);
     return iq::check_launch("knn_kernel");
 }
 
@@ -834,6 +966,7 @@ struct WsD {
     float* pq;      // (B,N,512)
     float* xx;      // (B,N)
     int16_t* idx;   // (B,N,20)
+    uint8_t* near_tie;  // (B,N) queries whose neighbourhood boundary the float32 distances cannot decide
     float* h;       // (B*N/32, 2, 1024) per-tile max / weighted sum of conv5
     float *g, *f1, *f2;
     int32_t *roff, *nkept, *ncopy, *dpad, *row_cloud;  // ragged layout
@@ -855,6 +988,7 @@ WsD carve_d(void* base, int B, int N) {
     s.pq = (float*)take(r * 512 * 4);
     s.xx = (float*)take(r * 4);
     s.idx = (int16_t*)take(r * kK * 2);
+    s.near_tie = (uint8_t*)take(r);
     s.h = (float*)take(r * 64 * 4);  // pooling partials of conv5: (rows/32, 2, 1024)
     s.g = (float*)take((size_t)B * 2048 * 4);
     s.f1 = (float*)take((size_t)B * 512 * 4);
@@ -881,7 +1015,7 @@ extern "C" size_t iq_dgcnn_workspace_bytes(int B, int N) {
     return carve_d(nullptr, B, N).bytes;
 }
 
-// Op-level kNN for tests: x (B,N,C) row-major, C in {3, 64, 128}; idx (B,N,20) int32; tmp >= B*N*80 + 16*B + 4096 bytes.
+// Op-level kNN for tests: x (B,N,C) row-major, C in {3, 64, 128}; idx (B,N,20) int32; tmp >= B*N*84 + 16*B + 8192 bytes.
 extern "C" int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes, int B, int N, int C, int k,
                       iq_stream_t stream) {
     IQ_REQUIRE(x && idx && tmp, "iq_knn: null pointer");
@@ -889,7 +1023,7 @@ extern "C" int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes,
     IQ_REQUIRE(B >= 1 && N >= 32 && N % 32 == 0 && N <= 32767, "iq_knn: N=%d must be a multiple of 32", N);
     IQ_REQUIRE(C == 3 || C == 64 || C == 128, "iq_knn: C=%d unsupported", C);
     const size_t r = (size_t)B * N;
-    IQ_REQUIRE(tmp_bytes >= r * 80 + (size_t)B * 16 + 4096, "iq_knn: tmp too small");
+    IQ_REQUIRE(tmp_bytes >= r * 84 + (size_t)B * 16 + 8192, "iq_knn: tmp too small");
     hipStream_t st = iq::as_stream(stream);
     char* p = reinterpret_cast<char*>(tmp);
     size_t off = 0;
@@ -897,6 +1031,7 @@ extern "C" int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes,
     float* x0 = reinterpret_cast<float*>(take(r * 8 * 4));
     float* xx = reinterpret_cast<float*>(take(r * 4));
     int16_t* i16 = reinterpret_cast<int16_t*>(take(r * kK * 2));
+    uint8_t* near_tie = reinterpret_cast<uint8_t*>(take(r));
     int32_t* row_cloud = reinterpret_cast<int32_t*>(take(r * 4));
     int32_t* roff = reinterpret_cast<int32_t*>(take((size_t)(B + 1) * 4));
     int32_t* nkept = reinterpret_cast<int32_t*>(take((size_t)B * 4));
@@ -911,7 +1046,7 @@ extern "C" int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes,
         src = x0; ld = 8; cpad = 8;
     }
     hipLaunchKernelGGL(rownorm_kernel, dim3((r + 63) / 64), dim3(kThreads), 0, st, src, ld, C, xx, rg, B);
-    int rc = launch_knn(src, ld, cpad, xx, i16, B, N, rg, st);
+    int rc = launch_knn(src, ld, cpad, xx, i16, near_tie, B, N, (int)r, rg, st);
     if (rc) return rc;
     hipLaunchKernelGGL(widen_idx_kernel, dim3((r * kK + 255) / 256), dim3(256), 0, st, i16, idx, r * kK);
     if (iq::tuning(iq::kTuneKnnDebug) == 3)  // diagnostic: selection statistics into the first 24 bytes of tmp
@@ -969,7 +1104,7 @@ int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, i
         } else if (l == 0 || !fixed_graph) {
             iq::ProfileSpan span(iq::kSlotPrepool, st);
             hipLaunchKernelGGL(rownorm_kernel, dim3((rows + 63) / 64), dim3(kThreads), 0, st, src, ld, creal, s.xx, rg, B);
-            if ((rc = launch_knn(src, ld, cin, s.xx, s.idx, B, N, rg, st, fused))) return rc;
+            if ((rc = launch_knn(src, ld, cin, s.xx, s.idx, s.near_tie, B, N, rows, rg, st, fused))) return rc;
         }
         {
             iq::ProfileSpan span(iq::kSlotFstn, st);

@@ -13,7 +13,7 @@
 //   L2  (MFMA)     64->128  conv2+bn+relu                                    -> LDS act2
 //   L3  (MFMA)     128->1024 conv3+bn(+relu), column max over rows           -> registers
 // v_mfma_f32_32x32x2_f32 throughout (exact fp32 fma chains).  A operands come from LDS
-// (XOR-swizzled, conflict-free ds_read_b128), B operands (weights) stream from L2 in a
+// (row stride padded by 4 floats: conflict-free ds_read_b128), B operands (weights) stream from L2 in a
 // pre-packed fragment order (1 KiB contiguous per wave-load).  LDS = 52 KB -> 3 workgroups/CU.
 #include <algorithm>
 

@@ -64,9 +64,18 @@ struct QueuedTopK {
     // used (own and partner's K-th, the two medians, the two quartile crossings).  Against each lane's own K-th value this
     // cuts the sorted inserts by a quarter (68 -> 50 per lane at K = 20, n = 544).
     __device__ __forceinline__ float union_threshold() const {
-        const float a1 = (float)v[K / 4 - 1], a2 = (float)v[K / 2 - 1], a3 = (float)v[3 * K / 4 - 1], a4 = thr;
+        // a_i of one list and b_j of the other with (i + 1) + (j + 1) >= K, i.e. i + j = K - 2 (0-based)
+        constexpr int i1 = K / 4 - 1, j1 = K - 2 - i1, i2 = K / 2 - 1, j2 = K - 2 - i2;
+        const float a1 = (float)v[i1], a3 = (float)v[j1], a2 = (float)v[i2], a4 = thr;
         const float b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32), b3 = __shfl_xor(a3, 32), b4 = __shfl_xor(a4, 32);
-        return fmaxf(fmaxf(a4, b4), fmaxf(fminf(a2, b2), fmaxf(fminf(a1, b3), fminf(a3, b1))));
+        float mid;
+        if (i2 == j2) {
+            mid = fminf(a2, b2);
+        } else {   // odd K: the two median crossings differ
+            const float a2b = (float)v[j2], b2b = __shfl_xor(a2b, 32);
+            mid = fmaxf(fminf(a2, b2b), fminf(a2b, b2));
+        }
+        return fmaxf(fmaxf(a4, b4), fmaxf(mid, fmaxf(fminf(a1, b3), fminf(a3, b1))));
     }
     // A queued candidate is the raw pair {key index, fp32 distance} (8 bytes); it becomes the packed double when it is
     // popped (one conversion per round instead of one per candidate).  push() is branch-free: the pair is always written

@@ -66,58 +66,61 @@ def farthest_point_sample_np(point, npoint, device=None):
     return idx[0].cpu().numpy().astype(np.int64)
 
 
+def _synset_table(root, class_choice=None):
+    """synsetoffset2category.txt -> [(category name, synset id)] in file order, restricted to ``class_choice``."""
+    rows = [line.split()[:2] for line in _read_lines(os.path.join(root, "synsetoffset2category.txt")) if line.strip()]
+    return [(name, synset) for name, synset in rows if class_choice is None or name in class_choice]
+
+
+def _selected_scans(root, table):
+    """The scans of misc/shapenet_train_selected.json as (category name, .pts path, .seg path), ordered by category in
+    the order of ``table`` and, inside a category, in list order - the item order of final_data_shapley.py:130-139."""
+    rank = {synset: k for k, (_, synset) in enumerate(table)}
+    with open(os.path.join("misc", DATA_SHAPENET_SHAPLEY_TEST)) as f:
+        entries = [e.split("/")[1:3] for e in json.load(f)]
+    entries = [(synset, uuid) for synset, uuid in entries if synset in rank]
+    entries.sort(key=lambda e: rank[e[0]])                                   # stable: list order inside a category
+    return [(table[rank[synset]][0], os.path.join(root, synset, "points", uuid + ".pts"),
+             os.path.join(root, synset, "points_label", uuid + ".seg")) for synset, uuid in entries]
+
+
+def normalise_scan(points):
+    """Centre on the mean and scale to max-norm 1 in float32 (final_data_shapley.py:155-157)."""
+    points = points - points.mean(axis=0, keepdims=True)
+    return points / np.sqrt((points ** 2).sum(axis=1)).max()
+
+
 class ShapeNetDataset_Shapley_test(Dataset):
-    """final_data_shapley.py:95-179.  Items: (point_set (npoints,3) f32 tensor, cls 0-d int64 tensor) or,
-    with classification=False, (point_set, seg (npoints,) int64)."""
+    """final_data_shapley.py:95-179.  Items: (point_set (npoints,3) f32 tensor, cls 0-d int64 tensor) or, with
+    classification=False, (point_set, seg (npoints,) int64).  Public attributes as in the reference: ``cat``
+    (name -> synset), ``id2cat``, ``datapath`` [(name, pts, seg)], ``classes`` (name -> label by sorted name),
+    ``seg_classes`` / ``num_seg_classes`` (when misc/num_seg_classes.txt exists)."""
 
     def __init__(self, opt, root="./data/shapenetcore_partanno_segmentation_benchmark_v0", npoints=2500,
                  classification=True, class_choice=None, split="train"):
         self.npoints, self.opt, self.root, self.split, self.classification = npoints, opt, root, split, classification
-        self.cat = {}
-        with open(os.path.join(self.root, "synsetoffset2category.txt")) as f:
-            for line in f:
-                ls = line.strip().split()
-                self.cat[ls[0]] = ls[1]
-        if class_choice is not None:
-            self.cat = {k: v for k, v in self.cat.items() if k in class_choice}
-        self.id2cat = {v: k for k, v in self.cat.items()}
-        self.meta = {item: [] for item in self.cat}
-        with open(os.path.join("misc", DATA_SHAPENET_SHAPLEY_TEST)) as f:
-            filelist = json.load(f)
-        for file in filelist:
-            _, category, uuid = file.split("/")
-            if category in self.cat.values():
-                self.meta[self.id2cat[category]].append((os.path.join(self.root, category, "points", uuid + ".pts"),
-                                                         os.path.join(self.root, category, "points_label", uuid + ".seg")))
-        # grouped by category in the order of synsetoffset2category.txt, as the reference's dict iteration does
-        self.datapath = [(item, fn[0], fn[1]) for item in self.cat for fn in self.meta[item]]
-        self.classes = dict(zip(sorted(self.cat), range(len(self.cat))))
-        self.seg_classes = {}
+        table = _synset_table(root, class_choice)
+        self.cat = dict(table)
+        self.id2cat = {synset: name for name, synset in table}
+        self.datapath = _selected_scans(root, table)
+        self.meta = {name: [(p, g) for n, p, g in self.datapath if n == name] for name, _ in table}
+        self.classes = {name: label for label, name in enumerate(sorted(self.cat))}
         seg_file = os.path.join("misc", "num_seg_classes.txt")
-        if os.path.exists(seg_file):
-            with open(seg_file) as f:
-                for line in f:
-                    ls = line.strip().split()
-                    self.seg_classes[ls[0]] = int(ls[1])
-        self.num_seg_classes = self.seg_classes.get(next(iter(self.cat), None))
+        self.seg_classes = ({ls[0]: int(ls[1]) for ls in (line.split() for line in _read_lines(seg_file)) if len(ls) >= 2}
+                            if os.path.exists(seg_file) else {})
+        self.num_seg_classes = self.seg_classes.get(table[0][0]) if table else None
 
     def __len__(self):
         return len(self.datapath)
 
     def __getitem__(self, index):
-        item, pts_file, seg_file = self.datapath[index]
-        cls = self.classes[item]
-        point_set = np.loadtxt(pts_file).astype(np.float32)
-        point_set = point_set - np.expand_dims(np.mean(point_set, axis=0), 0)      # centre
-        dist = np.max(np.sqrt(np.sum(point_set ** 2, axis=1)), 0)
-        point_set = point_set / dist                                               # scale to max-norm 1
-        choice = farthest_point_sample_np(point_set, self.npoints, getattr(self.opt, "device", None))
-        point_set = torch.from_numpy(point_set[choice, :].astype(np.float32))
-        cls = torch.from_numpy(np.array(cls).astype(np.int64))
+        name, pts_file, seg_file = self.datapath[index]
+        scan = normalise_scan(np.loadtxt(pts_file).astype(np.float32))
+        choice = farthest_point_sample_np(scan, self.npoints, getattr(self.opt, "device", None))
+        point_set = torch.from_numpy(scan[choice].astype(np.float32))
         if self.classification:
-            return point_set, cls
-        seg = np.loadtxt(seg_file).astype(np.int64)
-        return point_set, torch.from_numpy(seg[choice])
+            return point_set, torch.from_numpy(np.array(self.classes[name]).astype(np.int64))
+        return point_set, torch.from_numpy(np.loadtxt(seg_file).astype(np.int64)[choice])
 
 
 def batches_of_one(dataset):

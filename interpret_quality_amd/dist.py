@@ -7,18 +7,50 @@ rewards) per (cloud, pose | setting) so that rank 0 can write the artefacts and 
 reference's order.  Payloads are small (<= a few MB), so the gather is latency-bound: one padded
 all_gather, never one per batch.
 """
+import contextlib
 import os
 
 import torch
 import torch.distributed as dist
 
+_LOCAL_ONLY = [False]
 
-def world():
+
+@contextlib.contextmanager
+def local_only():
+    """Inside this context the stage code sees a world of ONE rank (it computes every unit it is given and writes its
+    artefacts itself, no collective) although a process group exists: the mode of the outer sweep (tools/sweep.py), which
+    hands whole (model, dataset, cloud) units to ranks and needs the group only for its barriers (SURVEY.md 8e bullet 3)."""
+    prev = _LOCAL_ONLY[0]
+    _LOCAL_ONLY[0] = True
+    try:
+        yield
+    finally:
+        _LOCAL_ONLY[0] = prev
+
+
+def group_rank():
+    """Rank / size of the real process group, whatever local_only() says."""
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def group_world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def world():
+    return 1 if _LOCAL_ONLY[0] else group_world()
+
+
 def rank():
-    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    return 0 if _LOCAL_ONLY[0] else group_rank()
+
+
+def cloud_selected(args, index):
+    """Stage loops run over the 30 clouds of a dataset; ``args.cloud_subset`` (a set of indices, additive) restricts a call
+    to some of them - the unit of the outer sweep.  None / absent: all clouds, as in the reference."""
+    subset = getattr(args, "cloud_subset", None)
+    return subset is None or index in subset
 
 
 def init_from_env(device_type="cuda"):
@@ -47,7 +79,7 @@ def force_dist():
 
 def collectives_on():
     """True when results travel through the collectives: more than one rank, or a forced single-rank group."""
-    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_dist())
+    return (not _LOCAL_ONLY[0]) and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_dist())
 
 
 def shard_range(n, r=None, w=None):
@@ -81,15 +113,8 @@ def all_gather_rows(t, n_total):
         pad[:t.shape[0]] = t
     # ONE preallocated (w * cap, ...) receive buffer: all_gather_into_tensor writes every rank's chunk in place (the
     # list form of all_gather costs an extra copy per rank on RCCL, and these payloads are latency-bound)
-    if t.is_cuda and dist.get_backend() == "gloo":
-        # rehearsal runs (IQ_REHEARSAL: several ranks on one GPU, gloo): gloo's own device-tensor path is the one piece of this
-        # stack that has aborted intermittently under two ranks sharing a GPU, so device tensors are staged through the host
-        host = torch.empty((w * cap,) + tail, dtype=t.dtype)
-        dist.all_gather_into_tensor(host, pad.cpu())
-        out = host.to(t.device)
-    else:
-        out = torch.empty((w * cap,) + tail, dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, pad)
+    out = torch.empty((w * cap,) + tail, dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, pad)
     if all(c == cap for c in counts):
         return out
     return torch.cat([out[r * cap:r * cap + c] for r, c in enumerate(counts)], dim=0)
@@ -121,28 +146,60 @@ def barrier():
         dist.barrier()
 
 
-def record(fn):
-    """Decorator for the stage scripts' main(): under a multi-rank launch a failing rank's exception (with its traceback)
-    goes to torchrun's error file and to stderr BEFORE the launcher tears the other ranks down, so the cause of a child
-    death is on record (torch.distributed.elastic's ``record``; a plain call otherwise)."""
-    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
-        return fn
+def group_barrier():
+    """Barrier of the real group (the sweep's phase boundaries), whatever local_only() says."""
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def shutdown(ok=True):
+    """Leave the process group in an orderly way: after a successful stage every rank waits for the others (so that no
+    rank's sockets / communicator disappear under a peer that is still inside its last gather or still writing the
+    artefacts) and then destroys the group.  A process that exits with a live group leaves the teardown of the backend's
+    worker threads to interpreter exit, where an exception in one of them is a C++ terminate = SIGABRT after the work is
+    done; every stage main goes through here (``record`` below).  After a failure there is no barrier (the peers may
+    never reach it): the group is dropped and the exception travels on."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
     try:
-        from torch.distributed.elastic.multiprocessing.errors import record as _record
-    except ImportError:
-        return fn
+        if ok:
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                torch.cuda.synchronize()
+            dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def record(fn):
+    """Decorator for the stage scripts' main(): (1) the process group the stage created is shut down on every exit path
+    (``shutdown``); (2) under a multi-rank launch a failing rank's exception (with its traceback) goes to torchrun's
+    error file and to stderr BEFORE the launcher tears the other ranks down, so the cause of a child death is on record
+    (torch.distributed.elastic's ``record``)."""
     import functools
     import sys
     import traceback
 
-    recorded = _record(fn)
+    inner = fn
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        try:
+            from torch.distributed.elastic.multiprocessing.errors import record as _record
+            inner = _record(fn)
+        except ImportError:
+            pass
 
     @functools.wraps(fn)
     def wrapper(*a, **k):
+        owns = not (dist.is_available() and dist.is_initialized())  # a caller's group (sweep driver, tests) is the caller's
         try:
-            return recorded(*a, **k)
+            out = inner(*a, **k)
         except BaseException:
-            sys.stderr.write("[rank %s] stage failed:\n%s\n" % (os.environ.get("RANK", "?"), traceback.format_exc()))
-            sys.stderr.flush()
+            if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+                sys.stderr.write("[rank %s] stage failed:\n%s\n" % (os.environ.get("RANK", "?"), traceback.format_exc()))
+                sys.stderr.flush()
+            if owns:
+                shutdown(ok=False)
             raise
+        if owns:
+            shutdown(ok=True)
+        return out
     return wrapper

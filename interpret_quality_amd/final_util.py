@@ -161,6 +161,10 @@ def load_model(args):
     DataParallel ``module.`` prefix), eval mode.  ``args.synthetic`` (additive flag of the drop-in
     scripts) substitutes the deterministic synthetic weights when no checkpoint exists offline."""
     from . import synth
+    cache = getattr(args, "model_cache", None)   # additive: the sweep driver builds each (model, dataset) once per process
+    key = (args.model, args.dataset, args.model_path, bool(getattr(args, "synthetic", False)))
+    if cache is not None and key in cache:
+        return cache[key]
     if args.model == "pointnet":
         from .pointnet import PointNetCls
         model, synth_sd = PointNetCls(args).to(args.device), synth.pointnet_state_dict
@@ -184,7 +188,10 @@ def load_model(args):
     for k, v in state_dict.items():
         new_state_dict[k[len("module."):] if "module." in k else k] = v
     model.load_state_dict(new_state_dict)
-    return model.eval()
+    model = model.eval()
+    if cache is not None:
+        cache[key] = model
+    return model
 
 
 def get_folder_name_list(args):

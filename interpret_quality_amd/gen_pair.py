@@ -169,9 +169,8 @@ def save_pred_label(args, disturb_fn, folder_name_list):
                 gen_pred_label(model, data, lbl, disturb_fn, region_folder + "min_pose/", args)
 
 
-@iqdist.record
-def main(argv=None):
-    """final_gen_pair.py:323-374, same flags and stage order."""
+def make_args(argv=None):
+    """final_gen_pair.py:323-374, same flags."""
     p = argparse.ArgumentParser(description="Point Cloud Recognition")
     p.add_argument("--model", type=str, default="pointnet", metavar="N",
                    choices=["pointnet", "pointnet2", "pointconv", "dgcnn", "gcnn", "gcnn_adv"])
@@ -187,16 +186,26 @@ def main(argv=None):
     p.add_argument("--softmax_type", default="modified", type=str, choices=["normal", "modified"])
     p.add_argument("--synthetic", action="store_true")
     p.add_argument("--num_clouds", type=int, default=30)
-    args = p.parse_args(argv)
+    return p.parse_args(argv)
+
+
+def run(args):
+    """Same stage order as final_gen_pair.py:323-374.  Host RNG streams that run on from cloud to cloud + one small search
+    per cloud: never sharded by cloud (the draws of cloud k depend on what clouds < k consumed)."""
+    names = get_folder_name_list(args)
+    disturb_fn = translate_pc if args.mode == "trans" else rotate_xyz
+    save_pair_random(args, names)
+    check_adv_success(args, disturb_fn, names)
+    save_pair_single_region(args, names)
+    save_context(args, names)
+    save_pred_label(args, disturb_fn, names)
+
+
+@iqdist.record
+def main(argv=None):
+    args = make_args(argv)
     finish_args(args)
-    # host RNG streams + one small search per cloud: not sharded.  Under a multi-rank launch rank 0 does the work and
-    # the others wait, so that no two ranks write the same files.
+    # under a multi-rank launch rank 0 does the work and the others wait, so that no two ranks write the same files
     if iqdist.rank() == 0:
-        names = get_folder_name_list(args)
-        disturb_fn = translate_pc if args.mode == "trans" else rotate_xyz
-        save_pair_random(args, names)
-        check_adv_success(args, disturb_fn, names)
-        save_pair_single_region(args, names)
-        save_context(args, names)
-        save_pred_label(args, disturb_fn, names)
+        run(args)
     iqdist.barrier()

@@ -79,6 +79,56 @@ def masks_to_tensor(masks, device):
     return torch.from_numpy(np.ascontiguousarray(arr)).to(device)
 
 
+def mt_state_to_device(device, state=None):
+    """NumPy legacy generator state (np.random.get_state(); default: the GLOBAL generator's) -> (625,) int32 device tensor
+    holding the 624 key words and the position, the form iq_sample_permutations advances."""
+    st = np.random.get_state() if state is None else state
+    if st[0] != "MT19937":
+        raise _lib.IqError("the reference's sampling stream is NumPy's legacy MT19937 generator, got %r" % (st[0],))
+    words = np.empty(625, dtype=np.uint32)
+    words[:624], words[624] = st[1], st[2]
+    return torch.from_numpy(words.view(np.int32)).to(device)
+
+
+def mt_state_to_host(mt_state, set_global=True):
+    """The advanced state back on the host (one device->host copy); ``set_global`` installs it as NumPy's global generator
+    so that whatever the host draws next continues the reference's stream."""
+    words = mt_state.cpu().numpy().view(np.uint32)
+    st = ("MT19937", words[:624].copy(), int(words[624]), 0, 0.0)
+    if set_global:
+        np.random.set_state(st)
+    return st
+
+
+def sample_permutations(mt_state, num_samples, num_regions):
+    """iq_sample_permutations: (S,R) int32 permutations continuing the generator ``mt_state`` (advanced in place, no sync)."""
+    lib = _lib.load()
+    orders = torch.empty((int(num_samples), int(num_regions)), dtype=torch.int32, device=mt_state.device)
+    _lib.check(lib.iq_sample_permutations(_dev(mt_state, torch.int32, "mt_state"), _p(orders), int(num_samples), int(num_regions),
+                                          _stream()), "iq_sample_permutations")
+    return orders
+
+
+def prefix_keep_masks(orders):
+    """orders (S,R) i32 -> (S*(R+1),) int64-typed keep masks of the prefix coalitions (tools/final_common.py:56-60)."""
+    lib = _lib.load()
+    s, r = orders.shape
+    keep = torch.empty((s * (r + 1),), dtype=torch.int64, device=orders.device)
+    _lib.check(lib.iq_prefix_keep_masks(_dev(orders, torch.int32, "orders"), _p(keep), s, r, _stream()), "iq_prefix_keep_masks")
+    return keep
+
+
+def context_keep_masks(pairs, contexts):
+    """pairs (P,2) i32, contexts (P,C,m) i32 -> (4*P*C,) int64-typed keep masks, rows S+{i,j}, S+{i}, S+{j}, S per context
+    (final_point_binary_interaction_logits.py:45-52)."""
+    lib = _lib.load()
+    p, c, m = contexts.shape
+    keep = torch.empty((4 * p * c,), dtype=torch.int64, device=pairs.device)
+    _lib.check(lib.iq_context_keep_masks(_dev(pairs, torch.int32, "pairs"), _dev(contexts, torch.int32, "contexts") if m else ctypes.c_void_p(0),
+                                         _p(keep), p, c, m, _stream()), "iq_context_keep_masks")
+    return keep
+
+
 def mask_shapley(cloud, region_id, orders, center, channel_first=False):
     """cloud (N,3) f32, region_id (N,) i32, orders (bs,R) i32, center (3,) f32 ->
     (bs*(R+1), N, 3) or (bs*(R+1), 3, N)."""
@@ -189,7 +239,7 @@ def knn(x, k=20):
     lib = _lib.load()
     b, n, c = x.shape
     out = torch.empty((b, n, k), dtype=torch.int32, device=x.device)
-    tmp = torch.empty((b * n * 80 + 16 * b + 8192,), dtype=torch.uint8, device=x.device)
+    tmp = torch.empty((b * n * 84 + 16 * b + 16384,), dtype=torch.uint8, device=x.device)
     _lib.check(lib.iq_knn(_dev(x, torch.float32, "x"), _p(out), _p(tmp), tmp.numel(), b, n, c, k, _stream()), "iq_knn")
     return out
 

@@ -112,7 +112,7 @@ def save_logits(args, disturb_fn):
     folder_name_list = get_folder_name_list(args)
     with torch.no_grad():
         for pc_idx, (data, lbl) in enumerate(data_loader(args)):
-            if pc_idx not in _selected(args):
+            if pc_idx not in _selected(args) or not iqdist.cloud_selected(args, pc_idx):
                 continue
             name = folder_name_list[pc_idx]
             print("======= sample %s =========" % name)
@@ -162,7 +162,7 @@ def cal_interaction(args):
     folder_name_list = get_folder_name_list(args)
     with torch.no_grad():
         for pc_idx, (data, lbl) in enumerate(data_loader(args)):
-            if pc_idx not in _selected(args):
+            if pc_idx not in _selected(args) or not iqdist.cloud_selected(args, pc_idx):
                 continue
             name = folder_name_list[pc_idx]
             print("======= sample %s =========" % name)
@@ -210,17 +210,27 @@ def build_parser(with_cal_flags):
     return p
 
 
-@iqdist.record
-def main_logits(argv=None):
-    args = build_parser(False).parse_args(argv)
-    args.softmax_type = "modified"
-    finish_args(args)
+def make_args(with_cal_flags, argv=None):
+    args = build_parser(with_cal_flags).parse_args(argv)
+    if not with_cal_flags:
+        args.softmax_type = "modified"
+    return args
+
+
+def run_logits(args):
     set_interaction_batch_size(args)
     save_logits(args, disturb_fn=translate_pc if args.mode == "trans" else rotate_xyz)
 
 
 @iqdist.record
+def main_logits(argv=None):
+    args = make_args(False, argv)
+    finish_args(args)
+    run_logits(args)
+
+
+@iqdist.record
 def main_cal(argv=None):
-    args = build_parser(True).parse_args(argv)
+    args = make_args(True, argv)
     finish_args(args)
     cal_interaction(args)

@@ -176,6 +176,8 @@ def test(args, get_transform_params_fn, disturb_fn, print_info_fn, save_info_fn)
     folder_name_list = get_folder_name_list(args)
     write = iqdist.rank() == 0
     for pc_index, (data, lbl) in enumerate(data_loader(args)):
+        if not iqdist.cloud_selected(args, pc_index):
+            continue
         data, lbl = data.to(args.device), lbl.to(args.device)
         base_folder = args.exp_folder + "%s/" % folder_name_list[pc_index]
         mode_folder = base_folder + "%s_all/" % args.mode
@@ -207,8 +209,7 @@ def test(args, get_transform_params_fn, disturb_fn, print_info_fn, save_info_fn)
             io.close()
 
 
-@iqdist.record
-def _main(mode, argv=None):
+def make_args(mode, argv=None):
     default_model = {"trans": "gcnn_adv", "rotate": "pointconv", "scale": "pointconv"}[mode]
     args = build_parser(default_model).parse_args(argv)
     args.num_samples = NUM_SAMPLES
@@ -216,12 +217,23 @@ def _main(mode, argv=None):
     args.angle_threshold, args.num_grid_enum_rotate = ANGLE_THRESHOLD, NUM_GRID_ENUM_ROTATE
     args.trans_dist_threshold, args.num_grid_enum_trans = TRANS_DIST_THRESHOLD, NUM_GRID_ENUM_TRANS
     args.scale_upper, args.scale_lower, args.num_grid_enum_scale = SCALE_UPPER, SCALE_LOWER, NUM_GRID_ENUM_SCALE
-    finish_args(args)
+    return args
+
+
+def run(args):
+    """The body of the three sweep scripts after argument handling (final_*_center_enum_all.py mains)."""
     set_shapley_batch_size(args)
     fns = {"trans": (generate_trans_vector, translate_pc, print_trans_info, save_trans_info),
            "rotate": (generate_rotate_angle, rotate_xyz, print_rotate_info, save_rotate_info),
-           "scale": (generate_scale, scale_pc, print_scale_info, save_scale_info)}[mode]
+           "scale": (generate_scale, scale_pc, print_scale_info, save_scale_info)}[args.mode]
     test(args, *fns)
+
+
+@iqdist.record
+def _main(mode, argv=None):
+    args = make_args(mode, argv)
+    finish_args(args)
+    run(args)
 
 
 def main_trans(argv=None):

@@ -45,10 +45,19 @@ def save_fps(args, loader=None):
 def data_loader(args):
     """The 30-cloud loaders of final_data_shapley.py (data_shapley.py here) when the dataset trees exist;
     ``--synthetic`` (additive flag) substitutes the seeded synthetic clouds when they do not."""
+    cache = getattr(args, "data_cache", None)   # additive: the sweep driver parses a dataset once per process
+    key = (args.dataset, bool(getattr(args, "synthetic", False)), getattr(args, "num_clouds", 30), args.num_points)
+    if cache is not None and key in cache:
+        return iter(cache[key])
     if getattr(args, "synthetic", False):
-        return synthetic_loader(args)
-    from .data_shapley import shapley_test_loader
-    return shapley_test_loader(args)
+        items = synthetic_loader(args)
+    else:
+        from .data_shapley import shapley_test_loader
+        items = shapley_test_loader(args)
+    if cache is None:
+        return items
+    cache[key] = list(items)
+    return iter(cache[key])
 
 
 def cal_region_id(data, fps_index, result_path, save=True):
@@ -72,11 +81,14 @@ def cal_norm_factor(model, data, lbl, center, result_path, args, save=True):
 
 
 def generate_all_orders(result_path, args, save=True):
-    """final_shapley_value.py:59-72 - host NumPy global RNG, so the stream (and all_orders.npy) is
-    the reference's for the same seed."""
-    rows = [np.random.permutation(np.arange(0, args.num_regions, 1)).reshape((1, -1))
-            for _ in range(args.num_samples_save)]
-    all_orders = np.concatenate(rows, axis=0)
+    """final_shapley_value.py:59-72.  The reference draws ``num_samples_save`` permutations from NumPy's global generator;
+    here the SAME stream is continued on the device (iq_sample_permutations: MT19937 + the legacy shuffle, bit-identical),
+    and the advanced state is handed back to NumPy, so all_orders.npy and every later host draw are the reference's for the
+    same seed.  Returns the (S,R) int64 ndarray the reference returns."""
+    state = hip_ops.mt_state_to_device(args.device)
+    orders = hip_ops.sample_permutations(state, args.num_samples_save, args.num_regions)
+    hip_ops.mt_state_to_host(state, set_global=True)
+    all_orders = orders.cpu().numpy().astype(np.int64)
     if save:
         np.save(result_path + "all_orders.npy", all_orders)
     return all_orders
@@ -123,6 +135,9 @@ def shap_sampling(model, dataloader, args, folder_name_list):
         fps_indices = np.load(fps_index_path(args))
         for i, (data, lbl) in enumerate(dataloader):
             result_path = args.exp_folder + "%s/" % folder_name_list[i]
+            if not iqdist.cloud_selected(args, i):
+                generate_all_orders(result_path, args, save=False)  # the stream runs on from cloud to cloud: draw, do not compute
+                continue
             mkdir(result_path)
             data, lbl = data.to(args.device), lbl.to(args.device)
             write = iqdist.rank() == 0
@@ -165,43 +180,51 @@ def build_parser(default_model="pointconv", default_dataset="shapenet"):
     return p
 
 
-def finish_args(args):
-    """Common tail of every stage's main() (final_shapley_value.py:189-203)."""
+def prepare_args(args, device):
+    """The device-independent tail of every stage's main() (final_shapley_value.py:189-203): constants, folders, seeds,
+    model arguments.  ``device``: the torch device this process already selected."""
     args.num_points = NUM_POINTS
     args.num_regions = getattr(args, "num_regions", None) or NUM_REGIONS
     args.exp_folder = exp_folder(args)
-    _, world, local_rank = iqdist.init_from_env("cuda")
-    if world == 1:
-        # CUDA_VISIBLE_DEVICES = device_id in the reference (final_shapley_value.py:192-193).  When the launcher has
-        # already restricted the visible devices, or device_id names a GPU this box does not have (the reference's
-        # final_cal_interactions.py defaults to 1), device_id is mapped onto the visible devices instead of hiding every GPU.
-        n_dev = torch.cuda.device_count()  # does not initialise the GPU
-        if "HIP_VISIBLE_DEVICES" in os.environ or "CUDA_VISIBLE_DEVICES" in os.environ or args.device_id >= n_dev:
-            local_rank = args.device_id % max(n_dev, 1)
-            if local_rank != args.device_id:
-                print("warning: --device_id %d is not among the %d visible device(s); using device %d" % (args.device_id, n_dev, local_rank))
-        else:
-            os.environ["HIP_VISIBLE_DEVICES"] = str(args.device_id)
-            local_rank = 0
-    if args.no_cuda or not torch.cuda.is_available():
-        raise SystemExit("this build has no CPU path: a GPU is required (the reference's --no_cuda is not supported)")
-    torch.cuda.set_device(local_rank)
     args.cuda = True
-    args.device = torch.device("cuda", local_rank)
+    args.device = device
     mkdir("checkpoints")
     mkdir(args.exp_folder)
     set_random(args.seed)
     set_model_args(args)
+    return args
+
+
+def finish_args(args):
+    """Common tail of every stage's main(): process group, device selection, then prepare_args."""
+    _, world, local_rank = iqdist.init_from_env("cuda")
+    if world == 1:
+        # The reference pins the process with CUDA_VISIBLE_DEVICES = device_id (final_shapley_value.py:196-198).  Here the
+        # device is SELECTED (torch.cuda.set_device below), never hidden: writing HIP_VISIBLE_DEVICES only works before the
+        # first HIP call of the process, which no code path of torch guarantees.  device_id counts within whatever the
+        # launcher left visible; one beyond that (the reference's final_cal_interactions.py defaults to 1) wraps around.
+        n_dev = torch.cuda.device_count()
+        local_rank = args.device_id % max(n_dev, 1)
+        if local_rank != args.device_id:
+            print("warning: --device_id %d is not among the %d visible device(s); using device %d" % (args.device_id, n_dev, local_rank))
+    if args.no_cuda or not torch.cuda.is_available():
+        raise SystemExit("this build has no CPU path: a GPU is required (the reference's --no_cuda is not supported)")
+    torch.cuda.set_device(local_rank)
+    prepare_args(args, torch.device("cuda", local_rank))
     print("Using GPU : %d from %d devices" % (torch.cuda.current_device(), torch.cuda.device_count()))
     return args
 
 
-@iqdist.record
-def main(argv=None):
+def make_args(argv=None):
     parser = build_parser()
     parser.add_argument("--num_samples_save", type=int, default=NUM_SAMPLES_SAVE)  # additive
     parser.add_argument("--num_regions", type=int, default=NUM_REGIONS)            # additive
-    args = parser.parse_args(argv)
+    return parser.parse_args(argv)
+
+
+@iqdist.record
+def main(argv=None):
+    args = make_args(argv)
     finish_args(args)
     test(args)
 

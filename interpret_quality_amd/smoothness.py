@@ -110,6 +110,8 @@ def test_smoothness(args):
     model = load_model(args)
     folder_name_list = get_folder_name_list(args)
     for pc_index, (data, lbl) in enumerate(data_loader(args)):
+        if not iqdist.cloud_selected(args, pc_index):
+            continue
         data, lbl = data.to(args.device), lbl.to(args.device)
         base_folder = args.exp_folder + "%s/" % folder_name_list[pc_index]
         mode_folder = base_folder + "%s_all/" % args.mode
@@ -119,15 +121,24 @@ def test_smoothness(args):
         test_all_region(model, data, lbl, load_order_list, region_id, mode_folder, args, objective="dec")
 
 
-@iqdist.record
-def main(argv=None):
+def make_args(argv=None):
     args = build_parser("pointnet").parse_args(argv)
     args.num_samples = NUM_SAMPLES
     args.step, args.enum_step, args.epoch = STEP, ENUM_STEP, EPOCH
     args.var_threshold, args.dist_threshold = VAR_THRESHOLD, DIST_THRESHOLD
     args.stop_ratio, args.max_iteration = STOP_RATIO, MAX_ITERATION
-    finish_args(args)
+    return args
+
+
+def run(args):
     set_shapley_batch_size(args)
     for mode in ("linearity", "planarity", "scattering"):   # :413-418
         args.mode = mode
         test_smoothness(args)
+
+
+@iqdist.record
+def main(argv=None):
+    args = make_args(argv)
+    finish_args(args)
+    run(args)

@@ -1,10 +1,10 @@
-"""Baseline, not a test and not product code: the reference's Shapley loop restated with stock
+"""Baseline leg of bench.py - checker-side code like the rest of oracle/, never on the product path: the reference's Shapley loop restated with stock
 PyTorch-ROCm eager ops on the MI355X - the stand-in for the unpublished "reference on a GPU"
 figure (SURVEY.md §8d baseline (ii)).  Same structure as tools/final_common.py:64-103: bs*R
 boolean-index assignments per batch, one batched forward, one host sync per permutation.
 bench.py reports it as `gpu_eager_baseline`.
 
-    python tests/eager_gpu_baseline.py [--perms 100] [--bs 50]
+    python oracle/eager_gpu_baseline.py [--perms 100] [--bs 50]
 """
 import argparse
 import os

@@ -4,9 +4,10 @@ float32 path.  DGCNN rebuilds its kNN graph in feature space at every layer, so 
 flip a neighbour under any rounding change; this fixture is what the rate of such coalitions is measured on
 (tests/test_dgcnn_gpu.py::test_dgcnn_parity_rate_at_scale).
 
-    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/gen_golden_dgcnn_scale.py     (about 10 minutes, 8 cores)
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/gen_golden_dgcnn_scale.py [dgcnn|gcnn]   (about 10 minutes, 8 cores)
 
-Output tests/golden/dgcnn_scale.npz (data only)."""
+Output tests/golden/dgcnn_scale.npz (default) or gcnn_scale.npz: the same inputs through GCNN_cls (one fixed xyz graph; the
+control for the near-tie attribution and the second model of the context-averaged interaction check).  Data only."""
 import argparse
 import os
 import sys
@@ -31,7 +32,9 @@ import final_point_binary_interaction_logits as ref_inter  # noqa: E402
 
 def main():
     torch.set_num_threads(8)
-    model = ref_dg.DGCNN_cls(argparse.Namespace(dataset="modelnet10", k=20))
+    name = sys.argv[1] if len(sys.argv) > 1 else "dgcnn"
+    cls = {"dgcnn": ref_dg.DGCNN_cls, "gcnn": ref_dg.GCNN_cls}[name]
+    model = cls(argparse.Namespace(dataset="modelnet10", k=20))
     model.load_state_dict(synth.to_torch(synth.dgcnn_state_dict(0)))
     model.eval()
     cloud_id, num_regions = 5, 32
@@ -40,7 +43,7 @@ def main():
     fps_index = ref_fps.farthest_point_sample(data, num_regions)[0]
     region_id = ref_stage1.cal_region_id(data, fps_index, None, save=False)
     ratios = [0.07, 0.3, 0.6, 0.9]            # m = 2, 9, 18, 27 context regions
-    args = argparse.Namespace(model="dgcnn", softmax_type="modified", num_regions=num_regions, num_pairs_random=21,
+    args = argparse.Namespace(model=name, softmax_type="modified", num_regions=num_regions, num_pairs_random=21,
                               num_save_context_max=6, ratio=ratios, interaction_batch_size=6)
     ref_util.set_random(7)
     pairs = ref_pair.gen_pair_random(args)
@@ -48,7 +51,7 @@ def main():
            "ratios": np.array(ratios)}
     # the reference itself in float64 on the same inputs: how far ITS float32 result is from exact arithmetic shows which
     # coalitions sit on a kNN near-tie (their graphs flip under any change of rounding), i.e. the reference's own conditioning
-    m64 = ref_dg.DGCNN_cls(argparse.Namespace(dataset="modelnet10", k=20)).double()
+    m64 = cls(argparse.Namespace(dataset="modelnet10", k=20)).double()
     m64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in synth.to_torch(synth.dgcnn_state_dict(0)).items()})
     m64.eval()
     n = 0
@@ -65,7 +68,7 @@ def main():
             n += logits.shape[0] * logits.shape[1]
             print(tag, ctx.shape, tuple(logits.shape), flush=True)
     print("coalitions:", n)
-    np.savez_compressed(os.path.join(HERE, "dgcnn_scale.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "%s_scale.npz" % name), **out)
 
 
 if __name__ == "__main__":

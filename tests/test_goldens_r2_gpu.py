@@ -2,7 +2,8 @@
 
 * gen_pair.npz      - the device logic of final_gen_pair.py (check_adv_success, save_pair_single_region, save_pred_label)
 * pointnet_config0.npz - BASELINE configs[0] at spec: 30 clouds, 8 regions, 64 permutations, bs 8 (17 280 coalitions)
-* dgcnn_scale.npz   - 2016 DGCNN interaction coalitions: how many exceed 1e-4, and why
+* dgcnn_scale.npz / gcnn_scale.npz - 2016 interaction coalitions each, the reference in float32 and float64: conditioning
+  against exact arithmetic, near-tie attribution, context-averaged interactions
 """
 import argparse
 import os
@@ -12,7 +13,7 @@ import pytest
 import torch
 
 from conftest import assert_close_elementwise, load_golden
-from interpret_quality_amd import final_common, gen_pair, hip_ops, interaction, pose_sweep, synth
+from interpret_quality_amd import final_common, gen_pair, hip_ops, interaction, pose_sweep, shapley_stage, synth
 from interpret_quality_amd.dgcnn import DGCNN_cls
 from interpret_quality_amd.pointnet import PointNetCls
 
@@ -91,8 +92,9 @@ def test_config0_at_spec_30_clouds_8_regions_64_permutations(pointnet):
         assert np.array_equal(fps.cpu().numpy(), g["fps_index"][ci])
         rid = hip_ops.region_assign(data[0].contiguous(), fps.contiguous()).cpu().numpy()
         assert (rid != g["region_id"][ci]).sum() <= 2                   # true near-ties only (test_hip_parity.py::test_region_assign)
-        orders = np.stack([np.random.permutation(np.arange(0, r, 1)) for _ in range(s)])   # final_shapley_value.py:59-72
-        assert np.array_equal(orders, g["orders"][ci])
+        # final_shapley_value.py:59-72 through the product's device sampler (iq_sample_permutations continues NumPy's stream)
+        orders = shapley_stage.generate_all_orders(None, argparse.Namespace(device=dev(), num_samples_save=s, num_regions=r), save=False)
+        assert orders.dtype == np.int64 and np.array_equal(orders, g["orders"][ci])
         phi, logits = final_common.shap_sampling_all_regions_batch(pointnet, data, lbl, g["region_id"][ci].astype(np.int64), orders, args)
         v = final_common.get_reward(logits, lbl, args).cpu().numpy()
         vmax = np.abs(g["v"][ci]).max()
@@ -123,54 +125,102 @@ def _knn_min_margin(sd, x):
     return best
 
 
-def test_dgcnn_parity_rate_at_scale():
-    """2016 DGCNN interaction coalitions against the reference's CPU float32 logits.  DGCNN rebuilds its graph in feature
-    space at every layer; a coalition on a kNN near-tie flips a neighbour under ANY change of rounding (here: MFMA k-order vs
-    ATen's sgemm blocking), after which the logits differ at the 1e-3 level.  The fixture also holds the REFERENCE's own
-    float64 run: where the reference's float32 result is far from its float64 result, the coalition is ill-conditioned for
-    the reference itself.  Asserted: the median error is at fp32 level; the share of coalitions above 1e-4 (relative to
-    max |logit|) is at most 6 % and at most twice the share on which the reference disagrees with ITSELF across precisions
-    (measured: 4.5 % against the reference's own 3.5 %); every such coalition has a kNN margin below 1e-5 of the squared
-    feature norm in one of ITS OWN three feature-space graphs (flips were observed up to 3.2e-6; well-separated graphs
-    never flip); none exceeds 3e-2.  The measured rates are printed (DESIGN.md quotes them)."""
-    from oracle import ref_cpu as O
-    g = load_golden("dgcnn_scale.npz")
+_SCALE_CACHE = {}
+
+
+def _scale_logits(name):
+    """HIP logits of the 2016 interaction coalitions of <name>_scale.npz (once per test session), beside the reference's
+    float32 and float64 logits: {tag: (contexts, got, ref32, ref64)}, plus the fixture, the CPU cloud and the state dict."""
+    if name in _SCALE_CACHE:
+        return _SCALE_CACHE[name]
+    from interpret_quality_amd.dgcnn import GCNN_cls
+    g = load_golden("%s_scale.npz" % name)
     sd = synth.to_torch(synth.dgcnn_state_dict(0))
-    model = DGCNN_cls(argparse.Namespace(dataset="modelnet10", k=20))
+    model = {"dgcnn": DGCNN_cls, "gcnn": GCNN_cls}[name](argparse.Namespace(dataset="modelnet10", k=20))
     model.load_state_dict(sd)
     model = model.to(dev()).eval()
     pts, _ = synth.make_cloud(int(g["cloud_id"]))
     data_cpu = torch.from_numpy(pts).unsqueeze(0)
-    data = data_cpu.to(dev())
-    region_id = g["region_id"].astype(np.int64)
-    pairs = g["pairs"].astype(np.int64)
-    args = argparse.Namespace(model="dgcnn", softmax_type="modified", num_regions=32, interaction_batch_size=6)
-    center = torch.mean(data_cpu, dim=1).squeeze()
-    errs, ref_errs, bad = [], [], []
+    args = argparse.Namespace(model=name, softmax_type="modified", num_regions=32, interaction_batch_size=6)
+    rows = {}
     for ratio in g["ratios"]:
         tag = "ratio%d" % int(ratio * 100)
         ctx = g[tag + "_contexts"].astype(np.int64)
-        want = g[tag + "_logits"]
-        got = interaction.compute_order_interaction_logits(model, data, region_id, pairs, ctx, args).cpu().numpy()
-        scale = np.abs(want).max()
-        err = np.abs(got - want).max(axis=-1) / scale                                            # (P, 4C)
-        errs.append(err.reshape(-1))
-        ref_errs.append((np.abs(g[tag + "_logits_fp64"] - want).max(axis=-1) / scale).reshape(-1))
-        for p, c in zip(*np.nonzero(err >= RTOL)):
+        got = interaction.compute_order_interaction_logits(model, data_cpu.to(dev()), g["region_id"].astype(np.int64),
+                                                           g["pairs"].astype(np.int64), ctx, args).cpu().numpy()
+        rows[tag] = (ctx, got, g[tag + "_logits"], g[tag + "_logits_fp64"])
+    _SCALE_CACHE[name] = (g, sd, data_cpu, rows)
+    return _SCALE_CACHE[name]
+
+
+def test_dgcnn_parity_rate_at_scale():
+    """2016 DGCNN interaction coalitions.  DGCNN rebuilds its kNN graph in feature space at every layer (models/dgcnn.py:12-18);
+    a coalition on a kNN near-tie flips a neighbour under ANY change of rounding, after which its logits move at the 1e-3
+    level - for the reference too: the fixture holds the reference's float32 AND float64 logits of the same inputs, and they
+    disagree beyond 1e-4 on a few per cent of the coalitions.  The bars, none of them fitted to a measurement of this path:
+
+    (a) against exact arithmetic the HIP path is AT LEAST AS WELL CONDITIONED AS THE REFERENCE: the number of coalitions whose
+        logits differ from the reference's float64 logits by more than 1e-4 (of max |logit|) is no larger than the number on
+        which the reference's own float32 run does;
+    (b) every coalition on which the HIP path differs from the reference's float32 run by more than 1e-4 is explained: the
+        reference's float32 run is itself off its float64 run there, or one of the coalition's OWN three feature-space graphs
+        has a kNN margin (gap between the 20th and a later candidate) below 1e-5 of the squared feature norm - no
+        well-separated coalition deviates;
+    (c) the median error against the reference's float32 logits is at float32 level (< 1e-5)."""
+    from oracle import ref_cpu as O
+    g, sd, data_cpu, rows = _scale_logits("dgcnn")
+    region_id, pairs = g["region_id"].astype(np.int64), g["pairs"].astype(np.int64)
+    center = torch.mean(data_cpu, dim=1).squeeze()
+    e32, e64, r64, unexplained = [], [], [], []
+    for tag, (ctx, got, ref32, ref64) in rows.items():
+        scale = np.abs(ref32).max()
+        err32 = np.abs(got - ref32).max(axis=-1) / scale          # (P, 4C): HIP vs the reference's float32 run
+        err64 = np.abs(got - ref64).max(axis=-1) / scale          # HIP vs the reference's float64 run
+        ref_err = np.abs(ref32 - ref64).max(axis=-1) / scale      # the reference against itself across precisions
+        e32.append(err32.reshape(-1)), e64.append(err64.reshape(-1)), r64.append(ref_err.reshape(-1))
+        for p, c in zip(*np.nonzero((err32 >= RTOL) & (ref_err < RTOL))):
             masked = O.interaction_masked_batch(data_cpu.permute(0, 2, 1), center, region_id, pairs[p][0], pairs[p][1], ctx[p])
-            bad.append((tag, int(p), int(c), float(err[p, c]), _knn_min_margin(sd, masked[c:c + 1].contiguous())))
-    errs, ref_errs = np.concatenate(errs), np.concatenate(ref_errs)
-    n, n_bad, n_ref_bad = errs.size, len(bad), int((ref_errs >= RTOL).sum())
-    print("DGCNN at scale: %d coalitions, median err %.2e; above 1e-4: HIP vs reference fp32 %d (%.2f %%), reference fp64 vs its own "
-          "fp32 %d (%.2f %%); worst %.2e" % (n, np.median(errs), n_bad, 100.0 * n_bad / n, n_ref_bad, 100.0 * n_ref_bad / n,
-                                             max([b[3] for b in bad], default=0.0)))
-    for b in sorted(bad, key=lambda b: -b[3]):
-        print("   %s pair %2d row %2d: err %.2e, smallest kNN margin %.2e" % b)
-    assert n >= 2000 and np.median(errs) < 1e-5
-    assert n_bad <= 0.06 * n and n_bad <= max(2 * n_ref_bad, 10)
-    for b in bad:
-        assert b[4] < 1e-5, "coalition %s: error %.2e without a kNN near-tie (margin %.2e)" % (b[:3], b[3], b[4])
-        assert b[3] < 3e-2
+            margin = _knn_min_margin(sd, masked[c:c + 1].contiguous())
+            if margin >= 1e-5:
+                unexplained.append((tag, int(p), int(c), float(err32[p, c]), margin))
+    e32, e64, r64 = np.concatenate(e32), np.concatenate(e64), np.concatenate(r64)
+    n = e32.size
+    n_hip64, n_ref64, n_hip32 = int((e64 >= RTOL).sum()), int((r64 >= RTOL).sum()), int((e32 >= RTOL).sum())
+    print("DGCNN at scale, %d coalitions; above 1e-4 of max |logit|: HIP vs reference-fp64 %d (%.2f %%), reference-fp32 vs reference-fp64 "
+          "%d (%.2f %%), HIP vs reference-fp32 %d (%.2f %%); median HIP vs fp32 %.2e, vs fp64 %.2e; worst vs fp64: HIP %.2e, reference-fp32 %.2e"
+          % (n, n_hip64, 100.0 * n_hip64 / n, n_ref64, 100.0 * n_ref64 / n, n_hip32, 100.0 * n_hip32 / n, np.median(e32), np.median(e64),
+             e64.max(), r64.max()))
+    assert n >= 2000
+    assert n_hip64 <= n_ref64, "HIP is off exact arithmetic on %d coalitions, the reference's own float32 run on %d" % (n_hip64, n_ref64)
+    assert not unexplained, "deviation from the reference without a near-tie: %s" % (unexplained[:5],)
+    assert np.median(e32) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["dgcnn", "gcnn"])
+def test_context_averaged_interactions_at_scale(name):
+    """What the paper publishes from these logits is not a single I_ij(S) but its average over the sampled contexts
+    (final_cal_interactions.py:28-36 then plot_interaction.py:40-41: `I.mean()` and `|I.mean(axis=1)|.mean()` per order).  On
+    the 2016-coalition fixtures, DGCNN and GCNN: per (pair, order) the context mean of I_ij is within 1e-4 * max|v| of the
+    reference's, and so are the two published per-order figures.  GCNN (one fixed xyz graph) additionally holds 1e-4 on every
+    single logit row."""
+    g, _, _, rows = _scale_logits(name)
+    label = int(g["label"])
+    lbl = torch.tensor([label], device=dev())
+    args = argparse.Namespace(model=name, softmax_type="modified", num_regions=32)
+    worst = 0.0
+    for tag, (ctx, got, ref32, _) in rows.items():
+        if name == "gcnn":
+            assert np.abs(got - ref32).max() < RTOL * np.abs(ref32).max()
+        i_got = interaction.compute_order_interaction(torch.from_numpy(got).to(dev()), lbl, args)      # (P, C)
+        i_ref = interaction.compute_order_interaction(torch.from_numpy(ref32).to(dev()), lbl, args)
+        vmax = np.abs(hip_ops.reward(torch.from_numpy(ref32).reshape(-1, ref32.shape[-1]).to(dev()), label).cpu().numpy()).max()
+        d_pair = np.abs(i_got.mean(axis=1) - i_ref.mean(axis=1)).max() / vmax
+        d_mean = abs(i_got.mean() - i_ref.mean()) / vmax
+        d_abs = abs(np.abs(i_got.mean(axis=1)).mean() - np.abs(i_ref.mean(axis=1)).mean()) / vmax
+        worst = max(worst, d_pair, d_mean, d_abs)
+        assert d_pair < RTOL, "%s %s: context-mean I_ij off by %.2e of max|v|" % (name, tag, d_pair)
+        assert d_mean < RTOL and d_abs < RTOL
+    print("%s: worst context-averaged interaction error %.2e of max |v|" % (name, worst))
 
 
 @pytest.mark.parametrize("name", ["pointnet2", "pointconv"])

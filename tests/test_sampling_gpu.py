@@ -1,0 +1,72 @@
+"""GPU: coalition sampling on the device (csrc/iq_sample.hip) against NumPy's legacy generator, which is where the reference
+draws its permutations (final_shapley_value.py:59-72 after tools/final_util.py:113-120), and the keep-mask constructors
+against the host constructions (tools/final_common.py:56-60, final_point_binary_interaction_logits.py:45-52).  Bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from interpret_quality_amd import final_common, hip_ops, interaction
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _numpy_permutations(s, r):
+    return np.stack([np.random.permutation(np.arange(0, r, 1)) for _ in range(s)]) if s else np.zeros((0, r), dtype=np.int64)
+
+
+@pytest.mark.parametrize("seed,s,r", [(1, 1000, 32), (1, 64, 8), (7, 300, 64), (3, 50, 2), (5, 40, 1), (2, 1, 33), (11, 5000, 32)])
+def test_device_permutations_continue_numpys_stream(seed, s, r):
+    """Same permutations as np.random.permutation drawn s times, and the generator state handed back equals NumPy's own
+    state after those draws: whatever the host draws next (final_gen_pair.py's pairs and contexts) is unchanged."""
+    np.random.seed(seed)
+    np.random.rand(seed)                                  # start somewhere inside a 624-word block, as a running script does
+    start = np.random.get_state()
+    want = _numpy_permutations(s, r)
+    after = np.random.get_state()
+    tail_want = np.random.randint(0, 1 << 30, size=8)
+
+    np.random.set_state(start)
+    state = hip_ops.mt_state_to_device(dev())
+    got = hip_ops.sample_permutations(state, s, r)
+    st = hip_ops.mt_state_to_host(state, set_global=True)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert st[2] == after[2] and np.array_equal(st[1], after[1])
+    assert np.array_equal(np.random.randint(0, 1 << 30, size=8), tail_want)
+
+
+def test_device_permutations_in_several_calls_equal_one_call():
+    """The state lives on the device between calls (bench.py keeps it there across steps: no host round trip)."""
+    np.random.seed(4)
+    want = _numpy_permutations(700, 32)
+    np.random.seed(4)
+    state = hip_ops.mt_state_to_device(dev())
+    parts = [hip_ops.sample_permutations(state, n, 32) for n in (1, 99, 250, 350)]
+    assert np.array_equal(torch.cat(parts).cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("s,r", [(1000, 32), (3, 8), (17, 64), (5, 1)])
+def test_prefix_keep_masks_kernel_equals_the_host_construction(s, r):
+    rng = np.random.default_rng(s * 100 + r)
+    orders = np.stack([rng.permutation(r) for _ in range(s)]).astype(np.int64)
+    want = final_common.prefix_keep_masks(orders, r)
+    got = hip_ops.prefix_keep_masks(hip_ops.as_i32(orders, dev())).cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want)
+    assert got[0] == 0 and got[r] == np.uint64((1 << r) - 1 if r < 64 else 0xFFFFFFFFFFFFFFFF)
+
+
+@pytest.mark.parametrize("p,c,m,r", [(300, 100, 15, 32), (7, 1, 0, 32), (5, 1, 30, 32), (4, 6, 9, 64), (1, 1, 1, 8)])
+def test_context_keep_masks_kernel_equals_the_host_construction(p, c, m, r):
+    rng = np.random.default_rng(p + 10 * c + 100 * m)
+    pairs = np.stack([rng.choice(r, size=2, replace=False) for _ in range(p)]).astype(np.int64)
+    ctx = np.zeros((p, c, m), dtype=np.int64)
+    for a in range(p):
+        rest = np.setdiff1d(np.arange(r), pairs[a])
+        for b in range(c):
+            ctx[a, b] = rng.choice(rest, size=m, replace=False)
+    want = interaction.context_keep_masks(pairs, ctx, r)
+    got = hip_ops.context_keep_masks(hip_ops.as_i32(pairs, dev()), hip_ops.as_i32(ctx, dev())).cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want)
