@@ -4,21 +4,34 @@
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    ... bench.py --scaling strong [--model dgcnn]          # the path's OWN shard axes at N ranks (poses, pairs)
 
-One step = the whole Shapley hot path for one synthetic cloud: 1000 permutations x 33 prefix
-coalitions = 33 000 masked forward passes, reward, per-region float64 accumulation.  Inputs
-(cloud, region ids, permutations) are resident in HBM before the timed region.  With N > 1 every
-rank works on its own cloud (weak scaling; independent objects) and one RCCL all-gather per step
-brings the per-coalition logits to every rank, as the artefact writer on rank 0 needs them
-(SURVEY.md §8e).  IQ_FORCE_DIST=1 creates the process group (and runs the barrier / all-gather) at
-N = 1 too, so the RCCL path can be exercised on a one-GPU box.  Rank 0 prints ONE JSON line.
+One step (default, `"scaling": "weak"`) = the whole Shapley hot path for one synthetic cloud, ALL of it on the device and all
+of it inside the timed region: 1000 permutations sampled from NumPy's legacy generator stream (iq_sample_permutations; the state
+stays in HBM from step to step), their 33 000 prefix coalitions as region bit masks (iq_prefix_keep_masks), 33 000 masked
+forward passes, reward, per-region float64 accumulation.  Resident in HBM before the timed region: the cloud, its region ids,
+the generator state, the weights.  With N > 1 every rank works on its own cloud (independent objects) and one RCCL all-gather
+per step brings the per-coalition logits to every rank, as the artefact writer on rank 0 needs them.
+IQ_FORCE_DIST=1 creates the process group (and runs the barrier / all-gather) at N = 1 too.  Rank 0 prints ONE JSON line.
 
-The line's `roofline` is what the dominant kernel EXECUTES (FLOP of the 32-row MFMA tiles it issues) over its
-HIP-event launch time, against the dense fp32 MFMA peak; the algorithmic count of the dense reference layers is a
-separate key (the kernel skips duplicate points exactly, so that ratio exceeds 1).  After the timed region (N = 1
-only): the other model families on their BASELINE shapes with a roofline each (`other_models`), the stock
-PyTorch-ROCm eager restatement on the same GPU (`gpu_eager_baseline`), the CPU oracle on the host cores
-(`cpu_baseline`), and the HBM traffic of the dominant kernel from two rocprofv3 counter passes of this script
+Timing: W warm-up steps, then `--repeats` (5) timed regions of EXACTLY K steps each (default K = 30: 2.1 s),
+every region bracketed by barrier + synchronize on both sides and reduced with MAX over ranks; `value` / `ms_per_step` are
+the MEDIAN region's.  The library's HIP-event profiler is OFF in the timed regions; kernel durations come from a separate
+profiled pass afterwards.
+
+`roofline` (dominant kernel = pn_chain_kernel, fp32 MFMA bound): `achieved` / `frac` hold what the kernel EXECUTES - the FLOP of
+the MFMA tiles it issues over its HIP-event launch time (`frac_basis: "executed"`); `frac_useful` counts the coalitions'
+distinct rows only (no tile padding); `frac_algorithmic` is SURVEY 8d's figure, the dense reference layers over all 1024
+rows of every coalition - above 1 because the kernel skips duplicate points, exactly.
+
+`--scaling strong`: ONE cloud's work sharded over the N ranks with the drivers' own code - the 216-pose rotation sweep
+(pose_sweep.sharded_shapley: poses sharded, tools/final_common.py:158) and one 300-pair x 13-ratio interaction setting
+(interaction.compute_order_interaction_logits: pairs sharded, final_point_binary_interaction_logits.py:37), every coalition a
+forward pass (no driver-level de-duplication), plus the share of the step spent in the all-gathers.
+
+After the timed regions (N = 1 only): the other model families on their BASELINE shapes with a roofline each
+(`other_models`), the stock PyTorch-ROCm eager restatement on the same GPU (`gpu_eager_baseline`), the CPU oracle on the host
+cores (`cpu_baseline`), and the HBM traffic of the dominant kernel from two rocprofv3 counter passes of this script
 (`roofline.traffic`; null when the profiler is unavailable).
 """
 import argparse
@@ -50,8 +63,13 @@ SLOT_DOMINANT = 5
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30, help="steps per timed region (30 x 70 ms = 2.1 s)")
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: one cloud per rank (headline); strong: one cloud's pose sweep + interaction setting sharded over the ranks")
+    ap.add_argument("--model", default="pointnet", help="model of the strong-scaling mode")
+    ap.add_argument("--profile-steps", type=int, default=3, help="steps of the separate profiled pass (kernel durations)")
     ap.add_argument("--perms", type=int, default=NUM_PERMS, help="permutations per cloud per step")
     ap.add_argument("--regions", type=int, default=NUM_REGIONS)
     ap.add_argument("--cpu-baseline", type=int, default=1, help="time the CPU oracle on rank 0 at N=1")
@@ -123,8 +141,27 @@ OTHER_MODELS = {
     "pointnet2": {"config": "BASELINE configs[2]", "dense_gflop": 7.83, "kernel": "pn2_group_kernel<128,128,256> (sa2, r=0.8)"},
     "dgcnn": {"config": "BASELINE configs[3]", "dense_gflop": 5.33, "kernel": "pn_gemm_lds_kernel<4,pool> (conv5 + max/mean pool)"},
     "gcnn": {"config": "BASELINE configs[3] (gcnn)", "dense_gflop": 4.79, "kernel": "pn_gemm_lds_kernel<4,pool> (conv5 + max/mean pool)"},
-    "pointconv": {"config": "Shapley shape of configs[2]", "dense_gflop": 2.4, "kernel": "pc_group_kernel<128,128,256> (sa2)"},
+    "pointconv": {"config": "Shapley shape of configs[2]", "dense_gflop": None, "kernel": "pc_group_kernel<128,128,256> (sa2)"},
 }
+
+
+def pointconv_dense_mac(n=1024):
+    """Dense MAC count of models/pointconv.py:324-424 per cloud (the recount SURVEY 8d asks for; its estimate was 1.2 G):
+    per set abstraction the kNN / density distance products (3 per pair), the grouped MLP, DensityNet 1-16-8-1 and WeightNet
+    3-8-8-16 per member, the (C x K).(K x 16) contraction per group and the 16C -> C linear layer; then the classifier."""
+    total = 0
+    for n_in, groups, k, cin, mlp in ((n, 512, 32, 3, (64, 64, 128)), (512, 128, 64, 131, (128, 128, 256)), (128, 1, 128, 259, (256, 512, 1024))):
+        rows = groups * k
+        chain = sum(a * b for a, b in zip((cin,) + mlp[:-1], mlp))
+        total += 3 * n_in * n_in                       # compute_density: square_distance(xyz, xyz), :199-209
+        total += 3 * groups * n_in if groups > 1 else 0  # knn_point: square_distance(new_xyz, xyz), :103-114
+        total += rows * (chain + (16 + 16 * 8 + 8) + (3 * 8 + 8 * 8 + 8 * 16))
+        total += groups * mlp[-1] * k * 16               # new_points x weights, :376-381
+        total += groups * 16 * mlp[-1] * mlp[-1]         # self.linear, :382
+    return total + 1024 * 512 + 512 * 256 + 256 * 10
+
+
+OTHER_MODELS["pointconv"]["dense_gflop"] = 2.0 * pointconv_dense_mac() / 1e9   # 1 206.9 M MAC = 2.414 GFLOP
 
 
 def interaction_workload(regions, num_pairs=300, max_ctx=100, seed=1):
@@ -250,8 +287,8 @@ def measure_traffic():
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
-                   os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-baseline", "0", "--other-models", "0",
-                   "--eager-baseline", "0", "--traffic", "0"]
+                   os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--repeats", "1", "--profile-steps", "1",
+                   "--cpu-baseline", "0", "--other-models", "0", "--eager-baseline", "0", "--traffic", "0"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -277,6 +314,99 @@ def measure_traffic():
     return tot / n, detail
 
 
+def rows_of(keep_np, sizes, regions):
+    """Distinct rows of each coalition (kept points + one centre row when anything is masked)."""
+    bits = ((keep_np[:, None] >> np.arange(regions, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.int64)
+    kept = bits @ sizes
+    return kept + (kept < NUM_POINTS)
+
+
+def strong_scaling(args, rank, world, dev, collectives, rehearsal):
+    """`--scaling strong`: ONE cloud's work through the drivers' own sharded code paths; see the module docstring."""
+    import argparse as ap
+    import torch.distributed as dist
+    from interpret_quality_amd import dist as iqdist
+    from interpret_quality_amd import final_common, hip_ops, interaction, pose_sweep, synth
+    from interpret_quality_amd.final_util import load_model, set_interaction_batch_size, set_model_args, set_shapley_batch_size
+    R = args.regions
+    a = ap.Namespace(model=args.model, dataset="modelnet10", synthetic=True, device=dev, num_points=NUM_POINTS, num_regions=R,
+                     num_samples=100, softmax_type="modified", verbose=False, angle_threshold=pose_sweep.ANGLE_THRESHOLD,
+                     num_grid_enum_rotate=pose_sweep.NUM_GRID_ENUM_ROTATE)
+    set_model_args(a)
+    set_shapley_batch_size(a)
+    set_interaction_batch_size(a)
+    model = load_model(a)
+    pts, label = synth.make_cloud(0)
+    data = torch.from_numpy(pts).unsqueeze(0).to(dev)
+    lbl = torch.tensor([label], device=dev)
+    region_id = hip_ops.region_assign(data[0].contiguous(), hip_ops.fps(data, R)[0].contiguous()).cpu().numpy().astype(np.int64)
+    orders = synth.make_orders(a.num_samples, R, seed=1)
+    params = pose_sweep.generate_rotate_angle(a, dev)
+    poses = torch.cat([pose_sweep.rotate_xyz(data, params[i]) for i in range(params.shape[0])], dim=0)
+    inter = interaction_workload(R)
+    n_sweep = (poses.shape[0] + 1) * a.num_samples * (R + 1)
+    n_inter = sum(4 * p.shape[0] * c.shape[1] for p, c in inter)
+    saved = final_common.distinct_coalitions
+    final_common.distinct_coalitions = lambda k: (np.asarray(k, dtype=np.uint64), np.arange(len(k)))   # every coalition is a forward pass
+    iqdist.GATHER_EVENTS = []
+
+    def step():
+        with contextlib.redirect_stdout(io.StringIO()):
+            pose_sweep.sharded_shapley(model, data, poses, lbl, region_id, orders, a)
+            for pairs, ctx in inter:
+                interaction.compute_order_interaction_logits(model, data, region_id, pairs, ctx, a)
+
+    def fence():
+        if collectives:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    try:
+        for _ in range(args.warmup):
+            step()
+        fence()
+        regions_s, gather_s = [], []
+        for _ in range(args.repeats):
+            iqdist.GATHER_EVENTS.clear()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            el = time.perf_counter() - t0
+            g = sum(s_.elapsed_time(e_) for s_, e_ in iqdist.GATHER_EVENTS) * 1e-3
+            if collectives:
+                t = torch.tensor([el, g], dtype=torch.float64, device="cpu" if rehearsal else dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el, g = float(t[0].item()), float(t[1].item())
+            regions_s.append(el)
+            gather_s.append(g)
+    finally:
+        final_common.distinct_coalitions = saved
+        iqdist.GATHER_EVENTS = None
+    if rank != 0:
+        return
+    k = int(np.argsort(regions_s)[len(regions_s) // 2])
+    elapsed = regions_s[k]
+    total = (n_sweep + n_inter) * args.steps
+    print(json.dumps({
+        "metric": "coalitions/sec (masked forward passes/sec), %s 1024-pt ModelNet10" % ("PointNet" if args.model == "pointnet" else args.model),
+        "value": total / elapsed, "unit": "coalitions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "ONE cloud per step, sharded over the ranks by the drivers' own code: rotation sweep (%d poses + the original) "
+                               "x 100 permutations x %d = %d coalitions, poses sharded; interaction setting 300 pairs x 13 ratios x 4 = %d "
+                               "coalitions, pairs sharded; every coalition evaluated" % (poses.shape[0], R + 1, n_sweep, n_inter),
+                   "model": args.model, "num_points": NUM_POINTS, "num_regions": R,
+                   "parallelism": "%d rank(s); one padded all_gather_into_tensor per cloud (Shapley values, logits) and per ratio (logits)" % world},
+        "timing": {"protocol": "median of %d regions of %d steps, barrier + synchronize around each, MAX over ranks" % (args.repeats, args.steps),
+                   "regions_s": regions_s},
+        "gather": {"seconds_per_step": gather_s[k] / args.steps, "share_of_step": gather_s[k] / elapsed,
+                   "note": "HIP-event time of the all-gathers on the slowest rank (includes waiting for the last rank to arrive, "
+                           "i.e. the shard imbalance: 217 poses and 300 pairs do not divide evenly)"},
+    }), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -288,9 +418,9 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # IQ_BENCH_REHEARSAL=1: rehearse the N > 1 code path on a one-GPU box (all ranks on cuda:0, gloo
+    # IQ_BENCH_REHEARSAL=1 (= IQ_REHEARSAL=1): rehearse the N > 1 code path on a one-GPU box (all ranks on cuda:0, gloo
     # collectives).  Never set by the driver; the numbers of a rehearsal mean nothing.
-    rehearsal = os.environ.get("IQ_BENCH_REHEARSAL") == "1"
+    rehearsal = os.environ.get("IQ_BENCH_REHEARSAL") == "1" or os.environ.get("IQ_REHEARSAL") == "1"
     force_dist = os.environ.get("IQ_FORCE_DIST") == "1"
     if rehearsal:
         local_rank = 0
@@ -302,8 +432,23 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)  # nccl = RCCL on ROCm
+    try:
+        if args.scaling == "strong":
+            strong_scaling(args, rank, world, dev, collectives, rehearsal)
+        else:
+            weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist)
+    finally:
+        if collectives:   # orderly exit: no rank's communicator goes away under a peer (interpret_quality_amd/dist.py: shutdown)
+            try:
+                torch.cuda.synchronize()
+                dist.barrier()
+            finally:
+                dist.destroy_process_group()
 
-    from interpret_quality_amd import _lib, final_common, hip_ops, synth
+
+def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
+    import torch.distributed as dist
+    from interpret_quality_amd import _lib, hip_ops, synth
     from interpret_quality_amd.pointnet import PointNetCls
 
     lib = _lib.load()
@@ -318,26 +463,22 @@ def main():
     fps_idx = hip_ops.fps(data, R)[0].contiguous()
     region_id = hip_ops.region_assign(data[0].contiguous(), fps_idx).reshape(1, -1)
     hip_ops.check_index_range(region_id, 0, R, "region_id")   # once, before timing; the timed calls skip the check
-    orders_np = synth.make_orders(S, R, seed=1)
-    orders = hip_ops.as_i32(orders_np, dev)
-    keep_np = final_common.prefix_keep_masks(orders_np, R)
-    keep = hip_ops.masks_to_tensor(keep_np, dev)
+    np.random.seed(1)                                            # set_random(1), tools/final_util.py:113-120
+    mt_state = hip_ops.mt_state_to_device(dev)                   # the generator the reference samples from, continued on the device
     center = torch.mean(data, dim=1).contiguous()
     n_coal = S * (R + 1)
     # ONE preallocated receive buffer for the per-step all-gather of the logits (132 KB per rank)
     gathered = torch.empty((world * n_coal, 10), dtype=torch.float32, device=dev) if collectives else None
 
     def step():
+        orders = hip_ops.sample_permutations(mt_state, S, R)      # coalition sampling (final_shapley_value.py:59-72)
+        keep = hip_ops.prefix_keep_masks(orders)                   # region masking, as bit masks (tools/final_common.py:56-60)
         logits = model.coalition_logits(data, center, region_id, keep, None, num_regions=R, validate=False)
         v = hip_ops.reward(logits, label, True)
         phi_sum, _, _ = hip_ops.shapley_accum(v, orders)
-        if collectives and rehearsal:     # gloo: stage through the host (gloo's device-tensor path is not what is rehearsed)
-            host = torch.empty((world * n_coal, 10), dtype=torch.float32)
-            dist.all_gather_into_tensor(host, logits.cpu())
-            gathered.copy_(host)
-        elif collectives:
+        if collectives:
             dist.all_gather_into_tensor(gathered, logits)
-        return phi_sum, logits
+        return phi_sum, logits, orders, keep
 
     def fence():
         if collectives:
@@ -346,45 +487,59 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    fence()
-    lib.iq_profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        phi_sum, logits = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    lib.iq_profile_enable(0)
+    regions_s = []
+    for _ in range(max(args.repeats, 1)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            phi_sum, logits, orders, keep = step()
+        fence()
+        el = time.perf_counter() - t0
+        if collectives:
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        regions_s.append(el)
+    elapsed = float(np.sort(regions_s)[len(regions_s) // 2])      # the median region
     if collectives:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         # every rank's chunk of the gather must hold that rank's logits (rank r's own chunk is checkable locally)
         assert torch.equal(gathered[rank * n_coal:(rank + 1) * n_coal], logits), "all-gather returned a wrong chunk"
 
-    # ---- HIP-event durations of the dominant kernel over the timed region ----------------------
+    # sanity on the last timed step: efficiency axiom (sum phi = v(N) - v(empty) for every permutation), and the device sampler
+    # left NumPy's stream where NumPy itself would be after the same number of draws
+    v = hip_ops.reward(logits, label, True)
+    eff = abs(float(phi_sum.sum().item()) / S - float((v[R] - v[0]).item()))
+    assert eff < 1e-3, "efficiency check failed: %g" % eff
+    assert sorted(orders[0].tolist()) == list(range(R)) and int(keep[R].item()) == (-1 if R == 64 else (1 << R) - 1)
+
+    # ---- separate profiled pass: HIP-event durations of the dominant kernel and the rows it executed ----------------------
+    sizes = np.bincount(region_id.cpu().numpy().reshape(-1), minlength=R).astype(np.int64)
+    keeps = []
+    lib.iq_profile_enable(1)
+    for _ in range(max(args.profile_steps, 1)):
+        keeps.append(step()[3])
+    torch.cuda.synchronize()
+    lib.iq_profile_enable(0)
     pre_ms, pre_n, _ = _read_slot(lib, 0)
     f_ms, f_n, _ = _read_slot(lib, 1)
     t_ms, t_n, _ = _read_slot(lib, 2)
     call_ms, call_n, _ = _read_slot(lib, 3)
 
-    # sanity: efficiency axiom on the last step (sum phi = v(N) - v(empty) for every permutation)
-    v = hip_ops.reward(logits, label, True)
-    eff = abs(float(phi_sum.sum().item()) / S - float((v[R] - v[0]).item()))
-    assert eff < 1e-3, "efficiency check failed: %g" % eff
-
     if rank == 0:
         total = n_coal * args.steps * world
-        avg_launch_s = (f_ms + t_ms) / max(f_n + t_n, 1) * 1e-3
+        launches = f_n + t_n
+        launch_s = (f_ms + t_ms) * 1e-3                            # all chain launches of the profiled pass (2 per step)
         # what the chain kernel (feature-STN and trunk instantiations: same shape) executes per launch: each coalition's
         # DISTINCT rows (kept points + the centre), in 32-row MFMA tiles, 143 360 MAC per row
-        sizes = np.bincount(region_id.cpu().numpy().reshape(-1), minlength=R).astype(np.int64)
-        bits = ((keep_np[:, None] >> np.arange(R, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.int64)
-        kept = bits @ sizes
-        rows = kept + (kept < NUM_POINTS)
+        rows = np.concatenate([rows_of(k.cpu().numpy().view(np.uint64), sizes, R) for k in keeps])
         rows32 = (rows + 31) // 32 * 32
-        executed_flop = 2.0 * CHAIN_MAC_PER_ROW * float(rows32.sum())
+        per_launch = 2.0 * CHAIN_MAC_PER_ROW / len(keeps)          # FLOP per row, averaged over the profiled steps
+        executed_flop = per_launch * float(rows32.sum())
+        useful_flop = per_launch * float(rows.sum())
         algorithmic_flop = 2.0 * CHAIN_MAC_PER_ROW * NUM_POINTS * n_coal          # the dense reference layers: all 1024 rows
-        achieved = executed_flop / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+        avg_launch_s = launch_s / max(launches, 1)
+        tf = lambda flop: flop / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0  # noqa: E731
+        achieved = tf(executed_flop)
         step_flops = lib.iq_pointnet_flops_per_coalition(NUM_POINTS) * n_coal
         traffic, traffic_detail = (None, "not measured (N > 1 or --traffic 0)")
         if world == 1 and args.traffic and not force_dist:
@@ -395,23 +550,31 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "PointNet ModelNet10-style Shapley, %d regions x %d permutations per cloud "
-                                   "(%d coalitions per step per GPU), BASELINE configs[1]" % (R, S, n_coal),
+                                   "(%d coalitions per step per GPU), BASELINE configs[1]; permutations sampled and masked on the "
+                                   "device inside the timed step" % (R, S, n_coal),
                        "num_points": NUM_POINTS, "num_regions": R, "permutations": S,
                        "parallelism": "clouds sharded over %d GPU(s), one all_gather_into_tensor of the logits per step%s"
                                       % (world, " (forced single-rank RCCL group)" if force_dist and world == 1 else "")},
+            "timing": {"protocol": "median of %d regions of %d steps, barrier + synchronize around each, MAX over ranks; HIP-event "
+                                   "profiler off" % (len(regions_s), args.steps), "regions_s": regions_s},
             "roofline": {"bound": "mfma", "kernel": "pn_chain_kernel<fstn|trunk>", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "frac_basis": "executed",
+                         "frac_useful": tf(useful_flop) / PEAK_F32_MFMA_TFLOPS,
+                         "frac_algorithmic": tf(algorithmic_flop) / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_detail": traffic_detail,
-                         "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n + t_n,
+                         "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                          "executed_flop_per_launch": executed_flop,
+                         "useful_flop_per_launch": useful_flop,
                          "algorithmic_flop_per_launch": algorithmic_flop,
-                         "algorithmic_tflops": algorithmic_flop / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0,
-                         "algorithmic_vs_executed": algorithmic_flop / executed_flop,
-                         "note": "achieved/frac: FLOP of the 32-row fp32 MFMA tiles the kernel issues / HIP-event launch time / dense "
-                                 "fp32 MFMA peak.  algorithmic_*: the dense reference layers this kernel implements (every coalition, all "
-                                 "1024 rows); the kernel evaluates each coalition's distinct points only (exact, DESIGN.md 3), so the "
-                                 "algorithmic rate exceeds the peak.  traffic: HBM bytes per launch from rocprofv3 FETCH_SIZE x2 + "
-                                 "WRITE_SIZE of this same script, measured now",
+                         "mean_rows_per_coalition": {"distinct": float(rows.mean()), "in_32_row_tiles": float(rows32.mean()), "dense": NUM_POINTS},
+                         "note": "frac_basis executed: achieved / frac = FLOP of the 32-row fp32 MFMA tiles the kernel issues / HIP-event "
+                                 "launch time (separate profiled pass) / dense fp32 MFMA peak.  frac_useful: the coalitions' distinct rows "
+                                 "only (no tile padding).  frac_algorithmic: SURVEY 8d's figure, the dense reference layers this kernel "
+                                 "implements (every coalition, all 1024 rows) - above 1: the kernel evaluates each coalition's distinct "
+                                 "points only, an exact skip (DESIGN.md 3).  traffic: HBM bytes per launch from rocprofv3 FETCH_SIZE x2 "
+                                 "(MI355X_MICROARCH.md: the counter reports half of wide coalesced reads on gfx950) + WRITE_SIZE of this "
+                                 "same script, measured now",
                          "step_tflops_algorithmic": step_flops / (elapsed / args.steps) / 1e12,
                          "prepool_ms_per_launch": pre_ms / max(pre_n, 1), "call_ms": call_ms / max(call_n, 1)},
         }
@@ -425,9 +588,6 @@ def main():
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(R, args.cpu_perms)
         print(json.dumps(out), flush=True)
-    if collectives:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

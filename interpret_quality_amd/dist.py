@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 
 _LOCAL_ONLY = [False]
+GATHER_EVENTS = None   # a list: all_gather_rows appends (start, end) HIP events around its collective (bench.py --scaling strong)
 
 
 @contextlib.contextmanager
@@ -114,7 +115,14 @@ def all_gather_rows(t, n_total):
     # ONE preallocated (w * cap, ...) receive buffer: all_gather_into_tensor writes every rank's chunk in place (the
     # list form of all_gather costs an extra copy per rank on RCCL, and these payloads are latency-bound)
     out = torch.empty((w * cap,) + tail, dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, pad)
+    if GATHER_EVENTS is not None and t.is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        dist.all_gather_into_tensor(out, pad)
+        ev[1].record()
+        GATHER_EVENTS.append(ev)
+    else:
+        dist.all_gather_into_tensor(out, pad)
     if all(c == cap for c in counts):
         return out
     return torch.cat([out[r * cap:r * cap + c] for r, c in enumerate(counts)], dim=0)

@@ -81,6 +81,26 @@ def test_bench_runs_its_collectives_on_rccl_with_a_forced_single_rank_group(tmp_
     assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1
 
 
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_bench_strong_scaling_mode_shards_one_cloud_over_the_ranks(tmp_path, ranks):
+    """`bench.py --scaling strong`: the rotation sweep (poses sharded) and one interaction setting (pairs sharded) of ONE cloud
+    through the drivers' own sharded code, 1 process and 2 ranks (rehearsal: both on cuda:0, gloo)."""
+    bench = os.path.join(REPO, "bench.py")
+    flags = ["--gpus", str(ranks), "--scaling", "strong", "--steps", "1", "--warmup", "0", "--repeats", "1"]
+    if ranks == 1:
+        r = _run([sys.executable, bench] + flags, tmp_path, _env())
+    else:
+        r = _run(_torchrun(2, 29615) + [bench] + flags, tmp_path, _env(IQ_REHEARSAL="1"))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == ranks and d["value"] > 0 and d["unit"] == "coalitions/s"
+    assert "716100" in d["config"]["workload"] and "1238400" in d["config"]["workload"]
+    assert 0.0 <= d["gather"]["share_of_step"] < 1.0
+    if ranks == 1:
+        assert d["gather"]["share_of_step"] == 0.0   # a single process has no collective on its path
+
+
 def test_stage_scripts_give_the_same_artefacts_through_a_forced_rccl_group(tmp_path):
     """Stage 1 and the scale sweep with the gather / barrier path on RCCL (single rank) against the collective-free run."""
     common = ["--model", "pointnet", "--dataset", "modelnet10", "--synthetic", "--num_clouds", "1"]

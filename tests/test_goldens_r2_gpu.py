@@ -199,28 +199,39 @@ def test_dgcnn_parity_rate_at_scale():
 @pytest.mark.parametrize("name", ["dgcnn", "gcnn"])
 def test_context_averaged_interactions_at_scale(name):
     """What the paper publishes from these logits is not a single I_ij(S) but its average over the sampled contexts
-    (final_cal_interactions.py:28-36 then plot_interaction.py:40-41: `I.mean()` and `|I.mean(axis=1)|.mean()` per order).  On
-    the 2016-coalition fixtures, DGCNN and GCNN: per (pair, order) the context mean of I_ij is within 1e-4 * max|v| of the
-    reference's, and so are the two published per-order figures.  GCNN (one fixed xyz graph) additionally holds 1e-4 on every
-    single logit row."""
+    (final_cal_interactions.py:28-36 then plot_interaction.py:40-41: `I.mean()` and `|I.mean(axis=1)|.mean()` per order), on the
+    2016-coalition fixtures.
+
+    GCNN (one fixed xyz graph): every logit row, every per-(pair, order) context mean of I_ij and both published per-order
+    figures are within 1e-4 (of max |logit| / max |v|) of the reference's float32 run.
+    DGCNN: the reference's float32 run is itself off its float64 run by more than 1e-4 * max|v| on some (pair, order) means
+    (a coalition on a kNN near-tie, see test_dgcnn_parity_rate_at_scale), so the yardstick is the reference's FLOAT64 result:
+    the two published per-order figures are within 1e-4 * max|v| of it, and the worst per-(pair, order) context mean is within
+    1e-4 * max|v| or, failing that, no farther from it than the reference's own float32 run is."""
     g, _, _, rows = _scale_logits(name)
     label = int(g["label"])
     lbl = torch.tensor([label], device=dev())
     args = argparse.Namespace(model=name, softmax_type="modified", num_regions=32)
-    worst = 0.0
-    for tag, (ctx, got, ref32, _) in rows.items():
+
+    def inter(logits):
+        return interaction.compute_order_interaction(torch.from_numpy(np.ascontiguousarray(logits)).to(dev()), lbl, args)      # (P, C)
+
+    worst_pair, worst_pair_ref, worst_pub = 0.0, 0.0, 0.0
+    for tag, (ctx, got, ref32, ref64) in rows.items():
+        truth = ref32 if name == "gcnn" else ref64
         if name == "gcnn":
             assert np.abs(got - ref32).max() < RTOL * np.abs(ref32).max()
-        i_got = interaction.compute_order_interaction(torch.from_numpy(got).to(dev()), lbl, args)      # (P, C)
-        i_ref = interaction.compute_order_interaction(torch.from_numpy(ref32).to(dev()), lbl, args)
+        i_got, i_true, i_ref32 = inter(got), inter(truth), inter(ref32)
         vmax = np.abs(hip_ops.reward(torch.from_numpy(ref32).reshape(-1, ref32.shape[-1]).to(dev()), label).cpu().numpy()).max()
-        d_pair = np.abs(i_got.mean(axis=1) - i_ref.mean(axis=1)).max() / vmax
-        d_mean = abs(i_got.mean() - i_ref.mean()) / vmax
-        d_abs = abs(np.abs(i_got.mean(axis=1)).mean() - np.abs(i_ref.mean(axis=1)).mean()) / vmax
-        worst = max(worst, d_pair, d_mean, d_abs)
-        assert d_pair < RTOL, "%s %s: context-mean I_ij off by %.2e of max|v|" % (name, tag, d_pair)
-        assert d_mean < RTOL and d_abs < RTOL
-    print("%s: worst context-averaged interaction error %.2e of max |v|" % (name, worst))
+        worst_pair = max(worst_pair, np.abs(i_got.mean(axis=1) - i_true.mean(axis=1)).max() / vmax)
+        worst_pair_ref = max(worst_pair_ref, np.abs(i_ref32.mean(axis=1) - i_true.mean(axis=1)).max() / vmax)
+        d_mean = abs(i_got.mean() - i_true.mean()) / vmax
+        d_abs = abs(np.abs(i_got.mean(axis=1)).mean() - np.abs(i_true.mean(axis=1)).mean()) / vmax
+        worst_pub = max(worst_pub, d_mean, d_abs)
+    print("%s: context-averaged interactions, error in units of max |v|: published per-order figures %.2e, worst (pair, order) mean %.2e "
+          "(the reference's float32 run against the same yardstick: %.2e)" % (name, worst_pub, worst_pair, worst_pair_ref))
+    assert worst_pub < RTOL
+    assert worst_pair < max(RTOL, worst_pair_ref)
 
 
 @pytest.mark.parametrize("name", ["pointnet2", "pointconv"])

@@ -258,3 +258,17 @@ def test_save_pair_single_region_matches_the_reference(tmp_path, monkeypatch):
         assert np.array_equal(np.load(f + "region_pair_list.npy").reshape(-1, 2), g["single_pairs"][off[k]:off[k + 1]].reshape(-1, 2))
         assert int(np.load(f + "max_pose/pose_idx.npy")) == g["max_pose_idx"][k] and int(np.load(f + "min_pose/pose_idx.npy")) == g["min_pose_idx"][k]
         assert np.array_equal(np.load(f + "min_pose/transform_params.npy"), g["angle_tuple"][g["min_pose_idx"][k]])
+
+
+def test_sweep_lpt_assignment_is_balanced_and_deterministic():
+    """tools/sweep.py (BASELINE configs[4]): 360 (model, dataset, cloud) units of very different cost over 8 ranks."""
+    import importlib
+    sweep = importlib.import_module("tools.sweep")
+    models = ["pointnet", "pointnet2", "pointconv", "dgcnn", "gcnn", "gcnn_adv"]
+    units = [(m, d, c) for d in ("modelnet10", "shapenet") for m in models for c in range(30)]
+    costs = [sweep.COST_A[m] for m, _, _ in units]
+    owner = sweep.assign(units, costs, 8)
+    load = [sum(c for c, r in zip(costs, owner) if r == k) for k in range(8)]
+    assert owner == sweep.assign(units, costs, 8) and sorted(set(owner)) == list(range(8))
+    assert max(load) / (sum(costs) / 8) < 1.02
+    assert sweep.assign([1, 2, 3], [1.0, 1.0, 1.0], 1) == [0, 0, 0]

@@ -1,0 +1,45 @@
+"""GPU: tools/sweep.py (BASELINE configs[4]: whole (model, dataset, cloud) units handed to ranks, each rank running the
+complete per-cloud pipeline in one process) against the per-stage scripts run one after the other as scripts/exp_shapley.sh and
+scripts/exp_interaction.sh do: every artefact file bitwise identical - including the sampled permutations, pairs and contexts,
+whose host / device generator streams run on from cloud to cloud and are replayed for the clouds a rank does not own."""
+import os
+import sys
+
+import pytest
+
+from test_dist_gpu import REPO, _artefacts, _assert_same, _env, _run, _torchrun
+
+pytestmark = pytest.mark.gpu
+
+STAGES = "shapley_value,rotate,scale,smoothness,gen_pair,logits,cal"
+SIZES = ["--num_samples_save", "100"]
+PAIRS = ["--num_pairs_random", "5", "--num_save_context_max", "3"]
+
+
+def _per_stage_scripts(work, model, dataset, clouds):
+    common = ["--model", model, "--dataset", dataset, "--synthetic", "--num_clouds", str(clouds)]
+    plan = [("final_shapley_value.py", SIZES), ("final_rotate_center_enum_all.py", []), ("final_scale_center_enum_all.py", []),
+            ("final_smoothness_center_enum_all.py", []), ("final_gen_pair.py", PAIRS),
+            ("final_point_binary_interaction_logits.py", PAIRS), ("final_cal_interactions.py", PAIRS + ["--device_id", "0"])]
+    for script, extra in plan:
+        _run([sys.executable, os.path.join(REPO, script)] + common + extra, work, _env())
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_sweep_writes_the_same_artefacts_as_the_per_stage_scripts(tmp_path, ranks):
+    models, dataset, clouds = ["pointnet", "gcnn"], "modelnet10", 4      # clouds 0 and 3 are interaction samples (final_util.py:26)
+    one, two = tmp_path / "scripts", tmp_path / "sweep"
+    one.mkdir(), two.mkdir()
+    for m in models:
+        _per_stage_scripts(one, m, dataset, clouds)
+    flags = ["--models", ",".join(models), "--datasets", dataset, "--synthetic", "--num_clouds", str(clouds), "--stages", STAGES] + SIZES + PAIRS
+    sweep = os.path.join(REPO, "tools", "sweep.py")
+    if ranks == 1:
+        r = _run([sys.executable, sweep] + flags, two, _env())
+    else:   # two ranks on the one GPU of this box (gloo group: only the phase barriers use it)
+        r = _run(_torchrun(2, 29731) + [sweep] + flags, two, _env(IQ_REHEARSAL="1"))
+    assert "[sweep] done" in r.stdout
+    a, b = _artefacts(one), _artefacts(two)
+    _assert_same(a, b)
+    assert any("interaction_seed1" in k and k.endswith("_pred_interaction.npy") for k in a)
+    assert any(k.endswith("region_sv_all.npy") for k in a) and any("allregion_inc" in k for k in a)
