@@ -184,7 +184,8 @@ class PointConvDensityClsSsg(nn.Module):
     def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None, num_regions=None, validate=True):
         """Same call as PointNetCls.coalition_logits: logits of B coalitions given as region bit masks (the masked clouds are
         written inside the library; sa1 / sa2 groups from the source clouds' sorted neighbour lists, csrc/iq_pointconv.hip).
-        Clouds of other sizes than 512..1024 points go through mask kernel + forward_points in the drivers."""
+        Clouds of more than 1024 points go through mask kernel + forward_points, source cloud by source cloud; fewer than 512
+        points are rejected here as in the dense forward (the architecture samples 512 centroids, models/pointconv.py:403)."""
         if validate:
             hip_ops.check_index_range(region_id, 0, int(num_regions) if num_regions else 64, "region_id")
         eng = self.engine()
@@ -192,6 +193,8 @@ class PointConvDensityClsSsg(nn.Module):
         nc, b = clouds.shape[0], keep.shape[0]
         if cloud_of is None and nc not in (1, b):
             raise _lib.IqError("cloud_of is required when 1 < number of clouds != number of coalitions")
+        if clouds.shape[1] < 512:
+            raise _lib.IqError("PointConv needs at least 512 points per cloud (sa1 samples 512 centroids), got %d" % clouds.shape[1])
         if clouds.shape[1] > 1024:   # beyond the library's coalition entry: mask kernel + forward, source cloud by source cloud
             which = cloud_of if cloud_of is not None else (torch.zeros(b, dtype=torch.int32, device=keep.device) if nc == 1
                                                           else torch.arange(b, dtype=torch.int32, device=keep.device))

@@ -70,3 +70,26 @@ def test_context_keep_masks_kernel_equals_the_host_construction(p, c, m, r):
     want = interaction.context_keep_masks(pairs, ctx, r)
     got = hip_ops.context_keep_masks(hip_ops.as_i32(pairs, dev()), hip_ops.as_i32(ctx, dev())).cpu().numpy().view(np.uint64)
     assert np.array_equal(got, want)
+
+
+def test_gen_context_on_the_device_equals_the_host_loop(tmp_path):
+    """final_gen_pair.py:18-43: the contexts np.random.choice(rest, m, replace=False) draws - the first m entries of a fresh
+    permutation of the R - 2 other regions - continued on the device: every ratio's context list (shape, dtype, entries) and
+    the generator state afterwards equal the reference's host loop."""
+    import argparse
+    from interpret_quality_amd import gen_pair
+    a = argparse.Namespace(num_regions=32, num_pairs_random=40, num_save_context_max=100, ratio=interaction.DEFAULT_RATIOS)
+    np.random.seed(1)
+    pairs = gen_pair.gen_pair_random(a)
+    start = np.random.get_state()
+    gen_pair.gen_context(pairs, str(tmp_path) + "/host_", a)
+    after = np.random.get_state()
+    np.random.set_state(start)
+    a.device = dev()
+    gen_pair.gen_context(pairs, str(tmp_path) + "/dev_", a)
+    got = np.random.get_state()
+    assert got[2] == after[2] and np.array_equal(got[1], after[1])
+    for ratio in a.ratio:
+        h = np.load(str(tmp_path) + "/host_ratio%d_context_list.npy" % int(ratio * 100))
+        d = np.load(str(tmp_path) + "/dev_ratio%d_context_list.npy" % int(ratio * 100))
+        assert h.shape == d.shape and h.dtype == d.dtype and np.array_equal(h, d), ratio
