@@ -531,6 +531,8 @@ struct PairTabs {
     // members inside the radius as a bit mask over the points (bit N, word 32: the centre), and per coalition its kept points
     const uint32_t* ball_bits[3];   // (nc, N+1, 33) each, or null
     const uint32_t* kept_bits;      // (B, 32)
+    const uint64_t* touch[3];       // (nc, N+1) region-reduced tables (pt_regtab_kernel), or null
+    const float* regtab[3];
 };
 
 __device__ __forceinline__ float pt_dist(const float* c, const float* v) {  // ball_query_kernel's expression
@@ -741,9 +743,58 @@ struct GatherArgs {
     const int32_t* cloud_of;   // (B) or null
     const int32_t* map;        // (nc,N+1,N+1)
     const float* feat;         // (rows,C3)
+    const uint64_t* touch;     // (nc,N+1) regions with a member inside the ball of centroid p; 0 = not a "simple" ball (or no region table)
+    const float* regtab;       // (nc,N+1,64,C3) per centroid and region: max over the region's members of the pair rows
     float* out;                // (B,S,ldo) at the scale's column offset
     int ldo, N, S, K, C3, nclouds, B;
 };
+
+// ---- region-reduced pair tables ---------------------------------------------------------------------------------------
+// A group's output is a max over the pair rows of its kept members, and "kept" is a property of a member's REGION.  For a
+// centroid p whose ball (a) does not contain the cloud centre - so no masked point is ever a member - and (b) holds at most
+// K points - so the K-lowest-indices cap never cuts - the members of ANY coalition are exactly the kept points inside, and
+// the output is max over the kept regions r of  T[p][r] = max over the members of region r of row(p, member).  T depends
+// on the source cloud only: it is built once per call (pt_regtab_kernel) and a group then reads one row per kept region that
+// touches its ball (r = 0.4: ~4 rows instead of ~32 member rows; the same rows for every coalition, so they stay in L2).
+// Max is exact and order-free: bit-identical to the member walk (tested with tuning key 5 = 15, which disables the tables).
+// Balls around the centre (6 % at r = 0.4) and over-full balls keep the member walk.
+constexpr int kRegSlots = 64;
+
+__global__ __launch_bounds__(kThreads) void pt_regtab_kernel(const float* __restrict__ feat, const uint32_t* __restrict__ pairs,
+                                                             const int32_t* __restrict__ off, const int32_t* __restrict__ cntp,
+                                                             int row0, const int32_t* __restrict__ region_id, int N, int K, int C3,
+                                                             float* __restrict__ regtab, uint64_t* __restrict__ touch) {
+    extern __shared__ unsigned tab_s[];                 // [kRegSlots][C3] non-negative floats as unsigned (order-preserving)
+    __shared__ unsigned long long touch_s;
+    __shared__ int centre_in;
+    const int p = blockIdx.x, t = threadIdx.x;
+    const int n = cntp[p], rbase = row0 + off[p];
+    const int per = C3 / 4, lanes_j = kThreads / per;
+    if (t == 0) { touch_s = 0ull; centre_in = 0; }
+    for (int e = t; e < kRegSlots * C3; e += kThreads) tab_s[e] = 0u;
+    __syncthreads();
+    const int c4 = t % per;
+    for (int j = t / per; j < n; j += lanes_j) {
+        const int row = rbase + j;
+        const int q = (int)(pairs[row] >> 16);
+        if (q >= N) { if (c4 == 0) centre_in = 1; continue; }
+        const int r = region_id[q];
+        if ((unsigned)r >= (unsigned)kRegSlots) continue;      // a point of no region is masked in every coalition
+        if (c4 == 0) atomicOr(&touch_s, 1ull << r);
+        const f32x4 v = reinterpret_cast<const f32x4*>(feat)[(size_t)row * per + c4];
+        unsigned* dst = tab_s + r * C3 + c4 * 4;
+        atomicMax(dst + 0, __float_as_uint(v[0])); atomicMax(dst + 1, __float_as_uint(v[1]));
+        atomicMax(dst + 2, __float_as_uint(v[2])); atomicMax(dst + 3, __float_as_uint(v[3]));
+    }
+    __syncthreads();
+    const bool simple = !centre_in && n <= K;
+    const unsigned long long tm = simple ? touch_s : 0ull;
+    if (t == 0) touch[p] = tm;
+    if (!simple) return;
+    float* dst = regtab + (size_t)p * kRegSlots * C3;
+    for (int e = t; e < kRegSlots * C3; e += kThreads)
+        if ((tm >> (e / C3)) & 1ull) dst[e] = __uint_as_float(tab_s[e]);
+}
 
 // Two passes per group (its C3 / 4 lanes sit in one wave).  Pass 1: the lanes split the member list, each resolves its
 // members to table rows (member index -> region bit -> row map: three dependent loads, now side by side over the lanes
@@ -768,6 +819,31 @@ __global__ __launch_bounds__(kThreads) void pt_gather_kernel(GatherArgs a) {
     const int32_t* rid = a.region_id + (size_t)c * a.N;
     const int pi = a.fps[(size_t)b * a.S + s];
     const int p = iq::keep_bit(k, rid[pi]) ? pi : a.N;
+    const f32x4* F = reinterpret_cast<const f32x4*>(a.feat);
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};                 // rows are post-ReLU (>= 0) and every group has >= 1 member
+    constexpr int U = 8;
+    if (a.touch) {                                  // a simple ball: one row per kept region that reaches into it
+        unsigned long long regs = a.touch[(size_t)c * (a.N + 1) + p] & k;
+        if (regs) {
+            const f32x4* T = reinterpret_cast<const f32x4*>(a.regtab) + ((size_t)c * (a.N + 1) + p) * kRegSlots * per + c4;
+            bool more = true;
+            while (more) {                          // four rows in flight; a used-up mask repeats its last row (max is idempotent)
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[u] = T[(size_t)__builtin_ctzll(regs) * per];
+                    const unsigned long long nx = regs & (regs - 1);
+                    if (nx) regs = nx; else more = false;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    m[0] = fmaxf(m[0], v[u][0]); m[1] = fmaxf(m[1], v[u][1]); m[2] = fmaxf(m[2], v[u][2]); m[3] = fmaxf(m[3], v[u][3]);
+                }
+            }
+            *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.S + s) * a.ldo + c4 * 4) = m;
+            return;
+        }
+    }
     const int32_t* mrow = a.map + ((size_t)c * (a.N + 1) + p) * (a.N + 1);
     const int16_t* mem = a.idx + ((size_t)b * a.S + s) * a.K;
     const int n = a.cnt[(size_t)b * a.S + s];
@@ -804,9 +880,6 @@ __global__ __launch_bounds__(kThreads) void pt_gather_kernel(GatherArgs a) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- pass 2 ----
-    const f32x4* F = reinterpret_cast<const f32x4*>(a.feat);
-    f32x4 m = {0.f, 0.f, 0.f, 0.f};                 // rows are post-ReLU (>= 0) and every group has >= 1 member
-    constexpr int U = 8;
     for (int j = 0; j < count; j += U) {
         int r[U];
 #pragma unroll
@@ -923,6 +996,7 @@ int run_pn2(const iq_pointnet2_weights* w, const float* xyz, float* logits, cons
             GatherArgs g = *gat;
             g.fps = s.fps1; g.idx = s.idx1[q]; g.cnt = s.cnt1[q]; g.n_unique = s.nu1;
             g.map = tab->map[q]; g.feat = tab->feat[q]; g.C3 = tab->c3[q];
+            g.touch = tab->touch[q]; g.regtab = tab->regtab[q];
             g.out = s.l1 + col; g.ldo = F1; g.N = N; g.S = S1; g.K = w->sa1[q].nsample; g.B = B;
             const int gpb = kThreads / (g.C3 / 4);
             iq::ProfileSpan span(iq::kSlotPrepool, st);
@@ -1015,6 +1089,8 @@ struct WsC {
     float* feat[3];    // (cap, C3)
     uint32_t* ball_bits[3];   // (nc, N+1, 33)
     uint32_t* kept_bits;      // (B, 32)
+    float* regtab[3];         // (nc, N+1, 64, C3) region-reduced pair rows (only the rows of touched regions are ever written or read)
+    uint64_t* touch[3];       // (nc, N+1)
     size_t bytes;
 };
 
@@ -1040,6 +1116,8 @@ WsC carve_c(void* base, int B, int nc, int N) {
     for (int q = 0; q < 3; ++q) s.feat[q] = (float*)take(cap * c3[q] * 4);
     for (int q = 0; q < 3; ++q) s.ball_bits[q] = (uint32_t*)take((size_t)nc * n1 * kBallWords * 4);
     s.kept_bits = (uint32_t*)take((size_t)B * 32 * 4);
+    for (int q = 0; q < 3; ++q) s.regtab[q] = (float*)take((size_t)nc * n1 * kRegSlots * c3[q] * 4);
+    for (int q = 0; q < 3; ++q) s.touch[q] = (uint64_t*)take((size_t)nc * n1 * 8);
     s.bytes = off;
     return s;
 }
@@ -1110,6 +1188,17 @@ extern "C" int iq_pointnet2_coalitions(const iq_pointnet2_weights* w, const floa
         if (row0 > 0) {
             if ((rc = iq::launch_linear(t.h1, sc.l2.cin, sc.l2, t.h2, sc.l2.cout, row0, 1, st))) return rc;
             if ((rc = iq::launch_linear(t.h2, sc.l2.cout, sc.l3, t.feat[q], sc.l3.cout, row0, 1, st))) return rc;
+        }
+        if (iq::tuning(iq::kTuneExperiment) != 15) {   // region-reduced rows of this scale (15: member walk only, A/B and tests)
+            int r0c = 0;
+            for (int c = 0; c < nclouds; ++c) {
+                hipLaunchKernelGGL(pt_regtab_kernel, dim3(n1), dim3(kThreads), (size_t)kRegSlots * sc.l3.cout * 4, st, t.feat[q], t.pairs,
+                                   t.off + ((size_t)c * 3 + q) * n1, t.cntp + ((size_t)c * 3 + q) * n1, r0c, region_id + (size_t)c * N, N,
+                                   sc.nsample, sc.l3.cout, t.regtab[q] + (size_t)c * n1 * kRegSlots * sc.l3.cout, t.touch[q] + (size_t)c * n1);
+                r0c += totals[c * 3 + q];
+            }
+            if ((rc = iq::check_launch("pt_regtab_kernel"))) return rc;
+            tab.touch[q] = t.touch[q]; tab.regtab[q] = t.regtab[q];
         }
     }
     if (tab.use[0] && tab.use[1] && tab.use[2] && N <= 1024 && iq::tuning(iq::kTuneExperiment) != 13) {

@@ -139,3 +139,26 @@ def test_coalitions_with_pair_tables_equal_the_forward_on_masked_clouds(model):
              for k, c in zip(keep, cloud_of)]
     want = model.forward_points(torch.stack(dense))
     assert torch.equal(got, want)   # same arithmetic per member row, max is order-independent
+
+
+def test_region_reduced_tables_equal_the_member_walk(model):
+    """sa1 from the region-reduced pair tables (csrc/iq_pointnet2.hip: pt_regtab_kernel - one row per kept region that reaches
+    into a ball) against the member walk over the pair rows (tuning key 5 = 15): bit-identical logits on 400 random coalitions
+    of two source clouds, among them the empty, the full and single-region ones."""
+    from interpret_quality_amd import _lib
+    d = dev()
+    rng = np.random.default_rng(11)
+    clouds = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in (2, 6)]).to(d)
+    rid = torch.stack([hip_ops.region_assign(clouds[c].contiguous(), hip_ops.fps(clouds[c:c + 1], 32)[0].contiguous()) for c in range(2)])
+    centers = clouds.mean(dim=1)
+    keep = [0, (1 << 32) - 1] + [1 << r for r in range(0, 32, 5)] + [int(x) for x in rng.integers(0, 1 << 32, size=390, dtype=np.uint64)]
+    keep_t = hip_ops.masks_to_tensor(keep, d)
+    co_t = torch.tensor([i % 2 for i in range(len(keep))], dtype=torch.int32, device=d)
+    got = model.coalition_logits(clouds, centers, rid, keep_t, co_t, num_regions=32)
+    lib = _lib.load()
+    lib.iq_set_tuning(5, 15)
+    try:
+        walk = model.coalition_logits(clouds, centers, rid, keep_t, co_t, num_regions=32)
+    finally:
+        lib.iq_set_tuning(5, 0)
+    assert torch.equal(got, walk)
