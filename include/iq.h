@@ -309,8 +309,9 @@ int iq_pointnet2_coalitions(const iq_pointnet2_weights* w, const float* clouds, 
  * int32; tmp = scratch of at least B*N*84 + 16*B + 8192 bytes.
  * Feature-space graphs (C = 64, 128): where the float32 expanded form cannot separate the 20th from the 21st nearest
  * (gap below 1e-5 of the magnitude of the summed terms: rounding noise decides for the reference's float32 path too), the
- * query is re-ranked by -sum (x_i - x_j)^2 accumulated in float64, i.e. the order the reference finds in float64
- * (csrc/iq_dgcnn.hip: knn_refine_kernel; iq_set_tuning(5, 14) keeps the float32 ranking, for A/B runs). */
+ * query's 21 best candidates are re-ranked by -sum (x_i - x_j)^2 accumulated in float64, i.e. the order the reference
+ * finds in float64 (csrc/iq_dgcnn.hip: knn_refine_kernel, 0.7 % of the queries; iq_set_tuning(5, 14) keeps the float32
+ * ranking, for A/B runs). */
 int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes, int B, int N, int C, int k,
            iq_stream_t stream);
 
@@ -417,6 +418,9 @@ int iq_debug_chain_occupancy(void);
  * used unless enabled).  enable != 0 arms and zeroes 8 counters; out_host (8 x u64 or NULL) receives
  * the counters accumulated so far. */
 int iq_debug_stamps(int enable, unsigned long long* out_host);
+/* Debug: counters of the kNN kernels while tuning key 4 = 3 (synchronises the device, reads and clears them): selection rounds, busy
+ * lanes summed over rounds, waves, queries flagged as near-ties, queries re-ranked, their candidates, fall-backs to the full scan. */
+int iq_debug_knn_counters(unsigned long long* out_host /*8, host*/);
 int iq_profile_read(int slot, double* total_ms, int* launches);
 
 #ifdef __cplusplus

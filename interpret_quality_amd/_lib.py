@@ -116,6 +116,7 @@ SIGNATURES = {
     "iq_set_tuning": (_I, [_I, _I]),
     "iq_debug_chain_occupancy": (_I, []),
     "iq_debug_stamps": (_I, [_I, ctypes.POINTER(ctypes.c_ulonglong)]),
+    "iq_debug_knn_counters": (_I, [ctypes.POINTER(ctypes.c_ulonglong)]),
     "iq_profile_read_work": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
     "iq_profile_read": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
 }

@@ -30,7 +30,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kK = 20;  // K_FOR_DGCNN, tools/final_util.py:19
 constexpr float kNearTie = 1e-5f;  // a boundary gap below this fraction of the summed terms' magnitude is re-ranked exactly
-constexpr int kRefineMaxRows = 2048;  // rows of one cloud whose exact distances fit the refinement kernel's LDS
+constexpr int kRefineMaxRows = 1056;  // rows of one cloud whose exact distances fit the refinement kernel's LDS
 constexpr int kRoundLanes = 32;  // an insert round of the kNN selection runs once this many lanes have a queued candidate
 
 // ---- pad xyz (B,N,3) -> (B,N,8) -------------------------------------------------------------------
@@ -276,9 +276,9 @@ __global__ __launch_bounds__(64) void dg_walk_kernel(const int16_t* __restrict__
 // ---- kNN ------------------------------------------------------------------------------------------
 // (A variant with two query tiles per wave and a v_permlane32_swap of the accumulator halves - one top-K list per
 // query instead of two half lists - was measured and dropped: 8 % faster at C = 64, 7 % slower at C = 8, spills at 128.)
-__device__ unsigned long long g_knn_dbg[3];  // rounds, busy lanes summed over rounds, waves (tuning key 4 = 3)
+__device__ unsigned long long g_knn_dbg[8];  // tuning key 4 = 3: rounds, busy lanes summed over rounds, waves | flagged queries, re-ranked queries, their candidates, fall-backs
 __global__ void knn_dbg_fetch_kernel(unsigned long long* dst) {
-    for (int i = 0; i < 3; ++i) { dst[i] = g_knn_dbg[i]; g_knn_dbg[i] = 0; }
+    for (int i = 0; i < 3; ++i) { dst[i] = g_knn_dbg[i]; g_knn_dbg[i] = 0; }   // (the op-level probe reads the selection counters only)
 }
 
 // One wave = one workgroup = 32 queries.  Key fragments come straight from L1/L2 (a key row's C floats are contiguous, so
@@ -289,10 +289,12 @@ __global__ void knn_dbg_fetch_kernel(unsigned long long* dst) {
 // REFINE (the feature-space graphs, C = 64 / 128): the list holds kK + 1 entries.  The 21st nearest tells how well the fp32
 // expanded-form distances separate the neighbourhood from the rest: a query whose boundary gap (or, in a coalition's compact
 // layout, the gap between the weighted centre row and a row next to it) is below kNearTie of the magnitude of the summed terms
-// is FLAGGED (near_tie[row] = 1) and knn_refine_kernel re-ranks it in exact arithmetic.
+// is FLAGGED: near_tie[row] holds its 21st candidate (else -1), its neighbour list the other 20 as raw rows, and
+// knn_refine_kernel re-ranks the 21 in exact arithmetic (bit 20 of the word: the gap is exactly zero - identical rows, as in
+// a dense masked cloud, may hide further candidates - so all rows are ranked).
 template <int C, bool REFINE>
 __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ xx,
-                                                 int16_t* __restrict__ idx, uint8_t* __restrict__ near_tie, Ragged rg, int B,
+                                                 int16_t* __restrict__ idx, int32_t* __restrict__ near_tie, Ragged rg, int B,
                                                  int tiles_per_cloud, int dbg) {
     constexpr int KB = C / 8;
     constexpr int KL = REFINE ? kK + 1 : kK;   // list length
@@ -477,16 +479,39 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
             }
         }
     }
-    if (REFINE && fh == 0) near_tie[(size_t)base + q0 + fl] = flagged ? 1 : 0;
+    if (REFINE && (dbg & 3) == 3) {
+        const int nf = __popcll(__ballot(flagged && fh == 0));
+        if (lane == 0) atomicAdd(&g_knn_dbg[3], (unsigned long long)nf);
+    }
     if (fh == 0) {
         // dbg & 8: the consumer is edge_fused_kernel, which wants the byte address of the row's (swizzled) first float4 in
         // its LDS slice instead of the row index: row * 64 + ((row >> 2) & 3) * 16 (< 65536 for rows < 1024)
         const bool as_addr = (dbg & 8) != 0;
         int16_t* o = idx + ((size_t)base + q0 + fl) * kK;
+        if constexpr (REFINE) {
+            // a flagged query hands its 21 candidates over as they are (raw rows, nothing dropped, -1 for an empty slot)
+            int word = -1;
+            if (flagged) {
+                bool zero_gap = false;
+                double t20 = top.v[0];
 #pragma unroll
-        for (int q = 0; q < kK; ++q) {
-            const int row = drop[q] ? centre : top.index(q);
-            o[q] = (int16_t)(as_addr ? (row << 6) | (((row >> 2) & 3) << 4) : row);
+                for (int q = 1; q < kK; ++q) t20 = fmin(t20, top.v[q]);
+                zero_gap = (float)t20 == (float)top.v[kK];
+                word = (top.v[kK] > -INFINITY ? top.index(kK) : 0x7fff) | (zero_gap ? 1 << 20 : 0);
+            }
+            near_tie[(size_t)base + q0 + fl] = word;
+#pragma unroll
+            for (int q = 0; q < kK; ++q) {
+                const int row = drop[q] ? centre : top.index(q);
+                const int raw = top.v[q] > -INFINITY ? top.index(q) : -1;
+                o[q] = (int16_t)(flagged ? raw : (as_addr ? (row << 6) | (((row >> 2) & 3) << 4) : row));
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kK; ++q) {
+                const int row = drop[q] ? centre : top.index(q);
+                o[q] = (int16_t)(as_addr ? (row << 6) | (((row >> 2) & 3) << 4) : row);
+            }
         }
     }
 }
@@ -500,79 +525,125 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
 // except where two distances agree to ~1e-7 of themselves.  One wave per group of 64 consecutive rows; the few flagged
 // rows of the group are handled one after the other by the whole wave: lane l owns rows l, l + 64, ... of the cloud.
 // Same weighted selection as knn_kernel's epilogue (the centre row of a compact coalition counts mult times).
+// Which rows can belong to the exact top-20 of a flagged query?  Only rows the float32 scores place within the band of
+// the 20th: the 20 of the list, the 21st, and - if THREE rows crowd into a band of 1e-5 - a 22nd, which is ignored (under 1 %
+// of the flagged queries, themselves 0.7 % of all).  So the re-ranking reads 21 rows, not the cloud: one lane per candidate
+// computes the float64 sum, every candidate's rank by (distance, row index) comes from one pass over the candidates with
+// v_readlane, and the cut is knn_kernel's (the centre row of a compact coalition counts mult times).  A first version scored
+// all rows of the cloud per flagged query: 25 GB of L2 reads per 12 000-coalition step, 5 ms.  A gap of exactly zero means
+// identical rows (the masked points of a DENSE masked cloud fill the list with copies and hide the rows behind them): those
+// queries rank all live rows by their float64 scores (LDS, best first) - the dense forward's price, not the coalition path's.
+// One wave per 64 consecutive rows; its flagged queries one after the other.
 template <int C>
-__global__ __launch_bounds__(64) void knn_refine_kernel(const float* __restrict__ x, int ldx, const uint8_t* __restrict__ near_tie,
-                                                        int16_t* __restrict__ idx, Ragged rg, int B, int as_addr) {
-    __shared__ __attribute__((aligned(16))) float qs[C];
+__global__ __launch_bounds__(64) void knn_refine_kernel(const float* __restrict__ x, int ldx, const int32_t* __restrict__ near_tie,
+                                                        int16_t* __restrict__ idx, Ragged rg, int B, int as_addr, int dbg) {
     __shared__ double dist[kRefineMaxRows];
+    __shared__ __attribute__((aligned(16))) float qs[C];
     const int lane = threadIdx.x;
     const int rows = rg.roff[B];
     const int r0 = blockIdx.x * 64;
     if (r0 >= rows) return;
-    unsigned long long todo = __ballot(r0 + lane < rows && near_tie[r0 + lane] != 0);
+    const int my_word = r0 + lane < rows ? near_tie[r0 + lane] : -1;
+    unsigned long long todo = __ballot(my_word >= 0);
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto shfl_xor_f64 = [](double v, int o) {
+        const long long b = __double_as_longlong(v);
+        const int lo = __shfl_xor((int)(b & 0xffffffffll), o), hi = __shfl_xor((int)(b >> 32), o);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    };
+    auto readlane_f64 = [](double v, int src) {   // src wave-uniform
+        const long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    };
+    // exact score of row j against the query in qs[]: differences in float32, squares summed in float64
+    auto exact_score = [&](const float* xb, int j) {
+        const f32x4* kr = reinterpret_cast<const f32x4*>(xb + (size_t)j * ldx);
+        double acc = 0.0;
+#pragma unroll 8
+        for (int c4 = 0; c4 < C / 4; ++c4) {
+            const f32x4 kv = kr[c4], qv = reinterpret_cast<const f32x4*>(qs)[c4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double df = (double)(qv[e] - kv[e]); acc = __builtin_fma(df, df, acc); }
+        }
+        return -acc;
+    };
     while (todo) {
         const int bit = __builtin_ctzll(todo);
         todo &= todo - 1;
         const int row = r0 + bit;
+        const int word = __shfl(my_word, bit);
         const int b = rg.row_cloud[row];
         const int base = rg.roff[b], centre = rg.nkept[b], mult = rg.ncopy[b];
         const int live = centre + (mult > 0 ? 1 : 0);
-        if (live > kRefineMaxRows) continue;   // (wave-uniform) larger clouds keep the float32 ranking
         const float* xb = x + (size_t)base * ldx;
+        int16_t* o = idx + (size_t)row * kK;
+        // the candidates as knn_kernel left them
+        int jc = -1;
+        if (lane < kK) jc = o[lane];
+        else if (lane == kK) jc = (word & 0x7fff) == 0x7fff ? -1 : (word & 0x7fff);
         if (lane < C / 4) reinterpret_cast<f32x4*>(qs)[lane] = *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + 4 * lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int j = lane; j < live; j += 64) {
-            const f32x4* kr = reinterpret_cast<const f32x4*>(xb + (size_t)j * ldx);
-            double acc = 0.0;
-#pragma unroll 4
-            for (int c4 = 0; c4 < C / 4; ++c4) {
-                const f32x4 kv = kr[c4], qv = reinterpret_cast<const f32x4*>(qs)[c4];
+        wave_sync();
+        int mine = centre;   // lane n < kK ends with the n-th neighbour
+        const bool full = (word >> 20) & 1;
+        if (dbg && lane == 0) {
+            atomicAdd(&g_knn_dbg[4], 1ull);
+            atomicAdd(&g_knn_dbg[6], full ? 1ull : 0ull);
+        }
+        if (!full || live > kRefineMaxRows) {
+            const bool valid = jc >= 0 && jc < live;
+            const double dc = valid ? exact_score(xb, jc) : -INFINITY;
+            const int jv = valid ? jc : 0x7fffffff;
+            int rank = 0, rank_centre = 0x7fffffff;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const double df = (double)(qv[e] - kv[e]);
-                    acc = __builtin_fma(df, df, acc);
+            for (int c = 0; c <= kK; ++c) {       // candidates ahead of mine by (distance, then row index)
+                const double d2 = readlane_f64(dc, c);
+                const int j2 = __builtin_amdgcn_readlane(jv, c);
+                rank += (d2 > dc || (d2 == dc && j2 < jv)) ? 1 : 0;
+            }
+            if (mult > 0) {   // where the weighted centre row stands
+                const unsigned long long isc = __ballot(valid && jc == centre);
+                if (isc) rank_centre = __builtin_amdgcn_readlane(rank, __builtin_ctzll(isc));
+            }
+            // position of my row in the multiset order: rows behind the centre are pushed back by its mult - 1 copies
+            const int posn = rank + (rank > rank_centre ? mult - 1 : 0);
+            const bool in = valid && posn < kK && rank < kK;
+#pragma unroll
+            for (int n = 0; n < kK; ++n) {        // neighbour n = the included candidate of rank n (the included ranks are a prefix)
+                const unsigned long long who = __ballot(in && rank == n);
+                if (who) { const int jn = __builtin_amdgcn_readlane(jc, __builtin_ctzll(who)); if (lane == n) mine = jn; }
+            }
+        } else {
+            for (int j = lane; j < live; j += 64) dist[j] = exact_score(xb, j);
+            wave_sync();
+            int n_out = 0, pos = 0;
+            while (pos < kK && n_out < kK) {
+                double bv = -INFINITY;
+                int bj = 0x7fffffff;
+                for (int j = lane; j < live; j += 64) {
+                    const double d = dist[j];
+                    if (d > bv) { bv = d; bj = j; }   // ascending j: the first of equal values stays
                 }
-            }
-            dist[j] = -acc;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // best first: the next row in order of (distance, then index) until the neighbourhood holds kK points
-        int mine = centre, n_out = 0, pos = 0;   // lane n holds the n-th neighbour; pos = points taken so far (the centre counts mult)
-        while (pos < kK && n_out < kK) {
-            double bv = -INFINITY;
-            int bj = 0x7fffffff;
-            for (int j = lane; j < live; j += 64) {
-                const double d = dist[j];
-                if (d > bv) { bv = d; bj = j; }   // ascending j: the first of equal values stays
-            }
-            double m = bv;
+                double m = bv;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const long long mb = __double_as_longlong(m);
-                const int lo = __shfl_xor((int)(mb & 0xffffffffll), o), hi = __shfl_xor((int)(mb >> 32), o);
-                m = fmax(m, __longlong_as_double(((long long)hi << 32) | (unsigned int)lo));
-            }
-            if (!(m > -INFINITY)) break;          // the cloud has fewer live rows than slots: the rest stays the centre
-            int cand = bv == m ? bj : 0x7fffffff;
+                for (int o2 = 32; o2 >= 1; o2 >>= 1) m = fmax(m, shfl_xor_f64(m, o2));
+                if (!(m > -INFINITY)) break;          // fewer live rows than slots: the rest stays the centre
+                int win = bv == m ? bj : 0x7fffffff;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
-            if ((cand & 63) == lane) dist[cand] = -INFINITY;
-            if (lane == n_out) mine = cand;
-            ++n_out;
-            pos += (cand == centre && mult > 0) ? mult : 1;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int o2 = 32; o2 >= 1; o2 >>= 1) win = min(win, __shfl_xor(win, o2));
+                if ((win & 63) == lane) dist[win] = -INFINITY;
+                if (lane == n_out) mine = win;
+                ++n_out;
+                pos += (win == centre && mult > 0) ? mult : 1;
+                wave_sync();
+            }
         }
-        if (lane < kK) {
-            const int r = lane < n_out ? mine : centre;
-            idx[(size_t)row * kK + lane] = (int16_t)(as_addr ? (r << 6) | (((r >> 2) & 3) << 4) : r);
-        }
-        __builtin_amdgcn_wave_barrier();
+        if (lane < kK) o[lane] = (int16_t)(as_addr ? (mine << 6) | (((mine >> 2) & 3) << 4) : mine);
+        wave_sync();   // qs is rewritten for the next flagged query
     }
 }
 
@@ -939,8 +1010,8 @@ __global__ __launch_bounds__(kThreads) void pool_reduce_kernel(const float* __re
 }
 
 // slice_addr: write the neighbours as LDS addresses for edge_fused_kernel (rows < 1024) instead of row indices.
-// near_tie: one byte per row (rows = upper bound of the row count), scratch of the exact re-ranking (C = 64 / 128).
-int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, uint8_t* near_tie, int B, int N, int rows, const Ragged& rg,
+// near_tie: one int32 per row (rows = upper bound of the row count), scratch of the exact re-ranking (C = 64 / 128).
+int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, int32_t* near_tie, int B, int N, int rows, const Ragged& rg,
                hipStream_t st, bool slice_addr = false) {
     const int tiles = (N + 31) / 32;
     dim3 grid((unsigned)((B + 7) / 8 * 8 * tiles));
@@ -952,10 +1023,10 @@ int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, ui
     else if (C == 128 && !refine) hipLaunchKernelGGL((knn_kernel<128, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
     else if (C == 64) {
         hipLaunchKernelGGL((knn_kernel<64, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
-        hipLaunchKernelGGL(knn_refine_kernel<64>, rgrid, dim3(64), 0, st, x, ldx, near_tie, idx, rg, B, slice_addr ? 1 : 0);
+        hipLaunchKernelGGL(knn_refine_kernel<64>, rgrid, dim3(64), 0, st, x, ldx, near_tie, idx, rg, B, slice_addr ? 1 : 0, (dbg & 3) == 3);
     } else if (C == 128) {
         hipLaunchKernelGGL((knn_kernel<128, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
-        hipLaunchKernelGGL(knn_refine_kernel<128>, rgrid, dim3(64), 0, st, x, ldx, near_tie, idx, rg, B, slice_addr ? 1 : 0);
+        hipLaunchKernelGGL(knn_refine_kernel<128>, rgrid, dim3(64), 0, st, x, ldx, near_tie, idx, rg, B, slice_addr ? 1 : 0, (dbg & 3) == 3);
     } else return iq::fail(IQ_EUNSUPPORTED, "knn: C=%d has no kernel instantiation (8, 64, 128)", C);
     return iq::check_launch("knn_kernel");
 }
@@ -966,7 +1037,7 @@ struct WsD {
     float* pq;      // (B,N,512)
     float* xx;      // (B,N)
     int16_t* idx;   // (B,N,20)
-    uint8_t* near_tie;  // (B,N) queries whose neighbourhood boundary the float32 distances cannot decide
+    int32_t* near_tie;  // (B,N) 21st candidate of a query whose neighbourhood boundary the float32 distances cannot decide, else -1
     float* h;       // (B*N/32, 2, 1024) per-tile max / weighted sum of conv5
     float *g, *f1, *f2;
     int32_t *roff, *nkept, *ncopy, *dpad, *row_cloud;  // ragged layout
@@ -988,7 +1059,7 @@ WsD carve_d(void* base, int B, int N) {
     s.pq = (float*)take(r * 512 * 4);
     s.xx = (float*)take(r * 4);
     s.idx = (int16_t*)take(r * kK * 2);
-    s.near_tie = (uint8_t*)take(r);
+    s.near_tie = (int32_t*)take(r * 4);
     s.h = (float*)take(r * 64 * 4);  // pooling partials of conv5: (rows/32, 2, 1024)
     s.g = (float*)take((size_t)B * 2048 * 4);
     s.f1 = (float*)take((size_t)B * 512 * 4);
@@ -1009,6 +1080,15 @@ __global__ void widen_idx_kernel(const int16_t* __restrict__ in, int32_t* __rest
 }
 
 }  // namespace
+
+extern "C" int iq_debug_knn_counters(unsigned long long* out_host) {
+    IQ_REQUIRE(out_host, "iq_debug_knn_counters: null pointer");
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_knn_dbg), sizeof(zero)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(g_knn_dbg), zero, sizeof(zero)) != hipSuccess)
+        return iq::fail(IQ_ELAUNCH, "iq_debug_knn_counters: copy failed");
+    return IQ_OK;
+}
 
 extern "C" size_t iq_dgcnn_workspace_bytes(int B, int N) {
     if (B < 0 || N < 0) return 0;
@@ -1031,7 +1111,7 @@ extern "C" int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes,
     float* x0 = reinterpret_cast<float*>(take(r * 8 * 4));
     float* xx = reinterpret_cast<float*>(take(r * 4));
     int16_t* i16 = reinterpret_cast<int16_t*>(take(r * kK * 2));
-    uint8_t* near_tie = reinterpret_cast<uint8_t*>(take(r));
+    int32_t* near_tie = reinterpret_cast<int32_t*>(take(r * 4));
     int32_t* row_cloud = reinterpret_cast<int32_t*>(take(r * 4));
     int32_t* roff = reinterpret_cast<int32_t*>(take((size_t)(B + 1) * 4));
     int32_t* nkept = reinterpret_cast<int32_t*>(take((size_t)B * 4));

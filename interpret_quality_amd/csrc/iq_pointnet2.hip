@@ -591,6 +591,7 @@ struct BitBallArgs {
     int32_t* cnt[3];
     int K[3];
     int N, S, B, nclouds;
+    const uint64_t* touch[3];  // (nc,N+1) per scale, or null: a "simple" ball (pt_regtab_kernel) needs no member list
 };
 
 __global__ __launch_bounds__(kThreads) void pn2_bitball_kernel(BitBallArgs a) {
@@ -603,6 +604,7 @@ __global__ __launch_bounds__(kThreads) void pn2_bitball_kernel(BitBallArgs a) {
     const int n1 = a.N + 1;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
+        if (a.touch[q] && a.touch[q][(size_t)c * n1 + ci]) continue;   // served from the region-reduced table: no list, no count
         const uint32_t* wb = a.bits[q] + ((size_t)c * n1 + ci) * kBallWords;
         const bool centre_in = (wb[a.N >> 5] >> (a.N & 31)) & 1u;     // the centre as a member: bit N
         int16_t* out = a.idx[q] + ((size_t)b * a.S + s) * a.K[q];
@@ -980,6 +982,7 @@ int run_pn2(const iq_pointnet2_weights* w, const float* xyz, float* logits, cons
         for (int q = 0; q < 3; ++q) { ba.bits[q] = tab->ball_bits[q]; ba.idx[q] = s.idx1[q]; ba.cnt[q] = s.cnt1[q]; ba.K[q] = w->sa1[q].nsample; }
         ba.kept = tab->kept_bits; ba.fps = s.fps1; ba.n_unique = s.nu1; ba.cloud_of = gat->cloud_of;
         ba.N = N; ba.S = S1; ba.B = B; ba.nclouds = gat->nclouds;
+        for (int q = 0; q < 3; ++q) ba.touch[q] = tab->use[q] ? tab->touch[q] : nullptr;
         hipLaunchKernelGGL(pn2_bitball_kernel, dim3((S1 + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st, ba);
         if ((rc = iq::check_launch("pn2_bitball_kernel"))) return rc;
     } else if ((rc = launch_ball(xyz, s.nx1, 3, w->sa1, 3, s.idx1, s.cnt1, nullptr, B, N, S1, st))) {

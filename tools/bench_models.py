@@ -121,3 +121,8 @@ sa1, sa2, sa3, call = read(0), read(1), read(2), read(3)
 print("%s: %d coalitions in %.3f s = %.0f coalitions/s | per step: slot0 (sa1 | kNN) %.1f ms, slot1 (sa2 | EdgeConv) %.1f ms, slot2 (sa3 | conv5+pool) %.1f ms, "
       "whole forward calls %.1f ms of %.1f ms" % (a.model, n, dt, n / dt, sa1 / a.steps, sa2 / a.steps, sa3 / a.steps,
                                                    call / a.steps, dt / a.steps * 1e3))
+if "4=3" in a.tune:
+    cnt = (ctypes.c_ulonglong * 8)()
+    _lib.check(lib.iq_debug_knn_counters(cnt), "iq_debug_knn_counters")
+    print("kNN counters: rounds %d, busy lanes %d, waves %d | flagged %d, re-ranked %d, candidates %d (%.1f per query), fall-backs %d"
+          % (cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[5] / max(cnt[4], 1), cnt[6]))
