@@ -144,6 +144,63 @@ def test_gloo_world2_sharded_shapley_matches_single_process(tmp_path):
     assert got["empty"].shape == (1, 2) and float(got["empty"][0, 0]) == 0.0
 
 
+def _stage_like_worker(rank, world, port, out_dir):
+    """What every stage main and tools/sweep.py do around their work: dist.record -> init_from_env -> work -> shutdown."""
+    import time
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+
+    @iqdist.record
+    def main():
+        r, w, _ = iqdist.init_from_env("cpu")                      # gloo
+        assert (r, w) == (rank, world) and iqdist.collectives_on()
+        got = iqdist.sharded_rows(5, lambda lo, hi: torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1))
+        assert got.reshape(-1).tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
+        with iqdist.local_only():                                  # the outer sweep's mode: a world of one for the stage code
+            assert iqdist.world() == 1 and iqdist.rank() == 0 and not iqdist.collectives_on()
+            assert iqdist.shard_range(7) == (0, 7)
+            assert iqdist.group_rank() == rank and iqdist.group_world() == world
+            alone = iqdist.sharded_rows(3, lambda lo, hi: torch.full((hi - lo, 1), float(rank)))
+            assert alone.shape == (3, 1)
+        assert iqdist.world() == world
+        if rank == 0:
+            time.sleep(2.0)            # rank 1 is long done: it must wait in shutdown's barrier, not tear the group down under rank 0
+        iqdist.group_barrier()
+        open(os.path.join(out_dir, "done_%d" % rank), "w").write("ok")
+
+    main()
+    assert not dist.is_initialized()   # record() shut the group down (barrier, then destroy_process_group)
+
+
+def test_gloo_world2_stage_teardown_and_local_only(tmp_path):
+    """The orderly exit every multi-rank stage now takes (dist.shutdown through dist.record) and the sweep driver's
+    local_only() mode, on two gloo ranks one of which finishes two seconds before the other."""
+    mp.spawn(_stage_like_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(str(tmp_path))) == ["done_0", "done_1"]
+
+
+def _failing_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+
+    @iqdist.record
+    def main():
+        iqdist.init_from_env("cpu")
+        assert dist.is_initialized()
+        raise ValueError("boom on rank %d" % rank)
+
+    try:
+        main()
+    except ValueError:
+        assert not dist.is_initialized()   # no barrier after a failure (the peers may never reach it), but the group is gone
+        return
+    raise AssertionError("the exception must travel on")
+
+
+def test_a_failing_stage_drops_its_group_without_waiting_for_the_peers():
+    mp.spawn(_failing_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
 def test_modelnet_loader_and_sample_names_match_reference(tmp_path, monkeypatch):
     """final_data_shapley.py:10-69, tools/final_util.py:265-283 on the miniature dataset tree."""
     import argparse
