@@ -57,6 +57,7 @@ sys.path.insert(0, REPO)
 NUM_POINTS, NUM_REGIONS, NUM_PERMS = 1024, 32, 1000
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak (no xf32/TF32 on gfx950)
 CHAIN_MAC_PER_ROW = 143360.0  # 64*64 + 64*128 + 128*1024: the MFMA layers of one chain-kernel row
+CHAIN_MAC_L12, CHAIN_MAC_L3 = 64 * 64 + 64 * 128, 128 * 1024   # layers 1-2 run in 32-row tiles, layer 3 ends on a 16-row tile
 SLOT_DOMINANT = 5
 
 
@@ -533,9 +534,10 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
         # DISTINCT rows (kept points + the centre), in 32-row MFMA tiles, 143 360 MAC per row
         rows = np.concatenate([rows_of(k.cpu().numpy().view(np.uint64), sizes, R) for k in keeps])
         rows32 = (rows + 31) // 32 * 32
-        per_launch = 2.0 * CHAIN_MAC_PER_ROW / len(keeps)          # FLOP per row, averaged over the profiled steps
-        executed_flop = per_launch * float(rows32.sum())
-        useful_flop = per_launch * float(rows.sum())
+        rows_l3 = np.where((rows - 1) % 32 < 16, (rows + 15) // 16 * 16, rows32)   # l3_tail16: a last tile of <= 16 rows is a 16-row tile
+        per_launch = 2.0 / len(keeps)                              # FLOP per MAC, averaged over the profiled steps
+        executed_flop = per_launch * (CHAIN_MAC_L12 * float(rows32.sum()) + CHAIN_MAC_L3 * float(rows_l3.sum()))
+        useful_flop = per_launch * CHAIN_MAC_PER_ROW * float(rows.sum())
         algorithmic_flop = 2.0 * CHAIN_MAC_PER_ROW * NUM_POINTS * n_coal          # the dense reference layers: all 1024 rows
         avg_launch_s = launch_s / max(launches, 1)
         tf = lambda flop: flop / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0  # noqa: E731
@@ -567,9 +569,11 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
                          "executed_flop_per_launch": executed_flop,
                          "useful_flop_per_launch": useful_flop,
                          "algorithmic_flop_per_launch": algorithmic_flop,
-                         "mean_rows_per_coalition": {"distinct": float(rows.mean()), "in_32_row_tiles": float(rows32.mean()), "dense": NUM_POINTS},
-                         "note": "frac_basis executed: achieved / frac = FLOP of the 32-row fp32 MFMA tiles the kernel issues / HIP-event "
-                                 "launch time (separate profiled pass) / dense fp32 MFMA peak.  frac_useful: the coalitions' distinct rows "
+                         "mean_rows_per_coalition": {"distinct": float(rows.mean()), "in_32_row_tiles": float(rows32.mean()),
+                                                     "layer3_tiles_16_row_tail": float(rows_l3.mean()), "dense": NUM_POINTS},
+                         "note": "frac_basis executed: achieved / frac = FLOP of the fp32 MFMA tiles the kernel issues (32-row tiles; layer 3, 91 % "
+                                 "of the work, ends on a 16-row tile when the last tile holds <= 16 rows) / HIP-event launch time (separate "
+                                 "profiled pass) / dense fp32 MFMA peak.  frac_useful: the coalitions' distinct rows "
                                  "only (no tile padding).  frac_algorithmic: SURVEY 8d's figure, the dense reference layers this kernel "
                                  "implements (every coalition, all 1024 rows) - above 1: the kernel evaluates each coalition's distinct "
                                  "points only, an exact skip (DESIGN.md 3).  traffic: HBM bytes per launch from rocprofv3 FETCH_SIZE x2 "

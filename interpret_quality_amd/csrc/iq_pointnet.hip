@@ -57,6 +57,7 @@ struct ChainArgs {
     float* out;                // (items,1024)
     int32_t* argrow;           // (items,1024) point index of the row that attains each column maximum, or null [ARGMAX trunk only]
     int N, R, items, nclouds, with_centre;
+    int tail16;                  // last m-tile of an item on 16x16x4 MFMAs when it holds at most 16 rows (l3_tail16)
     unsigned long long* stamps;  // diagnostic build only
 };
 
@@ -156,6 +157,54 @@ __device__ __forceinline__ void l3_pass_v2(const WBuf& w3, const float* abase, i
             for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? fmaxf(runmax[i], m) : runmax[i];
         }
         wq = wn;
+    }
+}
+
+// L3 for a LAST m-tile of at most 16 rows (rows row0 .. row0 + 15 of act2): v_mfma_f32_16x16x4_f32 instead of a 32-row tile
+// of which half would be padding (a coalition's row count is uniform mod 32, so this saves a quarter tile per coalition and
+// chain on average: 1.5 % of the kernel).  BIT-IDENTICAL to the 32x32x2 path: that instruction accumulates its two k values
+// (8 kb + j for half h = 0, 8 kb + 4 + j for h = 1) and the 16x16x4 instruction its four as ONE sequential fma chain in operand
+// order, so feeding the four lane groups kq = 0..3 with k = (j, 4 + j, j + 1, 5 + j), j = 0 then 2, repeats the chain of the
+// steps (j, j + 1) of a k-block exactly (tools/micro/mfma_tail.hip: 0 of 102 400 outputs differ; the plain k order differs in
+// 77 %).  Both operands come out of the SAME images: lane (r16 = lane & 15, kq) reads the float4 of act2 row row0 + r16 at
+// k = 8 kb + 4 (kq & 1) and the float4 of weight-fragment lane (16 half + r16) + 32 (kq & 1), and takes elements (kq >> 1) and
+// (kq >> 1) + 2.  C layout of 16x16x4: element i of lane l = row 4 (l >> 4) + i, column l & 15.
+__device__ __forceinline__ void l3_tail16(const WBuf& w3, const float* act2, int row0, int wave_s, int lane, float (&runmax)[8]) {
+    const int r16 = lane & 15, kq = lane >> 4, hsel = kq & 1;
+    const bool odd = (kq >> 1) != 0;
+    float a0[16], a1[16];
+    const float* arow = act2 + (row0 + r16) * kLd2 + 4 * hsel;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(arow + 8 * kb);
+        a0[kb] = odd ? v[1] : v[0];
+        a1[kb] = odd ? v[3] : v[2];
+    }
+    const int voff0 = (r16 + 32 * hsel) * 16, voff1 = (16 + r16 + 32 * hsel) * 16;   // bytes inside a fragment, column halves 0 / 1
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {
+        const int wq = (q * 4 + wave_s) * 16 * kFragBytes;
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+        f32x4 b0n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w3.rsrc, voff0, wq, 0));
+        f32x4 b1n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w3.rsrc, voff1, wq, 0));
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            const f32x4 b0 = b0n, b1 = b1n;
+            if (kb + 1 < 16) {
+                b0n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w3.rsrc, voff0, wq + (kb + 1) * kFragBytes, 0));
+                b1n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w3.rsrc, voff1, wq + (kb + 1) * kFragBytes, 0));
+            }
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], odd ? b0[1] : b0[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], odd ? b1[1] : b1[0], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], odd ? b0[3] : b0[2], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], odd ? b1[3] : b1[2], c1, 0, 0, 0);
+        }
+        float m0 = fmaxf(fmaxf(c0[0], c0[1]), fmaxf(c0[2], c0[3])), m1 = fmaxf(fmaxf(c1[0], c1[1]), fmaxf(c1[2], c1[3]));
+        m0 = fmaxf(m0, __shfl_xor(m0, 16)); m1 = fmaxf(m1, __shfl_xor(m1, 16));
+        m0 = fmaxf(m0, __shfl_xor(m0, 32)); m1 = fmaxf(m1, __shfl_xor(m1, 32));
+        const float m = (lane & 16) ? m1 : m0;            // lane l keeps column l & 31 of the n-tile, as the 32x32 path does
+#pragma unroll
+        for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? fmaxf(runmax[i], m) : runmax[i];
     }
 }
 
@@ -338,8 +387,10 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
             if (mts == 2) l3_pass_v0<2>(w3b, a2base, wave_s, runmax);
             else          l3_pass_v0<1>(w3b, a2base, wave_s, runmax);
         } else {
-            if (mts == 2) l3_pass_v2<2, ARGMAX>(w3b, a2base, wave_s, runmax, ring, runarg, ch * kMC, frag_h);
-            else          l3_pass_v2<1, ARGMAX>(w3b, a2base, wave_s, runmax, ring, runarg, ch * kMC, frag_h);
+            const bool tail = !ARGMAX && a.tail16 && rows_here - 32 * (mts - 1) <= 16;   // (uniform) the last m-tile holds <= 16 rows
+            if (mts == 2 && !tail) l3_pass_v2<2, ARGMAX>(w3b, a2base, wave_s, runmax, ring, runarg, ch * kMC, frag_h);
+            else if (mts == 2 || !tail) l3_pass_v2<1, ARGMAX>(w3b, a2base, wave_s, runmax, ring, runarg, ch * kMC, frag_h);
+            if (tail) l3_tail16(w3b, bufA, 32 * (mts - 1), wave_s, lane, runmax);
         }
         IQ_STAMP(6);
     }
@@ -699,6 +750,7 @@ extern "C" int iq_pointnet_coalitions_crt(const iq_pointnet_weights* w, const fl
     a.item_order = nullptr;
     a.N = N; a.R = R; a.nclouds = nclouds; a.with_centre = with_centre;
     a.stamps = g_stamps;
+    a.tail16 = iq::tuning(iq::kTuneExperiment) != 16;   // 16: 32-row tiles only (A/B and tests)
 
     // 1. input-STN chain, pre-pooled per (cloud, region) [+ centre]
     a.cloud_of = nullptr; a.trans = nullptr;
