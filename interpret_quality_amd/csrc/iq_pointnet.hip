@@ -169,7 +169,8 @@ __device__ __forceinline__ void l3_pass_v2(const WBuf& w3, const float* abase, i
 // 77 %).  Both operands come out of the SAME images: lane (r16 = lane & 15, kq) reads the float4 of act2 row row0 + r16 at
 // k = 8 kb + 4 (kq & 1) and the float4 of weight-fragment lane (16 half + r16) + 32 (kq & 1), and takes elements (kq >> 1) and
 // (kq >> 1) + 2.  C layout of 16x16x4: element i of lane l = row 4 (l >> 4) + i, column l & 15.
-__device__ __forceinline__ void l3_tail16(const WBuf& w3, const float* act2, int row0, int wave_s, int lane, float (&runmax)[8]) {
+__device__ __forceinline__ void l3_tail16(const WBuf& w3, const float* act2, int row0, int wave_s, int lane, float (&runmax)[8],
+                                          BRing& ring) {
     const int r16 = lane & 15, kq = lane >> 4, hsel = kq & 1;
     const bool odd = (kq >> 1) != 0;
     float a0[16], a1[16];
@@ -181,23 +182,29 @@ __device__ __forceinline__ void l3_tail16(const WBuf& w3, const float* act2, int
         a1[kb] = odd ? v[3] : v[2];
     }
     const int voff0 = (r16 + 32 * hsel) * 16, voff1 = (16 + r16 + 32 * hsel) * 16;   // bytes inside a fragment, column halves 0 / 1
+    // the B ring of the 32-row passes (dead by now: this is the item's last tile) holds the weight float4s of 4 k-blocks x 2
+    // column halves, 4 k-blocks (16 MFMAs = 512 cycles) ahead, rolling over the n-tile boundaries
+    const int w0 = wave_s * 16 * kFragBytes;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        ring.r[2 * d] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w3.rsrc, voff0, w0 + d * kFragBytes, 0));
+        ring.r[2 * d + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w3.rsrc, voff1, w0 + d * kFragBytes, 0));
+    }
+    int wq = w0;
 #pragma unroll 1
     for (int q = 0; q < 8; ++q) {
-        const int wq = (q * 4 + wave_s) * 16 * kFragBytes;
+        const int wn = (q < 7) ? wq + 4 * 16 * kFragBytes : w0;
         f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-        f32x4 b0n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w3.rsrc, voff0, wq, 0));
-        f32x4 b1n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w3.rsrc, voff1, wq, 0));
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb) {
-            const f32x4 b0 = b0n, b1 = b1n;
-            if (kb + 1 < 16) {
-                b0n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w3.rsrc, voff0, wq + (kb + 1) * kFragBytes, 0));
-                b1n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w3.rsrc, voff1, wq + (kb + 1) * kFragBytes, 0));
-            }
+            const f32x4 b0 = ring.r[2 * (kb & 3)], b1 = ring.r[2 * (kb & 3) + 1];
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], odd ? b0[1] : b0[0], c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], odd ? b1[1] : b1[0], c1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], odd ? b0[3] : b0[2], c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], odd ? b1[3] : b1[2], c1, 0, 0, 0);
+            const int soff = kb < 12 ? wq + (kb + 4) * kFragBytes : wn + (kb - 12) * kFragBytes;
+            ring.r[2 * (kb & 3)] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w3.rsrc, voff0, soff, 0));
+            ring.r[2 * (kb & 3) + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w3.rsrc, voff1, soff, 0));
         }
         float m0 = fmaxf(fmaxf(c0[0], c0[1]), fmaxf(c0[2], c0[3])), m1 = fmaxf(fmaxf(c1[0], c1[1]), fmaxf(c1[2], c1[3]));
         m0 = fmaxf(m0, __shfl_xor(m0, 16)); m1 = fmaxf(m1, __shfl_xor(m1, 16));
@@ -205,6 +212,7 @@ __device__ __forceinline__ void l3_tail16(const WBuf& w3, const float* act2, int
         const float m = (lane & 16) ? m1 : m0;            // lane l keeps column l & 31 of the n-tile, as the 32x32 path does
 #pragma unroll
         for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? fmaxf(runmax[i], m) : runmax[i];
+        wq = wn;
     }
 }
 
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
             const bool tail = !ARGMAX && a.tail16 && rows_here - 32 * (mts - 1) <= 16;   // (uniform) the last m-tile holds <= 16 rows
             if (mts == 2 && !tail) l3_pass_v2<2, ARGMAX>(w3b, a2base, wave_s, runmax, ring, runarg, ch * kMC, frag_h);
             else if (mts == 2 || !tail) l3_pass_v2<1, ARGMAX>(w3b, a2base, wave_s, runmax, ring, runarg, ch * kMC, frag_h);
-            if (tail) l3_tail16(w3b, bufA, 32 * (mts - 1), wave_s, lane, runmax);
+            if (tail) l3_tail16(w3b, bufA, 32 * (mts - 1), wave_s, lane, runmax, ring);
         }
         IQ_STAMP(6);
     }
