@@ -25,13 +25,23 @@ def _per_stage_scripts(work, model, dataset, clouds):
         _run([sys.executable, os.path.join(REPO, script)] + common + extra, work, _env())
 
 
+MODELS, DATASET, CLOUDS = ["pointnet", "gcnn"], "modelnet10", 4      # clouds 0 and 3 are interaction samples (final_util.py:26)
+
+
+@pytest.fixture(scope="module")
+def script_artefacts(tmp_path_factory):
+    """The per-stage scripts, one process each, once for both parametrisations below."""
+    one = tmp_path_factory.mktemp("scripts")
+    for m in MODELS:
+        _per_stage_scripts(one, m, DATASET, CLOUDS)
+    return _artefacts(one)
+
+
 @pytest.mark.parametrize("ranks", [1, 2])
-def test_sweep_writes_the_same_artefacts_as_the_per_stage_scripts(tmp_path, ranks):
-    models, dataset, clouds = ["pointnet", "gcnn"], "modelnet10", 4      # clouds 0 and 3 are interaction samples (final_util.py:26)
-    one, two = tmp_path / "scripts", tmp_path / "sweep"
-    one.mkdir(), two.mkdir()
-    for m in models:
-        _per_stage_scripts(one, m, dataset, clouds)
+def test_sweep_writes_the_same_artefacts_as_the_per_stage_scripts(tmp_path, script_artefacts, ranks):
+    models, dataset, clouds = MODELS, DATASET, CLOUDS
+    two = tmp_path / "sweep"
+    two.mkdir()
     flags = ["--models", ",".join(models), "--datasets", dataset, "--synthetic", "--num_clouds", str(clouds), "--stages", STAGES] + SIZES + PAIRS
     sweep = os.path.join(REPO, "tools", "sweep.py")
     if ranks == 1:
@@ -39,7 +49,7 @@ def test_sweep_writes_the_same_artefacts_as_the_per_stage_scripts(tmp_path, rank
     else:   # two ranks on the one GPU of this box (gloo group: only the phase barriers use it)
         r = _run(_torchrun(2, 29731) + [sweep] + flags, two, _env(IQ_REHEARSAL="1"))
     assert "[sweep] done" in r.stdout
-    a, b = _artefacts(one), _artefacts(two)
+    a, b = script_artefacts, _artefacts(two)
     _assert_same(a, b)
     assert any("interaction_seed1" in k and k.endswith("_pred_interaction.npy") for k in a)
     assert any(k.endswith("region_sv_all.npy") for k in a) and any("allregion_inc" in k for k in a)
