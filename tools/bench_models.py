@@ -124,5 +124,5 @@ print("%s: %d coalitions in %.3f s = %.0f coalitions/s | per step: slot0 (sa1 | 
 if "4=3" in a.tune:
     cnt = (ctypes.c_ulonglong * 8)()
     _lib.check(lib.iq_debug_knn_counters(cnt), "iq_debug_knn_counters")
-    print("kNN counters: rounds %d, busy lanes %d, waves %d | flagged %d, re-ranked %d, candidates %d (%.1f per query), fall-backs %d"
-          % (cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[5] / max(cnt[4], 1), cnt[6]))
+    print("kNN counters: rounds %d, busy lanes %d, waves %d (32 queries each) | flagged %d, re-ranked %d (their 21 candidates), of which zero-gap "
+          "rankings of all rows %d" % (cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[6]))
