@@ -53,3 +53,21 @@ def test_sweep_writes_the_same_artefacts_as_the_per_stage_scripts(tmp_path, scri
     _assert_same(a, b)
     assert any("interaction_seed1" in k and k.endswith("_pred_interaction.npy") for k in a)
     assert any(k.endswith("region_sv_all.npy") for k in a) and any("allregion_inc" in k for k in a)
+
+
+def test_sweep_covers_all_six_models_and_both_datasets_on_two_ranks(tmp_path):
+    """BASELINE configs[4] plumbing: every (model, dataset) pair through the sweep driver, two ranks (rehearsal: both on cuda:0),
+    one cloud each, stage 1 + the scale sweep (the 216-pose sweeps and the interaction stages of every family are covered by the
+    tests above and in test_dist_gpu.py; here the point is that all 12 pairs are assigned, run and written exactly once)."""
+    import glob
+    import json
+    sweep = os.path.join(REPO, "tools", "sweep.py")
+    flags = ["--synthetic", "--num_clouds", "1", "--stages", "shapley_value,scale", "--num_samples_save", "100"]
+    r = _run(_torchrun(2, 29735) + [sweep] + flags, tmp_path, _env(IQ_REHEARSAL="1"))
+    log = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"sweep"')][-1])["sweep"]
+    assert log["world"] == 2 and log["phases"]["A_shapley"]["units"] == 12 and 0 < log["phases"]["A_shapley"]["mine"] < 12
+    for model in ("pointnet", "pointnet2", "pointconv", "dgcnn", "gcnn", "gcnn_adv"):
+        for dataset in ("modelnet10", "shapenet"):
+            root = tmp_path / "checkpoints" / ("exp_MODEL_%s_DATA_%s_POINTNUM_1024_REGIONNUM_32_shapley_test" % (model, dataset)) / "synthetic_00"
+            assert (root / "region_sv_all.npy").exists() and (root / "scale_all" / "region_shapley_value.npy").exists(), (model, dataset)
+    assert len(glob.glob(str(tmp_path / "fps_*_index_final30.npy"))) == 2
