@@ -188,7 +188,8 @@ typedef struct iq_pointnet_weights {
     const float* stn_in;  /* [64][4] = (w0,w1,w2,bias) of feat.stn.conv1+bn1 */
     iq_dense_layer stn_c2, stn_c3, stn_fc1, stn_fc2, stn_fc3;       /* fc3 bias includes +I */
     const float* feat_in; /* [64][4] of feat.conv1+bn1 */
-    iq_dense_layer fstn_c1, fstn_c2, fstn_c3, fstn_fc1, fstn_fc2, fstn_fc3; /* fc3: iq_pack_fstn_fc3 */
+    iq_dense_layer fstn_c1, fstn_c2, fstn_c3, fstn_fc1, fstn_fc2, fstn_fc3; /* fc3: iq_pack_fstn_fc3.  feature_transform = False
+        (models/pointnet.py:62-63): fstn_c1.w = NULL and fstn_fc3.b = the packed identity (iq_pack_fstn_fc3 of a zero layer) */
     iq_dense_layer feat_c2, feat_c3, cls_fc1, cls_fc2, cls_fc3;
 } iq_pointnet_weights;
 

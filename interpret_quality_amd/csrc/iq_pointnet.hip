@@ -590,6 +590,13 @@ __global__ __launch_bounds__(kThreads) void pn_stn_gather_kernel(const float* __
     reinterpret_cast<f32x4*>(out)[(size_t)item * (kFeat / 4) + threadIdx.x] = m;
 }
 
+// every item's 64 x 64 transform := one packed image (4096 floats), float4 per thread
+__global__ __launch_bounds__(kThreads) void pn_fill_rows_kernel(float* __restrict__ out, const float* __restrict__ image, int B) {
+    const size_t t = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= (size_t)B * 1024) return;
+    reinterpret_cast<f32x4*>(out)[t] = reinterpret_cast<const f32x4*>(image)[t & 1023];
+}
+
 template <int MODE>
 void launch_chain(const ChainArgs& a, hipStream_t st) {
     const size_t extra_lds = (size_t)iq::tuning(iq::kTuneExtraLds);  // experiment: lower the occupancy
@@ -786,20 +793,29 @@ extern "C" int iq_pointnet_coalitions_crt(const iq_pointnet_weights* w, const fl
     a.rows = ws.rows; a.nrows = ws.nrows;
     a.item_order = lpt ? ws.order : nullptr;
     a.w_in = w->feat_in;
-    a.w1 = w->fstn_c1.w; a.b1 = w->fstn_c1.b;
-    a.w2 = w->fstn_c2.w; a.b2 = w->fstn_c2.b;
-    a.w3 = w->fstn_c3.w; a.b3 = w->fstn_c3.b;
-    a.out = ws.gbuf;
     a.items = B;
-    {
-        iq::ProfileSpan span(iq::kSlotFstn, st);
-        launch_chain<kFstn>(a, st);
-    }
-    if ((rc = iq::check_launch("pn_chain_kernel<fstn>"))) return rc;
+    a.out = ws.gbuf;
     float* tfp = trans_feat_packed ? trans_feat_packed : ws.tfp;
-    if ((rc = launch_linear(ws.gbuf, kFeat, w->fstn_fc1, ws.h1, 512, B, 1, st))) return rc;
-    if ((rc = launch_linear(ws.h1, 512, w->fstn_fc2, ws.h2, 256, B, 1, st))) return rc;
-    if ((rc = launch_linear(ws.h2, 256, w->fstn_fc3, tfp, 4096, B, 0, st))) return rc;
+    if (w->fstn_c1.w) {
+        a.w1 = w->fstn_c1.w; a.b1 = w->fstn_c1.b;
+        a.w2 = w->fstn_c2.w; a.b2 = w->fstn_c2.b;
+        a.w3 = w->fstn_c3.w; a.b3 = w->fstn_c3.b;
+        {
+            iq::ProfileSpan span(iq::kSlotFstn, st);
+            launch_chain<kFstn>(a, st);
+        }
+        if ((rc = iq::check_launch("pn_chain_kernel<fstn>"))) return rc;
+        if ((rc = launch_linear(ws.gbuf, kFeat, w->fstn_fc1, ws.h1, 512, B, 1, st))) return rc;
+        if ((rc = launch_linear(ws.h1, 512, w->fstn_fc2, ws.h2, 256, B, 1, st))) return rc;
+        if ((rc = launch_linear(ws.h2, 256, w->fstn_fc3, tfp, 4096, B, 0, st))) return rc;
+    } else {
+        // feature_transform = False (models/pointnet.py:62-63,72-78): no feature STN.  The trunk multiplies by the packed
+        // IDENTITY instead (fstn_fc3.b = iq_pack_fstn_fc3 of a zero layer): sum_k f[k] I[k][n] = f[n] + zeros, exact.
+        IQ_REQUIRE(w->fstn_fc3.b, "iq_pointnet_coalitions: without a feature STN, fstn_fc3.b must hold the packed identity");
+        hipLaunchKernelGGL(pn_fill_rows_kernel, dim3((unsigned)(((size_t)B * 1024 + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                           tfp, w->fstn_fc3.b, B);
+        if ((rc = iq::check_launch("pn_fill_rows_kernel"))) return rc;
+    }
 
     // 3. trunk chain
     a.argrow = crt_points;

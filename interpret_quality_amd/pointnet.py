@@ -80,13 +80,17 @@ class PackedWeights:
         dense("stn_fc2", "feat.stn.fc2", "feat.stn.bn5")
         dense("stn_fc3", "feat.stn.fc3", None, extra_bias=np.eye(3).reshape(-1))  # + iden, models/pointnet.py:42-45
         in_layer("feat_in", "feat.conv1", "feat.bn1")
-        dense("fstn_c1", "feat.fstn.conv1", "feat.fstn.bn1")
-        dense("fstn_c2", "feat.fstn.conv2", "feat.fstn.bn2")
-        dense("fstn_c3", "feat.fstn.conv3", "feat.fstn.bn3")
-        dense("fstn_fc1", "feat.fstn.fc1", "feat.fstn.bn4")
-        dense("fstn_fc2", "feat.fstn.fc2", "feat.fstn.bn5")
-        # fc3 of the feature STN: output = packed B image of trans_feat (+ identity)
-        w3, b3 = fold_bn(sd, "feat.fstn.fc3", None)
+        self.feature_transform = "feat.fstn.conv1.weight" in sd
+        if self.feature_transform:
+            dense("fstn_c1", "feat.fstn.conv1", "feat.fstn.bn1")
+            dense("fstn_c2", "feat.fstn.conv2", "feat.fstn.bn2")
+            dense("fstn_c3", "feat.fstn.conv3", "feat.fstn.bn3")
+            dense("fstn_fc1", "feat.fstn.fc1", "feat.fstn.bn4")
+            dense("fstn_fc2", "feat.fstn.fc2", "feat.fstn.bn5")
+            # fc3 of the feature STN: output = packed B image of trans_feat (+ identity)
+            w3, b3 = fold_bn(sd, "feat.fstn.fc3", None)
+        else:   # feature_transform = False: the trunk gets the packed identity (the struct's fstn_c1.w stays NULL)
+            w3, b3 = np.zeros((4096, 256), dtype=np.float32), np.zeros(4096, dtype=np.float32)
         w3 = np.ascontiguousarray(w3)
         b3 = np.ascontiguousarray(b3)
         ow = np.empty(lib.iq_packed_floats(4096, 256), dtype=np.float32)
@@ -160,8 +164,8 @@ class PointNetEngine:
         rid = torch.zeros((b, n), dtype=torch.int32, device=self.device)
         logits, tfp, crt = self.coalition_logits(x.contiguous(), None, rid, None, None, num_regions=1,
                                                  channel_first=True, return_trans_feat=True, return_crt=True)
-        trans_feat = tfp.index_select(1, self.weights.unpack_index).reshape(b, 64, 64)
-        return logits, trans_feat, crt.long()
+        trans_feat = tfp.index_select(1, self.weights.unpack_index).reshape(b, 64, 64) if self.weights.feature_transform else None
+        return logits, trans_feat, crt.long()   # trans_feat is None without a feature STN, as in models/pointnet.py:78
 
 
 def _param_holder_stn(k):
@@ -181,13 +185,13 @@ class PointNetCls(nn.Module):
         self.args = args
         dataset = getattr(args, "dataset", "modelnet10")
         self.output_channels = 40 if dataset == "modelnet40" else 10  # models/pointnet.py:95-98
-        if not getattr(args, "feature_transform", True):
-            raise _lib.IqError("feature_transform=False is not used by the reference path (final_util.py:173,191)")
+        self.feature_transform = bool(getattr(args, "feature_transform", True))   # models/pointnet.py:99 (the scripts set True)
         feat = nn.Module()
         feat.stn = _param_holder_stn(3)
         feat.conv1, feat.conv2, feat.conv3 = nn.Conv1d(3, 64, 1), nn.Conv1d(64, 128, 1), nn.Conv1d(128, 1024, 1)
         feat.bn1, feat.bn2, feat.bn3 = nn.BatchNorm1d(64), nn.BatchNorm1d(128), nn.BatchNorm1d(1024)
-        feat.fstn = _param_holder_stn(64)
+        if self.feature_transform:
+            feat.fstn = _param_holder_stn(64)
         self.feat = feat
         self.fc1, self.fc2, self.fc3 = nn.Linear(1024, 512), nn.Linear(512, 256), nn.Linear(256, self.output_channels)
         self.bn1, self.bn2 = nn.BatchNorm1d(512), nn.BatchNorm1d(256)

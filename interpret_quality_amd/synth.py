@@ -75,8 +75,10 @@ def _stn(sd, prefix, k, seed):
         _bn(sd, "%s.bn%d" % (prefix, j), c, seed)
 
 
-def pointnet_state_dict(seed=0):
-    """Reference-keyed PointNetCls state dict (111 tensors) as numpy arrays."""
+def pointnet_state_dict(seed=0, feature_transform=True):
+    """Reference-keyed PointNetCls state dict (111 tensors; 74 without the feature STN, models/pointnet.py:62-63) as numpy arrays."""
+    if not feature_transform:
+        return {k: v for k, v in pointnet_state_dict(seed).items() if not k.startswith("feat.fstn.")}
     sd = {}
     g = np.sqrt(2.0)
     _stn(sd, "feat.stn", 3, seed)

@@ -164,8 +164,10 @@ def pointnet_forward(sd, x):
     trans = _stn(x, sd, "feat.stn", 3)
     h = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)
     h = F.relu(_bn(_conv(h, sd, "feat.conv1"), sd, "feat.bn1"))
-    trans_feat = _stn(h, sd, "feat.fstn", 64)
-    h = torch.bmm(h.transpose(2, 1), trans_feat).transpose(2, 1)
+    trans_feat = None
+    if "feat.fstn.conv1.weight" in sd:   # feature_transform (models/pointnet.py:72-78); None without it
+        trans_feat = _stn(h, sd, "feat.fstn", 64)
+        h = torch.bmm(h.transpose(2, 1), trans_feat).transpose(2, 1)
     h = F.relu(_bn(_conv(h, sd, "feat.conv2"), sd, "feat.bn2"))
     h = _bn(_conv(h, sd, "feat.conv3"), sd, "feat.bn3")
     g, crt = torch.max(h, 2)

@@ -1,12 +1,14 @@
 """GPU parity tests: the HIP path, called through the C ABI (ctypes), against the CPU oracle and
 the golden vectors generated from the reference.  Bit-exact for masks / indices / reductions over
 given v; 1e-4 relative (the north star's tolerance) for anything that runs the network."""
+import argparse
+
 import numpy as np
 import pytest
 import torch
 
 from conftest import assert_close_elementwise, load_golden
-from interpret_quality_amd import hip_ops, synth
+from interpret_quality_amd import final_common, hip_ops, synth
 from interpret_quality_amd.pointnet import PointNetCls
 
 pytestmark = pytest.mark.gpu
@@ -325,3 +327,27 @@ def test_linear_variants_agree_and_match_fp32_reference(m, cin, cout, act):
     elif act == 2:
         ref = torch.nn.functional.leaky_relu(ref, 0.2)
     assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_pointnet_without_feature_transform():
+    """`feature_transform=False` (models/pointnet.py:62-63,72-78; a constructor option no stage script takes): no feature STN -
+    iq_pointnet_coalitions skips that chain and the trunk multiplies by the packed identity (exact).  Dense forward (logits,
+    trans_feat None, crt_points) and the Shapley path against the reference's own run (pointnet_noft.npz)."""
+    g = load_golden("pointnet_noft.npz")
+    sd = synth.to_torch(synth.pointnet_state_dict(0, feature_transform=False))
+    m = PointNetCls(argparse.Namespace(dataset="modelnet10", feature_transform=False))
+    m.load_state_dict(sd)                                            # strict: the module has no feat.fstn.* parameters
+    m = m.to(dev()).eval()
+    x = torch.stack([torch.from_numpy(synth.make_cloud(int(i))[0]) for i in g["dense_cloud_ids"]]).permute(0, 2, 1).contiguous()
+    logits, trans_feat, crt = m(x.to(dev()))
+    assert trans_feat is None
+    assert np.abs(logits.cpu().numpy() - g["dense_logits"]).max() < RTOL * np.abs(g["dense_logits"]).max()
+    assert (crt.cpu().numpy() != g["dense_crt"]).sum() <= 4             # near-tie flips of an arg-max, as with the feature STN
+    pts, label = synth.make_cloud(int(g["shap_cloud_id"]))
+    args = argparse.Namespace(model="pointnet", softmax_type="modified", num_points=1024, num_regions=8, num_samples=4, shapley_batch_size=2,
+                              verbose=False)
+    phi, shap_logits = final_common.shap_sampling_all_regions_batch(m, torch.from_numpy(pts).unsqueeze(0).to(dev()),
+                                                                    torch.tensor([label], device=dev()), g["region_id"].astype(np.int64),
+                                                                    g["orders"].astype(np.int64), args)
+    assert np.abs(shap_logits.cpu().numpy() - g["shap_logits"]).max() < RTOL * np.abs(g["shap_logits"]).max()
+    assert np.abs(phi - g["phi"]).max() < RTOL * np.abs(g["phi"]).max()

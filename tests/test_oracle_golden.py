@@ -276,3 +276,21 @@ def test_oracle_on_the_32_region_family_fixture(name):
                                                  g[name + "_pairs"][k:k + 1].astype(np.int64),
                                                  g[tag + "_contexts"][k:k + 1].astype(np.int64), 4, is_pointnet=False)
         np.testing.assert_allclose(got.numpy(), g[tag + "_logits"][k:k + 1], rtol=2e-5, atol=2e-5)
+
+
+def test_pointnet_without_feature_transform_matches_reference():
+    """models/pointnet.py:62-63,72-78 (`feature_transform=False`): the oracle without the feature STN against the reference's
+    own run (tests/golden/gen_golden_pointnet_noft.py)."""
+    g = load_golden("pointnet_noft.npz")
+    sd = synth.to_torch(synth.pointnet_state_dict(0, feature_transform=False))
+    assert len(sd) == 74 and not any(k.startswith("feat.fstn.") for k in sd)
+    x = torch.stack([torch.from_numpy(synth.make_cloud(int(i))[0]) for i in g["dense_cloud_ids"]]).permute(0, 2, 1).contiguous()
+    logits, trans_feat, crt = O.PointNetOracle(sd)(x)
+    assert trans_feat is None
+    assert np.abs(logits.numpy() - g["dense_logits"]).max() <= 1e-6 * np.abs(g["dense_logits"]).max()
+    assert np.array_equal(crt.numpy(), g["dense_crt"].astype(np.int64))
+    pts, label = synth.make_cloud(int(g["shap_cloud_id"]))
+    phi, shap_logits = O.shap_sampling_all_regions_batch(O.PointNetOracle(sd), torch.from_numpy(pts).unsqueeze(0), torch.tensor([label]),
+                                                         g["region_id"].astype(np.int64), g["orders"].astype(np.int64), 4, 2, 8)
+    assert np.abs(shap_logits.numpy() - g["shap_logits"]).max() <= 1e-6 * np.abs(g["shap_logits"]).max()
+    assert np.abs(phi - g["phi"]).max() <= 1e-6 * np.abs(g["phi"]).max()
