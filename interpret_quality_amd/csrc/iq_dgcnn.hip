@@ -1016,7 +1016,7 @@ int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, in
     const int tiles = (N + 31) / 32;
     dim3 grid((unsigned)((B + 7) / 8 * 8 * tiles));
     const int dbg = (iq::tuning(iq::kTuneKnnDebug) & 7) | (slice_addr ? 8 : 0);
-    const bool refine = iq::tuning(iq::kTuneExperiment) != 14;   // 14: float32 ranking only (A/B and tests)
+    const bool refine = iq::tuning(iq::kTuneExperiment) != 20;   // 20: float32 ranking only (A/B and tests)
     const dim3 rgrid((unsigned)((rows + 63) / 64));
     if (C == 8) hipLaunchKernelGGL((knn_kernel<8, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
     else if (C == 64 && !refine) hipLaunchKernelGGL((knn_kernel<64, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);

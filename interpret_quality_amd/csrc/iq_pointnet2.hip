@@ -758,7 +758,7 @@ struct GatherArgs {
 // the output is max over the kept regions r of  T[p][r] = max over the members of region r of row(p, member).  T depends
 // on the source cloud only: it is built once per call (pt_regtab_kernel) and a group then reads one row per kept region that
 // touches its ball (r = 0.4: ~4 rows instead of ~32 member rows; the same rows for every coalition, so they stay in L2).
-// Max is exact and order-free: bit-identical to the member walk (tested with tuning key 5 = 15, which disables the tables).
+// Max is exact and order-free: bit-identical to the member walk (tested with tuning key 5 = 21, which disables the tables).
 // Balls around the centre (6 % at r = 0.4) and over-full balls keep the member walk.
 constexpr int kRegSlots = 64;
 
@@ -1192,7 +1192,7 @@ extern "C" int iq_pointnet2_coalitions(const iq_pointnet2_weights* w, const floa
             if ((rc = iq::launch_linear(t.h1, sc.l2.cin, sc.l2, t.h2, sc.l2.cout, row0, 1, st))) return rc;
             if ((rc = iq::launch_linear(t.h2, sc.l2.cout, sc.l3, t.feat[q], sc.l3.cout, row0, 1, st))) return rc;
         }
-        if (iq::tuning(iq::kTuneExperiment) != 15) {   // region-reduced rows of this scale (15: member walk only, A/B and tests)
+        if (iq::tuning(iq::kTuneExperiment) != 21) {   // region-reduced rows of this scale (21: member walk only, A/B and tests)
             int r0c = 0;
             for (int c = 0; c < nclouds; ++c) {
                 hipLaunchKernelGGL(pt_regtab_kernel, dim3(n1), dim3(kThreads), (size_t)kRegSlots * sc.l3.cout * 4, st, t.feat[q], t.pairs,

@@ -143,7 +143,7 @@ def test_coalitions_with_pair_tables_equal_the_forward_on_masked_clouds(model):
 
 def test_region_reduced_tables_equal_the_member_walk(model):
     """sa1 from the region-reduced pair tables (csrc/iq_pointnet2.hip: pt_regtab_kernel - one row per kept region that reaches
-    into a ball) against the member walk over the pair rows (tuning key 5 = 15): bit-identical logits on 400 random coalitions
+    into a ball) against the member walk over the pair rows (tuning key 5 = 21): bit-identical logits on 400 random coalitions
     of two source clouds, among them the empty, the full and single-region ones."""
     from interpret_quality_amd import _lib
     d = dev()
@@ -156,7 +156,7 @@ def test_region_reduced_tables_equal_the_member_walk(model):
     co_t = torch.tensor([i % 2 for i in range(len(keep))], dtype=torch.int32, device=d)
     got = model.coalition_logits(clouds, centers, rid, keep_t, co_t, num_regions=32)
     lib = _lib.load()
-    lib.iq_set_tuning(5, 15)
+    lib.iq_set_tuning(5, 21)
     try:
         walk = model.coalition_logits(clouds, centers, rid, keep_t, co_t, num_regions=32)
     finally:

@@ -11,14 +11,14 @@ for m in pointnet2 dgcnn gcnn pointconv; do
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_$m -- python3 $R/tools/bench_models.py --model $m --mode $mode --steps 1 > $O/pmc_$m.log 2>&1
   grep coalitions $O/stats_$m.log
 done
-# PointNet++ sa1 gather: region-reduced tables against the member walk (tuning key 5 = 15), fabric-side fetch counters
+# PointNet++ sa1 gather: region-reduced tables against the member walk (tuning key 5 = 21), fabric-side fetch counters
 for v in reg walk; do
-  t=""; [ $v = walk ] && t="--tune 5=15"
+  t=""; [ $v = walk ] && t="--tune 5=21"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/gather_fetch_$v -- python3 $R/tools/bench_models.py --model pointnet2 --steps 2 $t > $O/gather_fetch_$v.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/gather_write_$v -- python3 $R/tools/bench_models.py --model pointnet2 --steps 2 $t > $O/gather_write_$v.log 2>&1
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $O/gather_tcc_$v -- python3 $R/tools/bench_models.py --model pointnet2 --steps 2 $t > $O/gather_tcc_$v.log 2>&1
 done
 python3 $R/tools/bench_models.py --model dgcnn --mode interaction --tune 4=3 --steps 1 > $O/knn_counters.log 2>&1
-python3 $R/tools/bench_models.py --model dgcnn --mode interaction --tune 5=14 > $O/dgcnn_no_refine.log 2>&1
+python3 $R/tools/bench_models.py --model dgcnn --mode interaction --tune 5=20 > $O/dgcnn_no_refine.log 2>&1
 python3 $R/tools/bench_models.py --model dgcnn --mode interaction > $O/dgcnn_refine.log 2>&1
-tail -1 $O/knn_counters.log $O/dgcnn_no_refine.log $O/dgcnn_refine.log
+for f in knn_counters dgcnn_no_refine dgcnn_refine; do tail -n 1 $O/$f.log; done

@@ -60,14 +60,14 @@ for v in ("reg", "walk"):
                      "%.1f" % (wd["WRITE_SIZE"] / 1024), "%.3e" % td["TCC_REQ_sum"], "%.3f" % (td["TCC_HIT_sum"] / max(td["TCC_HIT_sum"] + td["TCC_MISS_sum"], 1))])
 with open(os.path.join(DST, "r03_gather_ab.csv"), "w") as f:
     f.write("# tools/r03_profiles.sh: pt_gather_kernel of PointNet++ sa1 on the 3300-coalition Shapley step, region-reduced tables (reg) against the\n"
-            "# member walk (walk, tuning key 5 = 15); separate rocprofv3 passes (--pmc FETCH_SIZE | WRITE_SIZE | TCC_*); FETCH_SIZE in KB x 1024,\n"
+            "# member walk (walk, tuning key 5 = 21); separate rocprofv3 passes (--pmc FETCH_SIZE | WRITE_SIZE | TCC_*); FETCH_SIZE in KB x 1024,\n"
             "# raw and doubled (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section; includes Infinity-Cache hits)\n")
     f.write("variant,scale,us,fetch_MB_raw,fetch_MB_x2,write_MB,l2_requests,l2_hit_rate\n")
     for r in rows:
         f.write(",".join(str(x) for x in r) + "\n")
 with open(os.path.join(DST, "r03_knn_refine.txt"), "w") as f:
     f.write("# tools/r03_profiles.sh: DGCNN interaction step (12 000 coalitions): kNN counters (tuning key 4 = 3, two runs of the step), then the\n"
-            "# step with the float32 ranking only (tuning key 5 = 14) and with the exact re-ranking of near-ties (default)\n")
+            "# step with the float32 ranking only (tuning key 5 = 20) and with the exact re-ranking of near-ties (default)\n")
     for name in ("knn_counters.log", "dgcnn_no_refine.log", "dgcnn_refine.log"):
         f.write(open(os.path.join(SRC, name)).read().strip().splitlines()[-1] + "\n")
 print("written:", sorted(x for x in os.listdir(DST) if x.startswith("r03_")))
