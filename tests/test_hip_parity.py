@@ -351,3 +351,43 @@ def test_pointnet_without_feature_transform():
                                                                     g["orders"].astype(np.int64), args)
     assert np.abs(shap_logits.cpu().numpy() - g["shap_logits"]).max() < RTOL * np.abs(g["shap_logits"]).max()
     assert np.abs(phi - g["phi"]).max() < RTOL * np.abs(g["phi"]).max()
+
+
+def test_chain_tail_tiles_are_bit_identical_for_every_row_count(model):
+    """The 16-row tail tiles of the chain kernel (l3_tail16: v_mfma_f32_16x16x4_f32 fed in the k order of the 32x32x2 fragments)
+    against 32-row tiles only (tuning key 5 = 16): bit-identical logits and packed feature transforms for coalitions whose
+    distinct-row counts cover every residue mod 32 - 64 regions of 1 to 31 points, 400 random coalitions, plus the dense
+    forward (1024 rows: no tail) on the materialised clouds of a few of them."""
+    from interpret_quality_amd import _lib
+    d = dev()
+    rng = np.random.default_rng(3)
+    pts, _ = synth.make_cloud(11)
+    sizes = rng.integers(1, 32, size=64)
+    sizes[-1] += 1024 - sizes.sum() if sizes.sum() <= 1024 else 0
+    while sizes.sum() > 1024:
+        sizes[rng.integers(0, 64)] = max(1, sizes[rng.integers(0, 64)] - 1)
+        sizes = np.maximum(sizes, 1)
+    sizes[0] += 1024 - sizes.sum()
+    rid = np.repeat(np.arange(64), sizes)[:1024].astype(np.int32)
+    rng.shuffle(rid)
+    data = torch.from_numpy(pts).unsqueeze(0).to(d)
+    center = torch.mean(data, dim=1).contiguous()
+    keep = [int(x) for x in rng.integers(0, 1 << 63, size=398, dtype=np.uint64)] + [1, 3]
+    keep_t = hip_ops.masks_to_tensor(keep, d)
+    rid_t = torch.from_numpy(rid).to(d).reshape(1, -1)
+    eng = model.engine()
+    kept_rows = np.array([int(np.isin(rid, [r for r in range(64) if (k >> r) & 1]).sum()) for k in keep])
+    rows = kept_rows + (kept_rows < 1024)
+    assert len(set((rows % 32).tolist())) == 32                      # every residue occurs
+    got, tf = eng.coalition_logits(data, center, rid_t, keep_t, None, num_regions=64, return_trans_feat=True)
+    lib = _lib.load()
+    lib.iq_set_tuning(5, 16)
+    try:
+        ref, tf_ref = eng.coalition_logits(data, center, rid_t, keep_t, None, num_regions=64, return_trans_feat=True)
+    finally:
+        lib.iq_set_tuning(5, 0)
+    assert torch.equal(got, ref) and torch.equal(tf, tf_ref)
+    sel = [0, 57, 211, 398, 399]
+    dense = hip_ops.mask_coalitions(data[0].contiguous(), rid_t[0].contiguous(), keep_t[sel].contiguous(), center.reshape(3).contiguous(),
+                                    channel_first=True)
+    assert torch.equal(model(dense)[0], got[sel])
