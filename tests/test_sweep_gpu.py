@@ -71,3 +71,15 @@ def test_sweep_covers_all_six_models_and_both_datasets_on_two_ranks(tmp_path):
             root = tmp_path / "checkpoints" / ("exp_MODEL_%s_DATA_%s_POINTNUM_1024_REGIONNUM_32_shapley_test" % (model, dataset)) / "synthetic_00"
             assert (root / "region_sv_all.npy").exists() and (root / "scale_all" / "region_shapley_value.npy").exists(), (model, dataset)
     assert len(glob.glob(str(tmp_path / "fps_*_index_final30.npy"))) == 2
+
+
+def test_sweep_phase_barriers_and_teardown_on_rccl_with_a_forced_single_rank_group(tmp_path):
+    """The sweep's only collectives - the phase barriers and the orderly teardown (dist.shutdown) - on the real library:
+    IQ_FORCE_DIST=1 creates the "nccl" (= RCCL) process group at world size 1."""
+    sweep = os.path.join(REPO, "tools", "sweep.py")
+    flags = ["--models", "pointnet", "--datasets", "modelnet10", "--synthetic", "--num_clouds", "2", "--stages", "shapley_value,scale",
+             "--num_samples_save", "100"]
+    r = _run(_torchrun(1, 29737) + [sweep] + flags, tmp_path, _env(IQ_FORCE_DIST="1"))
+    assert "[sweep] done" in r.stdout
+    root = tmp_path / "checkpoints" / "exp_MODEL_pointnet_DATA_modelnet10_POINTNUM_1024_REGIONNUM_32_shapley_test"
+    assert (root / "synthetic_01" / "scale_all" / "region_shapley_value.npy").exists()
