@@ -35,6 +35,12 @@ def _torchrun(nproc, port):
 
 
 def _run(cmd, cwd, env, timeout=900):
+    # the child processes share the ONE GPU of the box with this pytest process: hand back what its caching allocator holds
+    # (freed workspaces of earlier tests' models, tens of GB each) before they start
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
     r = subprocess.run(cmd, cwd=str(cwd), env=env, capture_output=True, text=True, timeout=timeout)
     if r.returncode != 0:
         # keep the WHOLE output of a failed launch where it survives the run (gpurun_out/ is merged back): the assertion text below

@@ -92,6 +92,13 @@ class Runner:
         self.a, self.device = a, device
         self.model_cache, self.data_cache = {}, {}
 
+    def release_models(self):
+        """Drop the cached models (and with them their engines' workspaces) and hand the memory back to the device."""
+        import gc
+        self.model_cache.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
+
     def prepare(self, args, cloud=None):
         args.model_cache, args.data_cache = self.model_cache, self.data_cache
         args.cloud_subset = None if cloud is None else {cloud}
@@ -154,13 +161,22 @@ def main(argv=None):
         t0 = time.time()
         owner = assign(units, costs, world)
         mine = [u for u, r in zip(units, owner) if r == rank]
+        # a rank's units one model after the other: each family's engine holds a workspace of tens of GB (sized for thousands of
+        # coalitions per launch), so only ONE is alive at a time - the order inside a phase is free, every unit writes its own files
+        mine.sort(key=lambda u: (u[0] if isinstance(u, tuple) else "",) + (tuple(u[1:]) if isinstance(u, tuple) else (u,)))
+        current = None
         for u in mine:
+            model = u[0] if isinstance(u, tuple) else None
+            if model != current:
+                runner.release_models()
+                current = model
             with iqdist.local_only(), (contextlib.redirect_stdout(sink) if sink is not None else contextlib.nullcontext()):
                 fn(u)
             if sink is not None:
                 sink.seek(0)
                 sink.truncate()
         busy = time.time() - t0
+        runner.release_models()
         iqdist.group_barrier()
         log["phases"][name] = {"units": len(units), "mine": len(mine), "busy_s": round(busy, 3), "wall_s": round(time.time() - t0, 3)}
         if rank == 0:
