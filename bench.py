@@ -24,6 +24,8 @@ the MFMA tiles it issues over its HIP-event launch time (`frac_basis: "executed"
 distinct rows only (no tile padding); `frac_algorithmic` is SURVEY 8d's figure, the dense reference layers over all 1024
 rows of every coalition - above 1 because the kernel skips duplicate points, exactly.
 
+Every default line also carries `strong_scaling` (`--strong-steps`, default 1 step after the headline measurement): the same
+workload as `--scaling strong` at this rank count, so the driver's N = 1, 2, 4, 8 runs hold a strong-scaling curve too.
 `--scaling strong`: ONE cloud's work sharded over the N ranks with the drivers' own code - the 216-pose rotation sweep
 (pose_sweep.sharded_shapley: poses sharded, tools/final_common.py:158) and one 300-pair x 13-ratio interaction setting
 (interaction.compute_order_interaction_logits: pairs sharded, final_point_binary_interaction_logits.py:37), every coalition a
@@ -71,6 +73,8 @@ def parse():
                     help="weak: one cloud per rank (headline); strong: one cloud's pose sweep + interaction setting sharded over the ranks")
     ap.add_argument("--model", default="pointnet", help="model of the strong-scaling mode")
     ap.add_argument("--profile-steps", type=int, default=3, help="steps of the separate profiled pass (kernel durations)")
+    ap.add_argument("--strong-steps", type=int, default=1, help="weak mode: also time this many strong-scaling steps (one cloud sharded over the "
+                    "ranks) after the headline measurement and report them under `strong_scaling` (0: skip)")
     ap.add_argument("--perms", type=int, default=NUM_PERMS, help="permutations per cloud per step")
     ap.add_argument("--regions", type=int, default=NUM_REGIONS)
     ap.add_argument("--cpu-baseline", type=int, default=1, help="time the CPU oracle on rank 0 at N=1")
@@ -289,7 +293,7 @@ def measure_traffic():
             d = os.path.join(tmp, counter)
             cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--repeats", "1", "--profile-steps", "1",
-                   "--cpu-baseline", "0", "--other-models", "0", "--eager-baseline", "0", "--traffic", "0"]
+                   "--cpu-baseline", "0", "--other-models", "0", "--eager-baseline", "0", "--traffic", "0", "--strong-steps", "0"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -322,8 +326,12 @@ def rows_of(keep_np, sizes, regions):
     return kept + (kept < NUM_POINTS)
 
 
-def strong_scaling(args, rank, world, dev, collectives, rehearsal):
-    """`--scaling strong`: ONE cloud's work through the drivers' own sharded code paths; see the module docstring."""
+def strong_scaling(args, rank, world, dev, collectives, rehearsal, steps=None, warmup=None, repeats=None):
+    """`--scaling strong`: ONE cloud's work through the drivers' own sharded code paths; see the module docstring.
+    Returns the JSON record on rank 0 (None elsewhere)."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    repeats = args.repeats if repeats is None else repeats
     import argparse as ap
     import torch.distributed as dist
     from interpret_quality_amd import dist as iqdist
@@ -363,15 +371,15 @@ def strong_scaling(args, rank, world, dev, collectives, rehearsal):
         torch.cuda.synchronize()
 
     try:
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
         fence()
         regions_s, gather_s = [], []
-        for _ in range(args.repeats):
+        for _ in range(max(repeats, 1)):
             iqdist.GATHER_EVENTS.clear()
             fence()
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(steps):
                 step()
             fence()
             el = time.perf_counter() - t0
@@ -386,26 +394,26 @@ def strong_scaling(args, rank, world, dev, collectives, rehearsal):
         final_common.distinct_coalitions = saved
         iqdist.GATHER_EVENTS = None
     if rank != 0:
-        return
+        return None
     k = int(np.argsort(regions_s)[len(regions_s) // 2])
     elapsed = regions_s[k]
-    total = (n_sweep + n_inter) * args.steps
-    print(json.dumps({
+    total = (n_sweep + n_inter) * steps
+    return {
         "metric": "coalitions/sec (masked forward passes/sec), %s 1024-pt ModelNet10" % ("PointNet" if args.model == "pointnet" else args.model),
-        "value": total / elapsed, "unit": "coalitions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "value": total / elapsed, "unit": "coalitions/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "ONE cloud per step, sharded over the ranks by the drivers' own code: rotation sweep (%d poses + the original) "
                                "x 100 permutations x %d = %d coalitions, poses sharded; interaction setting 300 pairs x 13 ratios x 4 = %d "
                                "coalitions, pairs sharded; every coalition evaluated" % (poses.shape[0], R + 1, n_sweep, n_inter),
                    "model": args.model, "num_points": NUM_POINTS, "num_regions": R,
                    "parallelism": "%d rank(s); one padded all_gather_into_tensor per cloud (Shapley values, logits) and per ratio (logits)" % world},
-        "timing": {"protocol": "median of %d regions of %d steps, barrier + synchronize around each, MAX over ranks" % (args.repeats, args.steps),
+        "timing": {"protocol": "median of %d regions of %d steps, barrier + synchronize around each, MAX over ranks" % (len(regions_s), steps),
                    "regions_s": regions_s},
-        "gather": {"seconds_per_step": gather_s[k] / args.steps, "share_of_step": gather_s[k] / elapsed,
+        "gather": {"seconds_per_step": gather_s[k] / steps, "share_of_step": gather_s[k] / elapsed,
                    "note": "HIP-event time of the all-gathers on the slowest rank (includes waiting for the last rank to arrive, "
                            "i.e. the shard imbalance: 217 poses and 300 pairs do not divide evenly)"},
-    }), flush=True)
+    }
 
 
 def main():
@@ -435,9 +443,17 @@ def main():
         dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)  # nccl = RCCL on ROCm
     try:
         if args.scaling == "strong":
-            strong_scaling(args, rank, world, dev, collectives, rehearsal)
+            out = strong_scaling(args, rank, world, dev, collectives, rehearsal)
         else:
-            weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist)
+            out = weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist)
+            if args.strong_steps > 0:
+                # the SAME line also carries the path's own shard axes at this rank count (one cloud's pose sweep + interaction
+                # setting, poses / pairs sharded): the driver's N = 1, 2, 4, 8 runs then hold a strong-scaling curve as well
+                strong = strong_scaling(args, rank, world, dev, collectives, rehearsal, steps=args.strong_steps, warmup=1, repeats=1)
+                if rank == 0:
+                    out["strong_scaling"] = {k: strong[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "gather")}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
     finally:
         if collectives:   # orderly exit: no rank's communicator goes away under a peer (interpret_quality_amd/dist.py: shutdown)
             try:
@@ -591,7 +607,8 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
                 out["gpu_eager_baseline"] = {"error": repr(e)[:300]}
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(R, args.cpu_perms)
-        print(json.dumps(out), flush=True)
+        return out
+    return None
 
 
 if __name__ == "__main__":

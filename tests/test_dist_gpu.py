@@ -75,7 +75,7 @@ def test_bench_runs_its_collectives_on_rccl_with_a_forced_single_rank_group(tmp_
     of the timed region, all_gather_into_tensor of the logits every step, max-reduce of the elapsed time."""
     bench = os.path.join(REPO, "bench.py")
     flags = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--perms", "100", "--other-models", "0", "--cpu-baseline", "0",
-             "--eager-baseline", "0", "--traffic", "0"]
+             "--eager-baseline", "0", "--traffic", "0", "--strong-steps", "0"]
     r = _run(_torchrun(1, 29611) + [bench] + flags, tmp_path, _env(IQ_FORCE_DIST="1"))
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1

@@ -342,6 +342,9 @@ def test_bench_n2_rehearsal_prints_one_valid_json_line(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["unit"] == "coalitions/s" and d["value"] > 0 and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    # the same line carries the path's own shard axes at this rank count (one cloud's pose sweep + interaction setting sharded)
+    st = d["strong_scaling"]
+    assert st["value"] > 0 and st["steps"] == 1 and "poses sharded" in st["config"]["workload"] and 0.0 <= st["gather"]["share_of_step"] < 1.0
 
 
 def test_checkpoint_file_in_the_references_layout_is_loaded(tmp_path, monkeypatch):

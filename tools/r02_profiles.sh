@@ -2,7 +2,7 @@
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 5 --warmup 2 --cpu-baseline 0 --other-models 0 --eager-baseline 0 --traffic 0"
+B="python3 $R/bench.py --steps 5 --warmup 2 --cpu-baseline 0 --other-models 0 --eager-baseline 0 --traffic 0 --strong-steps 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- $B > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/bench_pmc -- $B > $O/bench_pmc.log 2>&1
 for m in pointnet2 dgcnn gcnn pointconv; do
