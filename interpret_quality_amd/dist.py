@@ -70,7 +70,11 @@ def init_from_env(device_type="cuda"):
     if (w > 1 or force_dist()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl" if device_type == "cuda" and not rehearsal else "gloo", rank=r, world_size=w)
+        # ranks meet only at a gather per cloud or at the sweep's phase barriers, minutes to hours apart: the backend's default
+        # collective timeout (10 minutes) would turn ordinary load imbalance into a watchdog abort
+        import datetime
+        timeout = datetime.timedelta(seconds=int(os.environ.get("IQ_DIST_TIMEOUT_S", "43200")))
+        dist.init_process_group("nccl" if device_type == "cuda" and not rehearsal else "gloo", rank=r, world_size=w, timeout=timeout)
     return r, w, lr
 
 
