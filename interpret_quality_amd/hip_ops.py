@@ -94,7 +94,8 @@ def mt_state_to_host(mt_state, set_global=True):
     """The advanced state back on the host (one device->host copy); ``set_global`` installs it as NumPy's global generator
     so that whatever the host draws next continues the reference's stream."""
     words = mt_state.cpu().numpy().view(np.uint32)
-    st = ("MT19937", words[:624].copy(), int(words[624]), 0, 0.0)
+    cur = np.random.get_state()          # the device drew 32-bit words only: a cached Gaussian of the host generator stays as it is
+    st = ("MT19937", words[:624].copy(), int(words[624]), cur[3], cur[4])
     if set_global:
         np.random.set_state(st)
     return st

@@ -38,6 +38,23 @@ def test_device_permutations_continue_numpys_stream(seed, s, r):
     assert np.array_equal(np.random.randint(0, 1 << 30, size=8), tail_want)
 
 
+def test_a_cached_gaussian_of_the_host_generator_survives_device_sampling():
+    """np.random.randn() draws Gaussians in pairs and caches the second (has_gauss, cached_gaussian of the legacy state): the device
+    consumes 32-bit words only, so the cache must come back untouched."""
+    np.random.seed(9)
+    np.random.randn()                                     # leaves one Gaussian cached
+    start = np.random.get_state()
+    assert start[3] == 1
+    want_perm = np.random.permutation(np.arange(32))
+    want_next = np.random.randn(3)
+    np.random.set_state(start)
+    state = hip_ops.mt_state_to_device(dev())
+    got = hip_ops.sample_permutations(state, 1, 32)
+    hip_ops.mt_state_to_host(state, set_global=True)
+    assert np.array_equal(got.cpu().numpy()[0], want_perm)
+    assert np.array_equal(np.random.randn(3), want_next)
+
+
 def test_device_permutations_in_several_calls_equal_one_call():
     """The state lives on the device between calls (bench.py keeps it there across steps: no host round trip)."""
     np.random.seed(4)
