@@ -367,7 +367,7 @@ def strong_scaling(args, rank, world, dev, collectives, rehearsal, steps=None, w
 
     def fence():
         if collectives:
-            dist.barrier()
+            iqdist.group_barrier()
         torch.cuda.synchronize()
 
     try:
@@ -436,6 +436,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    from interpret_quality_amd import dist as iqdist
     collectives = world > 1 or force_dist
     if collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -458,7 +459,7 @@ def main():
         if collectives:   # orderly exit: no rank's communicator goes away under a peer (interpret_quality_amd/dist.py: shutdown)
             try:
                 torch.cuda.synchronize()
-                dist.barrier()
+                iqdist.group_barrier()
             finally:
                 dist.destroy_process_group()
 
@@ -466,6 +467,7 @@ def main():
 def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
     import torch.distributed as dist
     from interpret_quality_amd import _lib, hip_ops, synth
+    from interpret_quality_amd import dist as iqdist
     from interpret_quality_amd.pointnet import PointNetCls
 
     lib = _lib.load()
@@ -499,7 +501,7 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
 
     def fence():
         if collectives:
-            dist.barrier()
+            iqdist.group_barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):

@@ -153,15 +153,24 @@ def sharded_rows(n_total, compute_fn):
     return all_gather_rows(compute_fn(lo, hi), n_total)
 
 
+def _group_barrier():
+    """``dist.barrier()`` of the default group.  RCCL runs a barrier as a collective on a device: name this rank's device
+    (the one the stage selected) instead of leaving the backend to guess it from the rank number."""
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+    else:
+        dist.barrier()
+
+
 def barrier():
     if collectives_on():
-        dist.barrier()
+        _group_barrier()
 
 
 def group_barrier():
     """Barrier of the real group (the sweep's phase boundaries), whatever local_only() says."""
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        _group_barrier()
 
 
 def shutdown(ok=True):
@@ -177,7 +186,7 @@ def shutdown(ok=True):
         if ok:
             if torch.cuda.is_available() and torch.cuda.is_initialized():
                 torch.cuda.synchronize()
-            dist.barrier()
+            _group_barrier()
     finally:
         dist.destroy_process_group()
 
