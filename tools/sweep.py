@@ -19,7 +19,7 @@ time), no collective on the data path, one barrier per phase:
   phase C  per (model, dataset, selected cloud): final_point_binary_interaction_logits, final_cal_interactions
 
 Units go to ranks longest-first onto the least loaded rank (static per-model cost estimates below; a PointConv cloud costs
-seven PointNet clouds), which needs no communication and is deterministic.  The stage code is the stage scripts' own
+six PointNet clouds), which needs no communication and is deterministic.  The stage code is the stage scripts' own
 (interpret_quality_amd.*: run / test with args.cloud_subset = {cloud}), inside dist.local_only(), so each rank computes and
 writes its clouds itself; every script's set_random(seed) and the draws of the clouds before the unit's own are replayed, so the
 artefacts are bit-identical to running the per-stage scripts (tests/test_sweep_gpu.py).
@@ -42,10 +42,10 @@ from interpret_quality_amd import dist as iqdist  # noqa: E402
 from interpret_quality_amd import gen_pair, interaction, pose_sweep, shapley_stage, smoothness  # noqa: E402
 from interpret_quality_amd.final_util import DATASETS, MODELNET_INTER_SELECTED_SAMPLE, MODELS, SHAPENET_INTER_SELECTED_SAMPLE  # noqa: E402
 
-# seconds per cloud on one MI355X at the reference's sizes (profiles/r02_e2e_times.txt minus the per-script start-up):
+# seconds per cloud on one MI355X at the reference's sizes (profiles/r03_e2e_times.txt minus the per-script start-up):
 # only the RATIOS matter - they balance the assignment
-COST_A = {"pointnet": 4.6, "pointnet2": 33.7, "pointconv": 34.8, "dgcnn": 17.9, "gcnn": 12.9, "gcnn_adv": 12.9}
-COST_C = {"pointnet": 4.9, "pointnet2": 44.6, "pointconv": 41.5, "dgcnn": 22.9, "gcnn": 17.3, "gcnn_adv": 17.3}
+COST_A = {"pointnet": 6.0, "pointnet2": 29.3, "pointconv": 35.0, "dgcnn": 14.8, "gcnn": 10.1, "gcnn_adv": 10.1}
+COST_C = {"pointnet": 5.3, "pointnet2": 36.2, "pointconv": 33.6, "dgcnn": 16.4, "gcnn": 11.6, "gcnn_adv": 11.6}
 STAGES_A = ("shapley_value", "trans", "rotate", "scale", "smoothness")
 STAGES_C = ("logits", "cal")
 ALL_STAGES = STAGES_A + ("gen_pair",) + STAGES_C
