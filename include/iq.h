@@ -312,7 +312,8 @@ int iq_pointnet2_coalitions(const iq_pointnet2_weights* w, const float* clouds, 
  * (gap below 1e-5 of the magnitude of the summed terms: rounding noise decides for the reference's float32 path too), the
  * query's 21 best candidates are re-ranked by -sum (x_i - x_j)^2 accumulated in float64, i.e. the order the reference
  * finds in float64 (csrc/iq_dgcnn.hip: knn_refine_kernel, 0.7 % of the queries; iq_set_tuning(5, 20) keeps the float32
- * ranking, for A/B runs). */
+ * ranking, for A/B runs).  Standing in front of that re-ranking, the float32 selection of these two cases compares distances in
+ * buckets of 32 ulps (3.8e-6 relative; csrc/iq_topk.h: TaggedTopK) - a fifth of the narrowest re-ranked band; C = 3 is exact. */
 int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes, int B, int N, int C, int k,
            iq_stream_t stream);
 

@@ -25,6 +25,8 @@
 #include "iq_srclist.h"
 #include "iq_topk.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -298,7 +300,11 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
                                                  int tiles_per_cloud, int dbg) {
     constexpr int KB = C / 8;
     constexpr int KL = REFINE ? kK + 1 : kK;   // list length
-    __shared__ double queue[17 * 64];                              // 16 slots per lane + the overflow slot of push()
+    // REFINE: the integer list with tagged indices (iq_topk.h: TaggedTopK) - its 32-ulp buckets lie far inside the band that
+    // knn_refine_kernel re-ranks exactly; the exact-only kernel keeps the packed fp64 list
+    using Sel = std::conditional_t<REFINE, TaggedTopK<KL, 16>, QueuedTopK<KL, 16>>;
+    constexpr int kSelLds = REFINE ? TaggedTopK<KL, 16>::kLdsBytes : 17 * 64 * 8;   // queue: 16 slots per lane + the overflow slot of push()
+    __shared__ __attribute__((aligned(16))) unsigned char queue[kSelLds];
     __shared__ __attribute__((aligned(16))) float kxs[2 * 64];   // |key|^2 of two pairs of key tiles (double-buffered)
     const int lane = threadIdx.x;
     // workgroups go round-robin over the 8 XCDs: give each XCD whole clouds, so that the ~17 waves which stream the same
@@ -321,8 +327,9 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
         qf[kb] = *reinterpret_cast<const f32x4*>(xb + (size_t)(q0 + fl) * ldx + 8 * kb + 4 * fh);
     const float xxq = xxb[q0 + fl];
 
-    QueuedTopK<KL, 16> top;
-    top.init(queue);
+    Sel sel;
+    if constexpr (REFINE) sel.init(queue);
+    else sel.init(reinterpret_cast<double*>(queue));
     const int ntiles = N / 32;
     // Key fragments by raw buffer loads (iq_mfma.h: WBuf): resource on this cloud's rows, ONE loop-invariant per-lane offset
     // (row fl of the tile, k offset 4 fh), the tile / k-block position is a scalar offset.  |key|^2 of two tiles (64 floats)
@@ -363,11 +370,11 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
     int dbg_rounds = 0, dbg_work = 0;
     int tcur = 0, half = 2;  // half == 2: the current tile is used up
     for (;;) {
-        const unsigned long long busy = __ballot(top.cnt > 0);
+        const unsigned long long busy = __ballot(sel.cnt > 0);
         const bool last = half == 2 && k == npairs;
-        if (busy != 0 && (last || __popcll(busy) >= kRoundLanes || __any(top.cnt > 8))) {
+        if (busy != 0 && (last || __popcll(busy) >= kRoundLanes || __any(sel.cnt > 8))) {
             if ((dbg & 3) == 3) { ++dbg_rounds; dbg_work += __popcll(busy); }
-            top.round(lane);
+            sel.round(lane);
             continue;
         }
         if (last) break;
@@ -404,22 +411,26 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
             half = 0;
             if ((dbg & 3) == 2) { half = 2; continue; }
         }
-        const float thr_f = top.union_threshold();   // bound on the 20th largest of both half-waves' keys (iq_topk.h)
+        const float thr_f = sel.union_threshold();   // bound on the 20th largest of both half-waves' keys (iq_topk.h)
         // queue the candidates of this half of the tile (accumulator registers 8 half .. 8 half + 7)
         const int ib = tcur * 32 + 4 * fh + 16 * half;
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const float v = half ? d[8 + rr] : d[rr];
-            top.push(v, ib + (rr & 3) + 8 * (rr >> 2), thr_f, lane);
+            sel.push(v, ib + (rr & 3) + 8 * (rr >> 2), thr_f, lane);
         }
         ++half;
-        if ((dbg & 3) == 1) top.cnt = 0;
+        if ((dbg & 3) == 1) sel.cnt = 0;
     }
     if ((dbg & 3) == 3 && lane == 0) {  // diagnostic counters (tools/knn_probe.py)
         atomicAdd(&g_knn_dbg[0], (unsigned long long)dbg_rounds);
         atomicAdd(&g_knn_dbg[1], (unsigned long long)dbg_work);
         atomicAdd(&g_knn_dbg[2], 1ull);
     }
+    // the list in its packed fp64 form (value | key index) for the merge of the two half-waves and the epilogue
+    QueuedTopK<KL, 16> top;
+    if constexpr (REFINE) sel.export_packed(top.v, lane);
+    else top = sel;
     top.merge_halves();  // each half-wave saw half of the keys of every tile
     const int centre = rg.nkept[b], mult = rg.ncopy[b];
     bool flagged = false;
@@ -437,7 +448,8 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
 #pragma unroll
         for (int q = 1; q < kK; ++q) t20 = fmin(t20, top.v[q]);
         // magnitude of the terms the expanded form sums: |q|^2 + |k|^2 + 2 |q.k| <= 2 (|q|^2 + |k|^2), |k|^2 <= 2 (|q|^2 + |q - k|^2)
-        margin = kNearTie * 2.f * (xxq + fmaxf(-(float)t20, 0.f));
+        // (+ two buckets of the tagged list: its values are the lower ends of 32-ulp buckets)
+        margin = kNearTie * 2.f * (xxq + fmaxf(-(float)t20, 0.f)) + 7.7e-6f * fabsf((float)t20);
         const bool live_q = q0 + fl < centre + (mult > 0 ? 1 : 0);
         flagged = live_q && (float)(t20 - v21) < margin;   // fewer than 21 live rows: v21 = -inf, never flagged by this rule
     }

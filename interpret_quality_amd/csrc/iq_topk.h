@@ -140,3 +140,88 @@ struct QueuedTopK {
     }
     __device__ __forceinline__ int index(int i) const { return (int)(__double_as_longlong(v[i]) & ((1ll << kIndexBits) - 1)); }
 };
+
+// ------------------------------------------------------------------------------------------------------------------
+// Tagged top-K [r3] - the selection of the kNN kernels whose near-ties are re-ranked exactly afterwards (knn_refine_kernel).
+//
+// QueuedTopK pays 45 fp64 min / max (8.8 cycles each) per sorted insert because a list entry must carry its key index.  Here an
+// entry is ONE 32-bit integer: the float32 distance as an order-preserving integer key (negative floats with their magnitude
+// bits flipped) whose low 5 bits are replaced by a TAG - the slot of the entry's key index in a small per-lane LDS table.
+// A sorted insert is v[i] = med3(c, v[i-1], v[i]) on integers: 21 full-rate instructions.  K + 1 tags circulate: the K list
+// entries hold K of them, the next candidate takes the free one, and the entry that drops out of the list - min(candidate,
+// old last entry) - hands its tag back.  The price is resolution: keys are compared in buckets of 32 float32 ulps (3.8e-6
+// relative), candidates in the bucket of the threshold are rejected like exact ties, and two entries of one bucket rank by
+// tag.  That is harmless exactly where knn_refine_kernel stands behind the selection: a boundary gap that small is far inside
+// the band (>= 2e-5 of the value) that is re-ranked in exact arithmetic anyway.  The exact-only kernel (C = 8) keeps QueuedTopK.
+template <int K, int CAP = 16>
+struct TaggedTopK {
+    static constexpr int kTagBits = 5, kTagMask = (1 << kTagBits) - 1;
+    static_assert(K + 1 <= (1 << kTagBits), "K + 1 tags must fit the tag bits");
+    static constexpr int kKeyNegInf = (int)0x807fffffu;   // key of -inf: every real distance is above it, every empty slot below
+    static constexpr int kLdsBytes = (CAP + 1) * 64 * 8 + (K + 1) * 64 * 2;
+    int v[K];             // descending keys; low 5 bits = tag
+    int cnt;              // queued candidates of this lane
+    int free_tag;
+    int2* q;              // this wave's queue, slot-major: q[slot * 64 + lane] = {key index, float bits}
+    unsigned short* tab;  // tab[tag * 64 + lane] = key index of the entry that carries `tag`
+
+    static __device__ __forceinline__ int key_of(float d) {   // order-preserving, its own inverse on the bit pattern
+        const int b = __float_as_int(d);
+        return b ^ ((b >> 31) & 0x7fffffff);
+    }
+    static __device__ __forceinline__ float float_of(int key) { return __int_as_float(key ^ ((key >> 31) & 0x7fffffff)); }
+    static __device__ __forceinline__ int med3(int a, int b, int c) {
+        int r;
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        return r;
+    }
+    __device__ __forceinline__ void init(void* wave_lds) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) v[i] = (int)0x80000000u + (K - 1 - i);   // empty slots: below every key, tags K-1 .. 0
+        cnt = 0;
+        free_tag = K;
+        q = reinterpret_cast<int2*>(wave_lds);
+        tab = reinterpret_cast<unsigned short*>(q + (CAP + 1) * 64);
+    }
+    // float32 threshold of a key: the upper end of its bucket (a candidate inside the bucket is rejected, like a tie)
+    static __device__ __forceinline__ float threshold_of(int key) { return float_of(max(key | kTagMask, kKeyNegInf)); }
+    __device__ __forceinline__ float union_threshold() const {   // see QueuedTopK::union_threshold
+        constexpr int i1 = K / 4 - 1, j1 = K - 2 - i1, i2 = K / 2 - 1, j2 = K - 2 - i2;
+        const int a1 = v[i1], a3 = v[j1], a2 = v[i2], a4 = v[K - 1];
+        const int b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32), b3 = __shfl_xor(a3, 32), b4 = __shfl_xor(a4, 32);
+        int mid;
+        if (i2 == j2) {
+            mid = min(a2, b2);
+        } else {
+            const int a2b = v[j2], b2b = __shfl_xor(a2b, 32);
+            mid = max(min(a2, b2b), min(a2b, b2));
+        }
+        return threshold_of(max(max(a4, b4), max(mid, max(min(a1, b3), min(a3, b1)))));
+    }
+    __device__ __forceinline__ void push(float d, int idx, float thr_f, int lane) {   // as QueuedTopK::push
+        q[cnt * 64 + lane] = make_int2(idx, __float_as_int(d));
+        cnt += d > thr_f ? 1 : 0;
+    }
+    __device__ __forceinline__ void round(int lane) {   // branch-free: a lane without a candidate inserts an empty-slot key
+        const bool has = cnt > 0;
+        cnt -= has ? 1 : 0;
+        const int2 e = q[cnt * 64 + lane];
+        const int key = has ? ((key_of(__int_as_float(e.y)) & ~kTagMask) | free_tag) : ((int)0x80000000u | free_tag);
+        tab[free_tag * 64 + lane] = (unsigned short)e.x;
+        const int dropped = min(key, v[K - 1]);
+#pragma unroll
+        for (int i = K - 1; i >= 1; --i) v[i] = med3(key, v[i - 1], v[i]);
+        v[0] = max(key, v[0]);
+        free_tag = dropped & kTagMask;
+    }
+    // the list as QueuedTopK holds it: (double)distance - the lower end of the entry's bucket - with the key index in the low
+    // mantissa bits; -inf for an empty slot
+    __device__ __forceinline__ void export_packed(double (&out)[K], int lane) const {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int idx = tab[(v[i] & kTagMask) * 64 + lane];
+            const double p = __longlong_as_double(__double_as_longlong((double)float_of(v[i] & ~kTagMask)) | (long long)idx);
+            out[i] = v[i] > kKeyNegInf ? p : -INFINITY;
+        }
+    }
+};
