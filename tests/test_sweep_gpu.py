@@ -62,7 +62,8 @@ def test_sweep_covers_all_six_models_and_both_datasets_on_two_ranks(tmp_path):
     import glob
     import json
     sweep = os.path.join(REPO, "tools", "sweep.py")
-    flags = ["--synthetic", "--num_clouds", "1", "--stages", "shapley_value,scale", "--num_samples_save", "100"]
+    # (--resume on a fresh directory skips nothing; it makes rank 0 broadcast its view of the finished units to the other rank)
+    flags = ["--synthetic", "--num_clouds", "1", "--stages", "shapley_value,scale", "--num_samples_save", "100", "--resume"]
     r = _run(_torchrun(2, 29735) + [sweep] + flags, tmp_path, _env(IQ_REHEARSAL="1"))
     log = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"sweep"')][-1])["sweep"]
     assert log["world"] == 2 and log["phases"]["A_shapley"]["units"] == 12 and 0 < log["phases"]["A_shapley"]["mine"] < 12
@@ -83,3 +84,15 @@ def test_sweep_phase_barriers_and_teardown_on_rccl_with_a_forced_single_rank_gro
     assert "[sweep] done" in r.stdout
     root = tmp_path / "checkpoints" / "exp_MODEL_pointnet_DATA_modelnet10_POINTNUM_1024_REGIONNUM_32_shapley_test"
     assert (root / "synthetic_01" / "scale_all" / "region_shapley_value.npy").exists()
+    # --resume: the units a run with the same settings completed are skipped (markers under checkpoints/.sweep/); a unit whose
+    # marker is gone is run again and writes the same files; other settings do not match the markers
+    before = _artefacts(tmp_path)
+    stamp = os.path.getmtime(root / "synthetic_00" / "scale_all" / "region_shapley_value.npy")
+    os.remove(tmp_path / "checkpoints" / ".sweep" / "A_shapley" / "pointnet-modelnet10-1.json")
+    r = _run(_torchrun(1, 29737) + [sweep] + flags + ["--resume"], tmp_path, _env(IQ_FORCE_DIST="1"))
+    assert "phase A_shapley: 1 units over 1 rank(s) (1 done before, skipped), rank 0 ran 1" in r.stdout, r.stdout
+    assert "phase 0_fps: 0 units over 1 rank(s) (1 done before, skipped)" in r.stdout
+    assert os.path.getmtime(root / "synthetic_00" / "scale_all" / "region_shapley_value.npy") == stamp
+    _assert_same(before, _artefacts(tmp_path))
+    r = _run([sys.executable, sweep] + flags[:-1] + ["50", "--resume"], tmp_path, _env())
+    assert "phase A_shapley: 2 units over 1 rank(s), rank 0 ran 2" in r.stdout, r.stdout

@@ -37,6 +37,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 import torch  # noqa: E402
+import torch.distributed  # noqa: E402
 
 from interpret_quality_amd import dist as iqdist  # noqa: E402
 from interpret_quality_amd import gen_pair, interaction, pose_sweep, shapley_stage, smoothness  # noqa: E402
@@ -77,7 +78,35 @@ def parse(argv=None):
     p.add_argument("--num_pairs_random", type=int, default=None)
     p.add_argument("--num_save_context_max", type=int, default=None)
     p.add_argument("--quiet", type=int, default=1, help="swallow the stage scripts' per-pose prints")
+    p.add_argument("--resume", action="store_true", help="skip the units a previous run with the same settings completed "
+                   "(markers under checkpoints/.sweep/, written after a unit's last stage)")
     return p.parse_args(argv)
+
+
+def marker_path(phase, unit):
+    """checkpoints/.sweep/<phase>/<unit>.json: written (atomically) once every stage of the unit has finished."""
+    name = "-".join(str(x) for x in (unit if isinstance(unit, tuple) else (unit,)))
+    return os.path.join("checkpoints", ".sweep", phase, name + ".json")
+
+
+def unit_done(phase, unit, settings):
+    """True if a previous run completed this unit under the same settings (the inter-stage artefacts are the checkpoint the
+    reference's pipelines have; a unit starts from set_random(seed) and replays the draws of the clouds before
+    its own, so skipping one changes nothing for the others)."""
+    try:
+        with open(marker_path(phase, unit)) as f:
+            return json.load(f) == settings
+    except (OSError, ValueError):
+        return False
+
+
+def mark_done(phase, unit, settings):
+    path = marker_path(phase, unit)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    tmp = "%s.tmp%d" % (path, os.getpid())
+    with open(tmp, "w") as f:
+        json.dump(settings, f)
+    os.replace(tmp, path)
 
 
 def stage_argv(a, model, dataset, extra=()):
@@ -156,9 +185,21 @@ def main(argv=None):
     log = {"rank": rank, "world": world, "phases": {}}
     t_all = time.time()
 
-    def phase(name, units, costs, fn):
+    def phase(name, units, costs, fn, phase_stages=()):
         """units of this phase -> the ones this rank owns, run in unit order; then the phase barrier."""
         t0 = time.time()
+        settings = {"seed": a.seed, "mode": a.mode, "num_clouds": a.num_clouds, "synthetic": bool(a.synthetic),
+                    "num_samples_save": a.num_samples_save, "num_pairs_random": a.num_pairs_random,
+                    "num_save_context_max": a.num_save_context_max, "stages": [s for s in phase_stages if s in stages]}
+        skipped = 0
+        if a.resume:   # before the assignment: the units that are left are balanced over the ranks
+            # rank 0 looks (a fast rank may finish a unit of this phase before a slow one has looked) and tells the others
+            done = [[unit_done(name, u, settings) for u in units] if rank == 0 else None]
+            if world > 1:
+                torch.distributed.broadcast_object_list(done, src=0)
+            left = [(u, c) for u, c, dn in zip(units, costs, done[0]) if not dn]
+            skipped = len(units) - len(left)
+            units, costs = [u for u, _ in left], [c for _, c in left]
         owner = assign(units, costs, world)
         mine = [u for u, r in zip(units, owner) if r == rank]
         # a rank's units one model after the other: each family's engine holds a workspace of tens of GB (sized for thousands of
@@ -172,30 +213,33 @@ def main(argv=None):
                 current = model
             with iqdist.local_only(), (contextlib.redirect_stdout(sink) if sink is not None else contextlib.nullcontext()):
                 fn(u)
+            mark_done(name, u, settings)
             if sink is not None:
                 sink.seek(0)
                 sink.truncate()
         busy = time.time() - t0
         runner.release_models()
         iqdist.group_barrier()
-        log["phases"][name] = {"units": len(units), "mine": len(mine), "busy_s": round(busy, 3), "wall_s": round(time.time() - t0, 3)}
+        log["phases"][name] = {"units": len(units), "skipped": skipped, "mine": len(mine), "busy_s": round(busy, 3),
+                               "wall_s": round(time.time() - t0, 3)}
         if rank == 0:
-            print("[sweep] phase %s: %d units over %d rank(s), rank 0 ran %d in %.1f s (phase wall %.1f s)"
-                  % (name, len(units), world, len(mine), busy, time.time() - t0), flush=True)
+            print("[sweep] phase %s: %d units over %d rank(s)%s, rank 0 ran %d in %.1f s (phase wall %.1f s)"
+                  % (name, len(units), world, " (%d done before, skipped)" % skipped if skipped else "", len(mine), busy,
+                     time.time() - t0), flush=True)
 
     selected = {"modelnet10": MODELNET_INTER_SELECTED_SAMPLE, "shapenet": SHAPENET_INTER_SELECTED_SAMPLE}
     md = [(m, d) for d in datasets for m in models]
     if any(s in stages for s in STAGES_A):
-        phase("0_fps", datasets, [1.0] * len(datasets), lambda d: runner.run("fps", models[0], d))
+        phase("0_fps", datasets, [1.0] * len(datasets), lambda d: runner.run("fps", models[0], d), ("fps",))
         units = [(m, d, c) for m, d in md for c in range(a.num_clouds)]
         phase("A_shapley", units, [COST_A[m] for m, _, _ in units],
-              lambda u: [runner.run(s, u[0], u[1], u[2]) for s in STAGES_A if s in stages])
+              lambda u: [runner.run(s, u[0], u[1], u[2]) for s in STAGES_A if s in stages], STAGES_A)
     if "gen_pair" in stages:
-        phase("B_gen_pair", md, [1.0] * len(md), lambda u: runner.run("gen_pair", u[0], u[1]))
+        phase("B_gen_pair", md, [1.0] * len(md), lambda u: runner.run("gen_pair", u[0], u[1]), ("gen_pair",))
     if any(s in stages for s in STAGES_C):
         units = [(m, d, c) for m, d in md for c in selected[d] if c < a.num_clouds]
         phase("C_interaction", units, [COST_C[m] for m, _, _ in units],
-              lambda u: [runner.run(s, u[0], u[1], u[2]) for s in STAGES_C if s in stages])
+              lambda u: [runner.run(s, u[0], u[1], u[2]) for s in STAGES_C if s in stages], STAGES_C)
     log["total_s"] = round(time.time() - t_all, 3)
     if rank == 0:
         print("[sweep] done: %d (model, dataset) pairs x %d clouds on %d GPU(s) in %.1f s" % (len(md), a.num_clouds, world, log["total_s"]))
