@@ -2,9 +2,10 @@
 """Headline benchmark: coalitions/sec (masked forward passes/sec), PointNet, 1024-point clouds,
 32 regions x 1000 sampled permutations per cloud (BASELINE.json configs[1]).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N ranks (interpret_quality_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
     ... bench.py --scaling strong [--model dgcnn]          # the path's OWN shard axes at N ranks (poses, pairs)
+    ... bench.py --scaling sweep [--sweep-clouds 1]        # BASELINE configs[4]: all models x datasets, units pulled by the ranks
 
 One step (default, `"scaling": "weak"`) = the whole Shapley hot path for one synthetic cloud, ALL of it on the device and all
 of it inside the timed region: 1000 permutations sampled from NumPy's legacy generator stream (iq_sample_permutations; the state
@@ -69,8 +70,14 @@ def parse():
     ap.add_argument("--steps", type=int, default=30, help="steps per timed region (30 x 70 ms = 2.1 s)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: one cloud per rank (headline); strong: one cloud's pose sweep + interaction setting sharded over the ranks")
+    ap.add_argument("--scaling", choices=["weak", "strong", "sweep"], default="weak",
+                    help="weak: one cloud per rank (headline); strong: one cloud's pose sweep + interaction setting sharded over the ranks; "
+                         "sweep: BASELINE configs[4], all models x datasets through both pipelines (tools/sweep.py), --sweep-clouds each")
+    ap.add_argument("--sweep-clouds", type=int, default=1, help="--scaling sweep: clouds per (model, dataset); the reference's is 30")
+    ap.add_argument("--sweep-models", default="", help="--scaling sweep: comma list (default: all six)")
+    ap.add_argument("--sweep-datasets", default="", help="--scaling sweep: comma list (default: both)")
+    ap.add_argument("--sweep-reduced", type=int, default=0, help="--scaling sweep: 1 = rehearsal sizes (100 saved permutations, 5 pairs, "
+                    "3 contexts) instead of the reference's")
     ap.add_argument("--model", default="pointnet", help="model of the strong-scaling mode")
     ap.add_argument("--profile-steps", type=int, default=3, help="steps of the separate profiled pass (kernel durations)")
     ap.add_argument("--strong-steps", type=int, default=1, help="weak mode: also time this many strong-scaling steps (one cloud sharded over the "
@@ -416,15 +423,55 @@ def strong_scaling(args, rank, world, dev, collectives, rehearsal, steps=None, w
     }
 
 
+def sweep_scaling(args, rank, world, collectives):
+    """`--scaling sweep`: BASELINE configs[4] through tools/sweep.py's own code in this process group - every (model, dataset,
+    cloud) unit through exp_shapley.sh's and exp_interaction.sh's stages, units pulled by the ranks from a shared queue.  ONE
+    step = the whole sweep (no warm-up: model loading, artefact writing and the phase barriers are part of the job), in a
+    scratch directory that is removed afterwards.  Returns the record on rank 0."""
+    import importlib.util
+    import torch.distributed as dist
+    spec = importlib.util.spec_from_file_location("iq_sweep", os.path.join(REPO, "tools", "sweep.py"))
+    sweep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sweep)
+    box = [tempfile.mkdtemp(prefix="iq_bench_sweep_", dir="/tmp") if rank == 0 else None]
+    if collectives:
+        dist.broadcast_object_list(box, src=0)
+    argv = ["--synthetic", "--num_clouds", str(args.sweep_clouds)]
+    if args.sweep_models:
+        argv += ["--models", args.sweep_models]
+    if args.sweep_datasets:
+        argv += ["--datasets", args.sweep_datasets]
+    if args.sweep_reduced:
+        argv += ["--num_samples_save", "100", "--num_pairs_random", "5", "--num_save_context_max", "3"]
+    cwd = os.getcwd()
+    os.chdir(box[0])
+    try:
+        rec = sweep.run(sweep.parse(argv), emit=False)
+    finally:
+        os.chdir(cwd)
+        if collectives:
+            from interpret_quality_amd import dist as iqdist
+            iqdist.group_barrier()
+        if rank == 0:
+            shutil.rmtree(box[0], ignore_errors=True)
+    if rec is not None:
+        rec["steps"], rec["warmup"] = 1, 0
+        rec["timing"] = {"protocol": "one whole sweep, wall clock on rank 0 from the first phase to the last phase barrier; no warm-up"}
+    return rec
+
+
 def main():
     args = parse()
+    from interpret_quality_amd import launch
+    if args.gpus > 1 and not launch.under_launcher():
+        # plain `python bench.py --gpus N`: this process has not touched the GPU; it becomes the parent of N fresh ranks
+        # (interpret_quality_amd/launch.py), relays rank 0's JSON line and the worst exit code
+        raise SystemExit(launch.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-        args.gpus = world
+        args.gpus = world    # the launcher's world size wins over the flag
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # IQ_BENCH_REHEARSAL=1 (= IQ_REHEARSAL=1): rehearse the N > 1 code path on a one-GPU box (all ranks on cuda:0, gloo
@@ -439,11 +486,14 @@ def main():
     from interpret_quality_amd import dist as iqdist
     collectives = world > 1 or force_dist
     if collectives:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)  # nccl = RCCL on ROCm
+        launch.ensure_rendezvous()    # the launcher's MASTER_PORT; a free one for a forced single-rank group
+        import datetime
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world,   # nccl = RCCL on ROCm
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("IQ_DIST_TIMEOUT_S", "1800"))))
     try:
-        if args.scaling == "strong":
+        if args.scaling == "sweep":
+            out = sweep_scaling(args, rank, world, collectives)
+        elif args.scaling == "strong":
             out = strong_scaling(args, rank, world, dev, collectives, rehearsal)
         else:
             out = weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist)

@@ -54,9 +54,14 @@ def cloud_selected(args, index):
     return subset is None or index in subset
 
 
-def init_from_env(device_type="cuda"):
-    """Initialise from torchrun's environment (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*).  Returns
-    (rank, world, local_rank).  A single process needs no process group."""
+DEFAULT_TIMEOUT_S = 1800   # the per-stage scripts meet once per cloud, seconds to minutes apart
+
+
+def init_from_env(device_type="cuda", timeout_s=None):
+    """Initialise from the launcher's environment (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*; torchrun or launch.self_launch).
+    Returns (rank, world, local_rank).  A single process needs no process group.  ``timeout_s``: collective timeout of the
+    group (default IQ_DIST_TIMEOUT_S or 30 minutes, so a hung or dead peer is noticed; tools/sweep.py, whose ranks meet only
+    at phase barriers hours apart, asks for its own)."""
     w = int(os.environ.get("WORLD_SIZE", "1"))
     r = int(os.environ.get("RANK", "0"))
     lr = int(os.environ.get("LOCAL_RANK", "0"))
@@ -68,12 +73,14 @@ def init_from_env(device_type="cuda"):
     # IQ_FORCE_DIST=1: create the process group even for a single rank, so that the RCCL communicator, the barrier and
     # the all-gather of the N > 1 path are exercised on a one-GPU box (a world of 1 is otherwise collective-free).
     if (w > 1 or force_dist()) and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        # ranks meet only at a gather per cloud or at the sweep's phase barriers, minutes to hours apart: the backend's default
-        # collective timeout (10 minutes) would turn ordinary load imbalance into a watchdog abort
+        from . import launch
+        launch.ensure_rendezvous()   # the launcher's MASTER_PORT; a free port for a forced single-rank group
+        # ranks meet at a gather per cloud, up to minutes apart: the backend's default collective timeout (10 minutes) is too
+        # close to ordinary load imbalance, 12 hours (round 3) hides a dead peer
         import datetime
-        timeout = datetime.timedelta(seconds=int(os.environ.get("IQ_DIST_TIMEOUT_S", "43200")))
+        if timeout_s is None:
+            timeout_s = int(os.environ.get("IQ_DIST_TIMEOUT_S", str(DEFAULT_TIMEOUT_S)))
+        timeout = datetime.timedelta(seconds=int(timeout_s))
         dist.init_process_group("nccl" if device_type == "cuda" and not rehearsal else "gloo", rank=r, world_size=w, timeout=timeout)
     return r, w, lr
 

@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-from . import hip_ops
+from . import hip_ops, work
 from ._lib import IqError
 
 
@@ -27,6 +27,7 @@ def get_reward(logits, lbl, args):
 def cal_reward(model, data, lbl, args):
     """tools/final_common.py:26-43.  data (B',N,3) -> (v (B',), logits (B',C))."""
     x = data.permute(0, 2, 1).contiguous()
+    work.add(x.shape[0])
     out = model(x)
     logits = out[0] if _is_pointnet(args) else out
     return get_reward(logits, lbl, args), logits
@@ -95,6 +96,7 @@ def shapley_logits(model, data, lbl, region_id, orders, args, center=None):
         center = torch.mean(data, dim=1)  # (1,3), tools/final_common.py:80
     rid = hip_ops.region_ids(region_id, dev, r)   # validated here: the model calls below skip their own check
     uniq, inv = distinct_coalitions(prefix_keep_masks(orders, r))
+    work.add(inv.size, uniq.size)
     inv_t = torch.from_numpy(inv.astype(np.int64)).to(dev)
     keep = hip_ops.masks_to_tensor(uniq, dev)
     strict = getattr(args, "strict_batch_cap", False)

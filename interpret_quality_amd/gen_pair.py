@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from scipy.special import comb
 
-from . import final_common
+from . import final_common, work
 from .final_util import (BALL_QUERY_COEF, ball_query, cal_rank, get_folder_name_list, load_model, mkdir,
                          square_distance_np)  # noqa: F401
 from .interaction import DEFAULT_RATIOS
@@ -98,6 +98,7 @@ def save_pair_random(args, folder_name_list):
 
 
 def _dense_logits(model, clouds_cf, args):
+    work.add(clouds_cf.shape[0])
     out = model(clouds_cf)
     return out[0] if args.model == "pointnet" else out
 

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import dist as iqdist
-from . import final_common, hip_ops
+from . import final_common, hip_ops, work
 from .final_util import (MODELNET_INTER_SELECTED_SAMPLE, NUM_POINTS, NUM_REGIONS, SHAPENET_INTER_SELECTED_SAMPLE,
                          get_folder_name_list, load_model, set_interaction_batch_size)
 from .pose_sweep import rotate_xyz, translate_pc
@@ -63,6 +63,7 @@ def compute_order_interaction_logits(model, data_disturb, region_id, region_pair
         if hi > lo:
             # equal sets are equal clouds (few-region contexts repeat a lot): evaluate the distinct ones once
             keep_np, inv = final_common.distinct_coalitions(context_keep_masks(pairs[lo:hi], ctx[lo:hi], r))
+            work.add(inv.size, keep_np.size)
             inv_t = torch.from_numpy(inv.astype(np.int64)).to(dev)
             strict = getattr(args, "strict_batch_cap", False)
             if hasattr(model, "coalition_logits"):

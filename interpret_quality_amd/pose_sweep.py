@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import dist as iqdist
-from . import final_common, hip_ops
+from . import final_common, hip_ops, work
 from .final_util import NUM_SAMPLES, IOStream, get_folder_name_list, load_model, mkdir, set_shapley_batch_size
 from .shapley_stage import build_parser, data_loader, finish_args
 
@@ -129,6 +129,7 @@ def shapley_over_poses(model, poses, lbl, region_id, orders, args, pose_batch=8)
         for lo in range(0, p, pose_batch):
             clouds = poses[lo:lo + pose_batch].contiguous()
             nb = clouds.shape[0]
+            work.add(nb * per, nb * nu)
             # centre of the PERTURBED cloud (tools/final_common.py:80), reduced one (1,N,3) cloud at a time as the reference
             # does: torch.mean over a (nb,N,3) batch picks a different reduction order for some nb, which moved the centre by
             # an ulp and made the result depend on how the poses were sharded (found by the two-rank test)

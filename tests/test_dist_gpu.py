@@ -83,8 +83,42 @@ def test_bench_runs_its_collectives_on_rccl_with_a_forced_single_rank_group(tmp_
     assert d["n_gpus"] == 1 and d["value"] > 0 and "forced single-rank RCCL group" in d["config"]["parallelism"]
     assert 0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["traffic"] is None
     # and without torchrun (RANK / WORLD_SIZE absent: defaults), same switch
-    r = _run([sys.executable, bench] + flags, tmp_path, _env(IQ_FORCE_DIST="1", MASTER_PORT="29612"))
+    r = _run([sys.executable, bench] + flags, tmp_path, _env(IQ_FORCE_DIST="1"))   # a free rendezvous port is picked
     assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
+    """Plain `python bench.py --gpus 2 --steps 2` - no torchrun: the script becomes the parent of two fresh ranks before it
+    touches the GPU (interpret_quality_amd/launch.py), picks a free rendezvous port, and rank 0's ONE JSON line comes back
+    through it (rehearsal: both ranks on cuda:0, gloo collectives)."""
+    bench = os.path.join(REPO, "bench.py")
+    flags = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "1", "--perms", "100", "--strong-steps", "0", "--profile-steps", "1"]
+    r = _run([sys.executable, bench] + flags, tmp_path, _env(IQ_REHEARSAL="1"))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "clouds sharded over 2 GPU(s)" in d["config"]["parallelism"]
+    # a node with fewer GPUs than ranks is refused up front (no rehearsal switch), before anything is started
+    r = subprocess.run([sys.executable, bench, "--gpus", "64"], cwd=str(tmp_path), env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "this node shows" in r.stderr
+
+
+def test_bench_sweep_mode_emits_a_configs4_line_on_two_self_launched_ranks(tmp_path):
+    """`python bench.py --gpus 2 --scaling sweep`: BASELINE configs[4] in the bench schema (two families x one dataset x one cloud
+    at rehearsal sizes here), units pulled from the shared queue."""
+    bench = os.path.join(REPO, "bench.py")
+    flags = ["--gpus", "2", "--scaling", "sweep", "--sweep-models", "pointnet,gcnn", "--sweep-datasets", "modelnet10", "--sweep-clouds", "1",
+             "--sweep-reduced", "1"]
+    r = _run([sys.executable, bench] + flags, tmp_path, _env(IQ_REHEARSAL="1"))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["unit"] == "coalitions/s" and d["value"] > 0
+    assert d["coalitions"] == sum(p["coalitions"] for p in d["phases"].values()) > 0
+    assert set(d["phases"]) == {"0_fps", "A_shapley", "B_gen_pair", "C_interaction"}
+    assert len(d["phases"]["A_shapley"]["per_rank"]) == 2 and "configs[4]" in d["config"]["workload"]
+    assert not (tmp_path / "checkpoints").exists()      # the sweep ran in a scratch directory
 
 
 @pytest.mark.parametrize("ranks", [1, 2])

@@ -25,6 +25,14 @@ def _per_stage_scripts(work, model, dataset, clouds):
         _run([sys.executable, os.path.join(REPO, script)] + common + extra, work, _env())
 
 
+def _record(stdout):
+    """The ONE bench-schema JSON line the sweep prints last."""
+    import json
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
 MODELS, DATASET, CLOUDS = ["pointnet", "gcnn"], "modelnet10", 4      # clouds 0 and 3 are interaction samples (final_util.py:26)
 
 
@@ -46,9 +54,22 @@ def test_sweep_writes_the_same_artefacts_as_the_per_stage_scripts(tmp_path, scri
     sweep = os.path.join(REPO, "tools", "sweep.py")
     if ranks == 1:
         r = _run([sys.executable, sweep] + flags, two, _env())
-    else:   # two ranks on the one GPU of this box (gloo group: only the phase barriers use it)
-        r = _run(_torchrun(2, 29731) + [sweep] + flags, two, _env(IQ_REHEARSAL="1"))
+    else:   # two ranks on the one GPU of this box (gloo group: the phase barriers and the pull queue's store use it), started by
+        # the script itself: plain `python tools/sweep.py --gpus 2`, no torchrun
+        r = _run([sys.executable, sweep, "--gpus", "2"] + flags, two, _env(IQ_REHEARSAL="1"))
     assert "[sweep] done" in r.stdout
+    rec = _record(r.stdout)
+    assert rec["n_gpus"] == ranks and rec["unit"] == "coalitions/s" and rec["value"] > 0 and rec["scaling"] == "strong"
+    pa, pc = rec["phases"]["A_shapley"], rec["phases"]["C_interaction"]
+    assert pa["units"] == len(models) * clouds and sum(x["units"] for x in pa["per_rank"]) == pa["units"]
+    assert len(pa["per_rank"]) == ranks and all(0.0 <= x["busy_over_wall"] <= 1.0 for x in pa["per_rank"])
+    assert pa["imbalance_max_over_mean_busy"] >= 1.0 and 0.0 <= pa["idle_share"] < 1.0
+    # the coalition count is the reference's row count: per cloud, stage 1 = 100 permutations x 33 + the norm factor's 2 clouds;
+    # rotate = 216 poses + the original, each x 100 x 33; the scale grid and smoothness (>= 2 x (1 pose + the original)) on top
+    per_cloud_min = 100 * 33 + 2 + (217 + 2 + 4) * 3300
+    assert pa["coalitions"] >= len(models) * clouds * per_cloud_min and pa["evaluated"] <= pa["coalitions"]
+    assert pc["coalitions"] > 0 and rec["coalitions"] == sum(p["coalitions"] for p in rec["phases"].values())
+    assert set(pa["by_model"]) == set(models)
     a, b = script_artefacts, _artefacts(two)
     _assert_same(a, b)
     assert any("interaction_seed1" in k and k.endswith("_pred_interaction.npy") for k in a)
@@ -60,13 +81,15 @@ def test_sweep_covers_all_six_models_and_both_datasets_on_two_ranks(tmp_path):
     one cloud each, stage 1 + the scale sweep (the 216-pose sweeps and the interaction stages of every family are covered by the
     tests above and in test_dist_gpu.py; here the point is that all 12 pairs are assigned, run and written exactly once)."""
     import glob
-    import json
     sweep = os.path.join(REPO, "tools", "sweep.py")
     # (--resume on a fresh directory skips nothing; it makes rank 0 broadcast its view of the finished units to the other rank)
     flags = ["--synthetic", "--num_clouds", "1", "--stages", "shapley_value,scale", "--num_samples_save", "100", "--resume"]
     r = _run(_torchrun(2, 29735) + [sweep] + flags, tmp_path, _env(IQ_REHEARSAL="1"))
-    log = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"sweep"')][-1])["sweep"]
-    assert log["world"] == 2 and log["phases"]["A_shapley"]["units"] == 12 and 0 < log["phases"]["A_shapley"]["mine"] < 12
+    rec = _record(r.stdout)
+    pa = rec["phases"]["A_shapley"]
+    assert rec["n_gpus"] == 2 and pa["units"] == 12 and sorted(x["rank"] for x in pa["per_rank"]) == [0, 1]
+    assert all(0 < x["units"] < 12 for x in pa["per_rank"]) and sum(x["units"] for x in pa["per_rank"]) == 12
+    assert set(pa["by_model"]) == {"pointnet", "pointnet2", "pointconv", "dgcnn", "gcnn", "gcnn_adv"}
     for model in ("pointnet", "pointnet2", "pointconv", "dgcnn", "gcnn", "gcnn_adv"):
         for dataset in ("modelnet10", "shapenet"):
             root = tmp_path / "checkpoints" / ("exp_MODEL_%s_DATA_%s_POINTNUM_1024_REGIONNUM_32_shapley_test" % (model, dataset)) / "synthetic_00"
@@ -96,3 +119,8 @@ def test_sweep_phase_barriers_and_teardown_on_rccl_with_a_forced_single_rank_gro
     _assert_same(before, _artefacts(tmp_path))
     r = _run([sys.executable, sweep] + flags[:-1] + ["50", "--resume"], tmp_path, _env())
     assert "phase A_shapley: 2 units over 1 rank(s), rank 0 ran 2" in r.stdout, r.stdout
+    # a marker whose unit's files are gone (checkpoints/ cleaned, checkpoints/.sweep/ kept) does not skip the unit
+    os.remove(root / "synthetic_01" / "region_sv_all.npy")
+    r = _run([sys.executable, sweep] + flags[:-1] + ["50", "--resume"], tmp_path, _env())
+    assert "phase A_shapley: 1 units over 1 rank(s) (1 done before, skipped), rank 0 ran 1" in r.stdout, r.stdout
+    assert (root / "synthetic_01" / "region_sv_all.npy").exists()

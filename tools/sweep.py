@@ -2,14 +2,15 @@
 """BASELINE.json configs[4]: ALL models x datasets through both pipelines (scripts/exp_shapley.sh and
 scripts/exp_interaction.sh), spread over the GPUs of one node.
 
+    python tools/sweep.py --gpus 8 [--synthetic]            # starts its own 8 ranks (interpret_quality_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/sweep.py [--synthetic]
     python tools/sweep.py --models pointnet,dgcnn --datasets modelnet10 --synthetic          # one GPU
 
 The reference leaves this to the user: one (model, dataset) per shell script, clouds looped serially, `device_id` edited by
-hand to use several GPUs (README.md:87, scripts/exp_shapley.sh:2-4, tools/final_common.py:134).  Every (model, dataset,
-cloud) is an independent object (third bullet), so whole clouds are handed to ranks and each rank runs the
-complete per-cloud pipeline IN ONE PROCESS - no per-stage start-up (1.4 s x 8 scripts, which is half of PointNet's per-cloud
-time), no collective on the data path, one barrier per phase:
+hand to use several GPUs (README.md:87, scripts/exp_shapley.sh:2-9, scripts/exp_interaction.sh:2-7,
+tools/final_common.py:134).  Every (model, dataset, cloud) is an independent object (third bullet), so whole
+clouds are handed to ranks and each rank runs the complete per-cloud pipeline IN ONE PROCESS - no per-stage start-up (1.4 s x 8
+scripts, which is half of PointNet's per-cloud time), no collective on the data path, one barrier per phase:
 
   phase 0  the FPS region centres of each dataset (final_save_fps.py), one rank per dataset
   phase A  per (model, dataset, cloud): final_shapley_value, final_{trans,rotate,scale}_center_enum_all,
@@ -18,11 +19,17 @@ time), no collective on the data path, one barrier per phase:
            and depend on the rotation sweeps of all earlier clouds, so it cannot be split by cloud
   phase C  per (model, dataset, selected cloud): final_point_binary_interaction_logits, final_cal_interactions
 
-Units go to ranks longest-first onto the least loaded rank (static per-model cost estimates below; a PointConv cloud costs
-six PointNet clouds), which needs no communication and is deterministic.  The stage code is the stage scripts' own
-(interpret_quality_amd.*: run / test with args.cloud_subset = {cloud}), inside dist.local_only(), so each rank computes and
-writes its clouds itself; every script's set_random(seed) and the draws of the clouds before the unit's own are replayed, so the
-artefacts are bit-identical to running the per-stage scripts (tests/test_sweep_gpu.py).
+Units are PULLED: the units of a phase stand in one queue, heavy model families first and one family after the other (so that a
+rank keeps one family's engine alive at a time), and every rank takes the next index from a counter in the process group's
+c10d store when it has finished its unit - a slow rank or an expensive real cloud delays nobody (round 3 assigned units up
+front from a static cost table).  Which rank runs a unit changes nothing in its files: the stage code is the stage scripts' own
+(interpret_quality_amd.*: run / test with args.cloud_subset = {cloud}), inside dist.local_only(), each unit starting from the
+script's set_random(seed) and replaying the draws of the clouds before its own, so the artefacts are bit-identical to running
+the per-stage scripts (tests/test_sweep_gpu.py).
+
+The last line rank 0 prints is ONE JSON object in bench.py's schema: `value` = coalitions of the whole sweep / its wall time,
+with the coalitions counted as the stages run (interpret_quality_amd/work.py), per-phase coalitions/s, per-rank busy / wall
+and the imbalance.
 """
 import argparse
 import contextlib
@@ -40,28 +47,53 @@ import torch  # noqa: E402
 import torch.distributed  # noqa: E402
 
 from interpret_quality_amd import dist as iqdist  # noqa: E402
-from interpret_quality_amd import gen_pair, interaction, pose_sweep, shapley_stage, smoothness  # noqa: E402
-from interpret_quality_amd.final_util import DATASETS, MODELNET_INTER_SELECTED_SAMPLE, MODELS, SHAPENET_INTER_SELECTED_SAMPLE  # noqa: E402
+from interpret_quality_amd import gen_pair, interaction, launch, pose_sweep, shapley_stage, smoothness, work  # noqa: E402
+from interpret_quality_amd.final_util import DATASETS, get_folder_name_list, MODELNET_INTER_SELECTED_SAMPLE, MODELS, SHAPENET_INTER_SELECTED_SAMPLE  # noqa: E402
 
-# seconds per cloud on one MI355X at the reference's sizes (profiles/r03_e2e_times.txt minus the per-script start-up):
-# only the RATIOS matter - they balance the assignment
-COST_A = {"pointnet": 6.0, "pointnet2": 29.3, "pointconv": 35.0, "dgcnn": 14.8, "gcnn": 10.1, "gcnn_adv": 10.1}
-COST_C = {"pointnet": 5.3, "pointnet2": 36.2, "pointconv": 33.6, "dgcnn": 16.4, "gcnn": 11.6, "gcnn_adv": 11.6}
+# rough seconds per cloud on one MI355X at the reference's sizes: ONLY the order of the queue comes from them (heavy families
+# first, the light ones fill the tail); the balance comes from pulling
+HINT_A = {"pointnet": 6.0, "pointnet2": 29.3, "pointconv": 35.0, "dgcnn": 14.8, "gcnn": 10.1, "gcnn_adv": 10.1}
+HINT_C = {"pointnet": 5.3, "pointnet2": 36.2, "pointconv": 33.6, "dgcnn": 16.4, "gcnn": 11.6, "gcnn_adv": 11.6}
 STAGES_A = ("shapley_value", "trans", "rotate", "scale", "smoothness")
 STAGES_C = ("logits", "cal")
 ALL_STAGES = STAGES_A + ("gen_pair",) + STAGES_C
+SWEEP_TIMEOUT_S = 43200    # ranks meet only at the phase barriers, up to hours apart at real sizes
+RUNS = [0]                 # run() calls of this process: a second sweep on the same process group starts its counters afresh
 
 
-def assign(units, costs, world):
-    """Longest processing time first onto the least loaded rank; ties by position, so every rank computes the same table.
-    -> [rank of unit k]."""
-    load = [0.0] * world
-    owner = [0] * len(units)
-    for k in sorted(range(len(units)), key=lambda k: (-costs[k], k)):
-        r = min(range(world), key=lambda r: (load[r], r))
-        owner[k] = r
-        load[r] += costs[k]
-    return owner
+def queue_order(units, hint):
+    """Order in which a phase's units are pulled: heavy model families first, ONE family after the other (ranks then work on the
+    same family at the same time and each keeps one engine alive), inside a family by dataset and cloud."""
+    fam = lambda u: u[0] if isinstance(u, tuple) else ""   # noqa: E731
+    return sorted(units, key=lambda u: (-hint.get(fam(u), 1.0), fam(u)) + (tuple(u[1:]) if isinstance(u, tuple) else (u,)))
+
+
+class PullQueue:
+    """Shared position in a phase's queue: a counter in the process group's c10d store (TCPStore.add is atomic), so every index
+    is handed out exactly once; a single process counts for itself."""
+
+    def __init__(self, name, rank, world):
+        self.key, self.rank, self.world, self.local = "next/" + name, rank, world, 0
+        self.store = None
+        if world > 1:
+            from torch.distributed.distributed_c10d import _get_default_store
+            self.store = torch.distributed.PrefixStore("iq_sweep", _get_default_store())
+
+    def next(self):
+        if self.store is None:
+            self.local += 1
+            return self.local - 1
+        return int(self.store.add(self.key, 1)) - 1
+
+    def publish(self, name, obj):
+        if self.store is not None:
+            self.store.set("stats/%s/%d" % (name, self.rank), json.dumps(obj))
+
+    def collect(self, name, mine):
+        """Every rank's stats record, on rank 0 after the phase barrier."""
+        if self.store is None:
+            return [mine]
+        return [json.loads(self.store.get("stats/%s/%d" % (name, r)).decode()) for r in range(self.world)]
 
 
 def parse(argv=None):
@@ -78,6 +110,8 @@ def parse(argv=None):
     p.add_argument("--num_pairs_random", type=int, default=None)
     p.add_argument("--num_save_context_max", type=int, default=None)
     p.add_argument("--quiet", type=int, default=1, help="swallow the stage scripts' per-pose prints")
+    p.add_argument("--gpus", type=int, default=1, help="N > 1 outside a launcher: start N ranks of this script, one per GPU")
+    p.add_argument("--timeout_s", type=int, default=SWEEP_TIMEOUT_S, help="collective timeout of the process group (the phase barriers)")
     p.add_argument("--resume", action="store_true", help="skip the units a previous run with the same settings completed "
                    "(markers under checkpoints/.sweep/, written after a unit's last stage)")
     return p.parse_args(argv)
@@ -90,22 +124,25 @@ def marker_path(phase, unit):
 
 
 def unit_done(phase, unit, settings):
-    """True if a previous run completed this unit under the same settings (the inter-stage artefacts are the checkpoint the
-    reference's pipelines have; a unit starts from set_random(seed) and replays the draws of the clouds before
-    its own, so skipping one changes nothing for the others)."""
+    """True if a previous run completed this unit under the same settings AND the files the marker names as the unit's
+    witnesses are still there (a cleaned checkpoints/ with a kept checkpoints/.sweep/ must not skip anything).  The
+    inter-stage artefacts are the checkpoint the reference's pipelines have; a unit starts from
+    set_random(seed) and replays the draws of the clouds before its own, so skipping one changes nothing for the others."""
     try:
         with open(marker_path(phase, unit)) as f:
-            return json.load(f) == settings
+            m = json.load(f)
     except (OSError, ValueError):
         return False
+    witness = m.pop("witness", [])
+    return m == settings and all(os.path.exists(w) for w in witness)
 
 
-def mark_done(phase, unit, settings):
+def mark_done(phase, unit, settings, witness=()):
     path = marker_path(phase, unit)
     os.makedirs(os.path.dirname(path), exist_ok=True)
     tmp = "%s.tmp%d" % (path, os.getpid())
     with open(tmp, "w") as f:
-        json.dump(settings, f)
+        json.dump(dict(settings, witness=sorted(set(witness))), f)
     os.replace(tmp, path)
 
 
@@ -120,6 +157,7 @@ class Runner:
     def __init__(self, a, device):
         self.a, self.device = a, device
         self.model_cache, self.data_cache = {}, {}
+        self.witness = []     # key output files of the unit being run (the resume markers name them)
 
     def release_models(self):
         """Drop the cached models (and with them their engines' workspaces) and hand the memory back to the device."""
@@ -134,6 +172,9 @@ class Runner:
         shapley_stage.prepare_args(args, self.device)   # folders, set_random(seed), model arguments - as each script's main does
         return args
 
+    def _cloud_folder(self, args, cloud):
+        return args.exp_folder + "%s/" % get_folder_name_list(args)[cloud]
+
     def run(self, stage, model, dataset, cloud=None):
         a = self.a
         sv = lambda *extra: stage_argv(a, model, dataset, extra)  # noqa: E731
@@ -147,26 +188,45 @@ class Runner:
             args = self.prepare(shapley_stage.make_args(sv()))
             if not os.path.exists(shapley_stage.fps_index_path(args)):
                 shapley_stage.save_fps(args)
+            self.witness.append(shapley_stage.fps_index_path(args))
         elif stage == "shapley_value":
             extra = ["--num_samples_save", str(a.num_samples_save)] if a.num_samples_save is not None else []
-            shapley_stage.test(self.prepare(shapley_stage.make_args(sv(*extra)), cloud))
+            args = self.prepare(shapley_stage.make_args(sv(*extra)), cloud)
+            shapley_stage.test(args)
+            self.witness.append(self._cloud_folder(args, cloud) + "region_sv_all.npy")
         elif stage in ("trans", "rotate", "scale"):
-            pose_sweep.run(self.prepare(pose_sweep.make_args(stage, sv()), cloud))
+            args = self.prepare(pose_sweep.make_args(stage, sv()), cloud)
+            pose_sweep.run(args)
+            self.witness.append(self._cloud_folder(args, cloud) + "%s_all/region_shapley_value.npy" % stage)
         elif stage == "smoothness":
             smoothness.run(self.prepare(smoothness.make_args(sv()), cloud))
         elif stage == "gen_pair":
-            gen_pair.run(self.prepare(gen_pair.make_args(sv("--mode", a.mode, *sizes))))
+            args = self.prepare(gen_pair.make_args(sv("--mode", a.mode, *sizes)))
+            gen_pair.run(args)
+            self.witness.append(args.exp_folder)
         elif stage == "logits":
-            interaction.run_logits(self.prepare(interaction.make_args(False, sv(*inter, *sizes)), cloud))
+            args = self.prepare(interaction.make_args(False, sv(*inter, *sizes)), cloud)
+            interaction.run_logits(args)
+            self.witness.append(self._cloud_folder(args, cloud) + "interaction_seed%d/normal/ratio0_all_logits.pt" % args.gen_pair_seed)
         elif stage == "cal":
             interaction.cal_interaction(self.prepare(interaction.make_args(True, sv(*inter, *sizes)), cloud))
         else:
             raise ValueError(stage)
 
 
-@iqdist.record   # the process group is shut down (barrier, destroy) on every exit path; a failing rank's traceback is kept
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     a = parse(argv)
+    if a.gpus > 1 and not launch.under_launcher():
+        # plain `python tools/sweep.py --gpus N`: this process has not touched the GPU; it becomes the parent of N fresh ranks
+        raise SystemExit(launch.self_launch(os.path.abspath(__file__), argv, a.gpus))
+    return run(a)
+
+
+@iqdist.record   # the process group is shut down (barrier, destroy) on every exit path; a failing rank's traceback is kept
+def run(a, emit=True):
+    """The sweep on this rank (the process group exists already or is created from the launcher's environment).  Returns the
+    bench-schema record on rank 0 (None elsewhere); ``emit``: rank 0 prints it as the last line."""
     models = [m for m in a.models.split(",") if m]
     datasets = [d for d in a.datasets.split(",") if d]
     stages = [s for s in a.stages.split(",") if s]
@@ -176,74 +236,138 @@ def main(argv=None):
             raise SystemExit("unknown %s(s): %s" % (name, ", ".join(bad)))
     if [s for s in stages if s not in ALL_STAGES]:
         raise SystemExit("unknown stage(s): %s" % ", ".join(s for s in stages if s not in ALL_STAGES))
-    rank, world, local_rank = iqdist.init_from_env("cuda")
+    rank, world, local_rank = iqdist.init_from_env("cuda", timeout_s=a.timeout_s)
     if not torch.cuda.is_available():
         raise SystemExit("tools/sweep.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     runner = Runner(a, torch.device("cuda", local_rank))
     sink = io.StringIO() if a.quiet else None
-    log = {"rank": rank, "world": world, "phases": {}}
+    phases = {}
+    RUNS[0] += 1
+    run_tag = "run%d/" % RUNS[0]
     t_all = time.time()
 
-    def phase(name, units, costs, fn, phase_stages=()):
-        """units of this phase -> the ones this rank owns, run in unit order; then the phase barrier."""
+    def phase(name, units, hint, fn, phase_stages=()):
+        """The units of this phase, pulled one at a time by whichever rank is free; then the phase barrier."""
         t0 = time.time()
         settings = {"seed": a.seed, "mode": a.mode, "num_clouds": a.num_clouds, "synthetic": bool(a.synthetic),
                     "num_samples_save": a.num_samples_save, "num_pairs_random": a.num_pairs_random,
                     "num_save_context_max": a.num_save_context_max, "stages": [s for s in phase_stages if s in stages]}
         skipped = 0
-        if a.resume:   # before the assignment: the units that are left are balanced over the ranks
+        if a.resume:
             # rank 0 looks (a fast rank may finish a unit of this phase before a slow one has looked) and tells the others
             done = [[unit_done(name, u, settings) for u in units] if rank == 0 else None]
             if world > 1:
                 torch.distributed.broadcast_object_list(done, src=0)
-            left = [(u, c) for u, c, dn in zip(units, costs, done[0]) if not dn]
+            left = [u for u, dn in zip(units, done[0]) if not dn]
             skipped = len(units) - len(left)
-            units, costs = [u for u, _ in left], [c for _, c in left]
-        owner = assign(units, costs, world)
-        mine = [u for u, r in zip(units, owner) if r == rank]
-        # a rank's units one model after the other: each family's engine holds a workspace of tens of GB (sized for thousands of
-        # coalitions per launch), so only ONE is alive at a time - the order inside a phase is free, every unit writes its own files
-        mine.sort(key=lambda u: (u[0] if isinstance(u, tuple) else "",) + (tuple(u[1:]) if isinstance(u, tuple) else (u,)))
+            units = left
+        queue = queue_order(units, hint)          # the same list on every rank
+        pull = PullQueue(run_tag + name, rank, world)
+        mine = {"rank": rank, "units": 0, "busy_s": 0.0, "coalitions": 0, "evaluated": 0, "by_model": {}}
         current = None
-        for u in mine:
+        while True:
+            k = pull.next()
+            if k >= len(queue):
+                break
+            u = queue[k]
             model = u[0] if isinstance(u, tuple) else None
             if model != current:
+                # each family's engine holds a workspace of tens of GB: only ONE is alive at a time
                 runner.release_models()
                 current = model
-            with iqdist.local_only(), (contextlib.redirect_stdout(sink) if sink is not None else contextlib.nullcontext()):
-                fn(u)
-            mark_done(name, u, settings)
+            runner.witness = []
+            before, tu = work.snapshot(), time.time()
+            try:
+                with iqdist.local_only(), (contextlib.redirect_stdout(sink) if sink is not None else contextlib.nullcontext()):
+                    fn(u)
+            except BaseException:
+                if sink is not None:   # which cloud, which pose: the stage's own prints up to the failure
+                    sys.stderr.write("[sweep] rank %d failed in phase %s unit %r; the stage printed:\n%s\n" % (rank, name, u, sink.getvalue()[-4000:]))
+                raise
+            dt, did = time.time() - tu, work.since(before)
+            mark_done(name, u, settings, runner.witness)
             if sink is not None:
                 sink.seek(0)
                 sink.truncate()
-        busy = time.time() - t0
+            mine["units"] += 1
+            mine["busy_s"] += dt
+            for key in ("coalitions", "evaluated"):
+                mine[key] += did[key]
+            bm = mine["by_model"].setdefault(model or "-", {"units": 0, "busy_s": 0.0, "coalitions": 0})
+            bm["units"] += 1
+            bm["busy_s"] += dt
+            bm["coalitions"] += did["coalitions"]
         runner.release_models()
+        pull.publish(name, mine)
         iqdist.group_barrier()
-        log["phases"][name] = {"units": len(units), "skipped": skipped, "mine": len(mine), "busy_s": round(busy, 3),
-                               "wall_s": round(time.time() - t0, 3)}
+        wall = time.time() - t0
         if rank == 0:
-            print("[sweep] phase %s: %d units over %d rank(s)%s, rank 0 ran %d in %.1f s (phase wall %.1f s)"
-                  % (name, len(units), world, " (%d done before, skipped)" % skipped if skipped else "", len(mine), busy,
-                     time.time() - t0), flush=True)
+            per_rank = pull.collect(name, mine)
+            busy = [r["busy_s"] for r in per_rank]
+            coal = sum(r["coalitions"] for r in per_rank)
+            by_model = {}
+            for r in per_rank:
+                for m, v in r["by_model"].items():
+                    t = by_model.setdefault(m, {"units": 0, "busy_s": 0.0, "coalitions": 0})
+                    for key in t:
+                        t[key] += v[key]
+            for v in by_model.values():
+                v["coalitions_per_busy_s"] = v["coalitions"] / v["busy_s"] if v["busy_s"] > 0 else 0.0
+                v["busy_s"] = round(v["busy_s"], 3)
+            mean_busy = sum(busy) / len(busy)
+            phases[name] = {"units": len(queue), "skipped": skipped, "wall_s": round(wall, 3), "coalitions": coal,
+                            "evaluated": sum(r["evaluated"] for r in per_rank),
+                            "coalitions_per_s": coal / wall if wall > 0 else 0.0,
+                            "per_rank": [{"rank": r["rank"], "units": r["units"], "busy_s": round(r["busy_s"], 3),
+                                          "busy_over_wall": round(r["busy_s"] / wall, 4) if wall > 0 else 0.0,
+                                          "coalitions": r["coalitions"]} for r in per_rank],
+                            "imbalance_max_over_mean_busy": round(max(busy) / mean_busy, 4) if mean_busy > 0 else 1.0,
+                            "idle_share": round(1.0 - sum(busy) / (len(busy) * wall), 4) if wall > 0 else 0.0,
+                            "by_model": by_model}
+            print("[sweep] phase %s: %d units over %d rank(s)%s, rank 0 ran %d in %.1f s (phase wall %.1f s, %d coalitions, "
+                  "busy max/mean %.2f)" % (name, len(queue), world, " (%d done before, skipped)" % skipped if skipped else "",
+                                            mine["units"], mine["busy_s"], wall, coal, phases[name]["imbalance_max_over_mean_busy"]),
+                  flush=True)
 
     selected = {"modelnet10": MODELNET_INTER_SELECTED_SAMPLE, "shapenet": SHAPENET_INTER_SELECTED_SAMPLE}
     md = [(m, d) for d in datasets for m in models]
     if any(s in stages for s in STAGES_A):
-        phase("0_fps", datasets, [1.0] * len(datasets), lambda d: runner.run("fps", models[0], d), ("fps",))
+        phase("0_fps", datasets, {}, lambda d: runner.run("fps", models[0], d), ("fps",))
         units = [(m, d, c) for m, d in md for c in range(a.num_clouds)]
-        phase("A_shapley", units, [COST_A[m] for m, _, _ in units],
-              lambda u: [runner.run(s, u[0], u[1], u[2]) for s in STAGES_A if s in stages], STAGES_A)
+        phase("A_shapley", units, HINT_A, lambda u: [runner.run(s, u[0], u[1], u[2]) for s in STAGES_A if s in stages], STAGES_A)
     if "gen_pair" in stages:
-        phase("B_gen_pair", md, [1.0] * len(md), lambda u: runner.run("gen_pair", u[0], u[1]), ("gen_pair",))
+        phase("B_gen_pair", md, HINT_A, lambda u: runner.run("gen_pair", u[0], u[1]), ("gen_pair",))
     if any(s in stages for s in STAGES_C):
         units = [(m, d, c) for m, d in md for c in selected[d] if c < a.num_clouds]
-        phase("C_interaction", units, [COST_C[m] for m, _, _ in units],
-              lambda u: [runner.run(s, u[0], u[1], u[2]) for s in STAGES_C if s in stages], STAGES_C)
-    log["total_s"] = round(time.time() - t_all, 3)
-    if rank == 0:
-        print("[sweep] done: %d (model, dataset) pairs x %d clouds on %d GPU(s) in %.1f s" % (len(md), a.num_clouds, world, log["total_s"]))
-        print(json.dumps({"sweep": log}), flush=True)
+        phase("C_interaction", units, HINT_C, lambda u: [runner.run(s, u[0], u[1], u[2]) for s in STAGES_C if s in stages], STAGES_C)
+    total_s = time.time() - t_all
+    if rank != 0:
+        return None
+    coal = sum(p["coalitions"] for p in phases.values())
+    sized = {k: getattr(a, k) for k in ("num_samples_save", "num_pairs_random", "num_save_context_max") if getattr(a, k) is not None}
+    rec = {
+        "metric": "coalitions/sec (masked forward passes/sec), all models x datasets sweep",
+        "value": coal / total_s if total_s > 0 else 0.0, "unit": "coalitions/s", "n_gpus": world, "steps": 1, "warmup": 0,
+        "ms_per_step": total_s * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" if a.synthetic else "files",
+        "config": {"workload": "BASELINE configs[4]: %d model(s) x %d dataset(s) x %d cloud(s) through exp_shapley.sh + exp_interaction.sh "
+                               "(stages %s)%s" % (len(models), len(datasets), a.num_clouds, ",".join(stages),
+                                                  "; reduced sizes %s" % sized if sized else "; the reference's sizes"),
+                   "models": models, "datasets": datasets, "num_clouds": a.num_clouds, "stages": stages,
+                   "parallelism": "%d rank(s), whole (model, dataset, cloud) units pulled from a shared queue, one barrier per phase, "
+                                  "no data-path collective" % world},
+        "coalitions": coal, "evaluated": sum(p["evaluated"] for p in phases.values()),
+        "note": "coalitions = rows the reference would push through the network (tools/final_common.py:88-93, "
+                "final_point_binary_interaction_logits.py:45-56), counted as the stages run; evaluated = the distinct clouds the "
+                "device ran; wall time includes model loading, artefact writing and the phase barriers",
+        "phases": phases,
+    }
+    print("[sweep] done: %d (model, dataset) pairs x %d clouds on %d GPU(s) in %.1f s, %d coalitions, %.0f coalitions/s"
+          % (len(md), a.num_clouds, world, total_s, coal, rec["value"]))
+    if emit:
+        print(json.dumps(rec), flush=True)
+    return rec
 
 
 if __name__ == "__main__":
