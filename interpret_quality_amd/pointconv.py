@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib, hip_ops
+from . import _lib, hip_ops, workspace
 from .pointnet2 import fold_conv_bn
 
 SA = [dict(npoint=512, nsample=32, in_channel=3, mlp=[64, 64, 128], bandwidth=0.1),          # models/pointconv.py:403
@@ -82,9 +82,7 @@ class PointConvEngine:
         if not xyz.is_cuda or xyz.dtype != torch.float32 or not xyz.is_contiguous():
             raise _lib.IqError("xyz must be a contiguous float32 GPU tensor (B,N,3)")
         b, n, _ = xyz.shape
-        need = self.lib.iq_pointconv_workspace_bytes(b, n)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        workspace.ensure(self, self.lib.iq_pointconv_workspace_bytes(b, n))
         logits = torch.empty((b, self.weights.num_classes), dtype=torch.float32, device=self.device)
         rc = self.lib.iq_pointconv_forward(ctypes.byref(self.weights.struct), ctypes.c_void_p(xyz.data_ptr()),
                                            ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(self._ws.data_ptr()),
@@ -103,9 +101,7 @@ class PointConvEngine:
                 raise _lib.IqError("%s must be a contiguous %s GPU tensor" % (nm, dt))
         nc, n, _ = clouds.shape
         b = keep.shape[0]
-        need = self.lib.iq_pointconv_coalitions_workspace_bytes(b, nc, n)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        workspace.ensure(self, self.lib.iq_pointconv_coalitions_workspace_bytes(b, nc, n))
         logits = torch.empty((b, self.weights.num_classes), dtype=torch.float32, device=self.device)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
         rc = self.lib.iq_pointconv_coalitions(ctypes.byref(self.weights.struct), p(clouds), p(centers), p(region_id), p(keep),
@@ -172,10 +168,9 @@ class PointConvDensityClsSsg(nn.Module):
 
     def forward_points(self, xyz):
         eng = self.engine()
-        step = self.max_clouds_per_call
-        if xyz.shape[0] <= step:
-            return eng.forward_points(xyz)
-        return torch.cat([eng.forward_points(xyz[i:i + step].contiguous()) for i in range(0, xyz.shape[0], step)], dim=0)
+        n = xyz.shape[1]
+        return workspace.run_in_steps(eng, xyz.shape[0], self.max_clouds_per_call, lambda b: eng.lib.iq_pointconv_workspace_bytes(b, n),
+                                      lambda lo, hi: eng.forward_points(xyz if (lo, hi) == (0, xyz.shape[0]) else xyz[lo:hi].contiguous()))
 
     def forward(self, xyz):
         """xyz (B,3,N) as in the reference -> logits (B,10)."""
@@ -189,7 +184,6 @@ class PointConvDensityClsSsg(nn.Module):
         if validate:
             hip_ops.check_index_range(region_id, 0, int(num_regions) if num_regions else 64, "region_id")
         eng = self.engine()
-        step = self.max_clouds_per_call
         nc, b = clouds.shape[0], keep.shape[0]
         if cloud_of is None and nc not in (1, b):
             raise _lib.IqError("cloud_of is required when 1 < number of clouds != number of coalitions")
@@ -206,11 +200,16 @@ class PointConvDensityClsSsg(nn.Module):
                                                 centers[c].contiguous())
                     out[sel] = self.forward_points(x)
             return out
-        if b <= step:
-            return eng.coalition_logits(clouds, centers, region_id, keep, cloud_of)
-        if cloud_of is None and nc == b:
-            cloud_of = torch.arange(b, dtype=torch.int32, device=keep.device)
-        out = [eng.coalition_logits(clouds, centers, region_id, keep[i:i + step].contiguous(),
-                                    cloud_of[i:i + step].contiguous() if cloud_of is not None else None)
-               for i in range(0, b, step)]
-        return torch.cat(out, dim=0)
+        own = [cloud_of]
+        n = clouds.shape[1]
+
+        def call(lo, hi):
+            if (lo, hi) == (0, b):
+                return eng.coalition_logits(clouds, centers, region_id, keep, cloud_of)
+            if own[0] is None and nc == b:     # one cloud per coalition, split over launches: name each launch's clouds
+                own[0] = torch.arange(b, dtype=torch.int32, device=keep.device)
+            return eng.coalition_logits(clouds, centers, region_id, keep[lo:hi].contiguous(),
+                                        own[0][lo:hi].contiguous() if own[0] is not None else None)
+        # the launch size comes from the memory that is free now (workspace.py), at most max_clouds_per_call
+        return workspace.run_in_steps(eng, b, self.max_clouds_per_call,
+                                      lambda k: eng.lib.iq_pointconv_coalitions_workspace_bytes(k, nc, n), call)

@@ -166,8 +166,10 @@ def test_degenerate_clouds_other_models(name):
     if name == "dgcnn":
         # DGCNN's feature-space graphs: on two of these clouds a query sits on a kNN near-tie and the reference's float32 run
         # decides it differently from its OWN float64 run (logits move by 1e-3 and 2e-3).  The HIP path re-ranks near-ties in
-        # exact arithmetic (knn_refine_kernel), so the yardstick is the reference in float64 - matched to 1e-6 - and wherever the
-        # float32 reference agrees with its float64 run, so does the HIP path with the float32 reference.
+        # exact arithmetic (knn_refine_kernel), so the yardstick is the ORACLE RUN IN DOUBLE (the reference itself cannot travel to
+        # this box; the oracle in double is pinned against the reference's float64 logits by
+        # tests/test_oracle_golden.py::test_oracle_dgcnn_fp64_on_a_slice_of_the_scale_fixture), and wherever the float32 oracle
+        # agrees with its double run, so does the HIP path with the float32 oracle.
         sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
         want64 = orc(sd64)(x.double()).numpy()
         scale = np.abs(want).max()

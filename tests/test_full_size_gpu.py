@@ -91,6 +91,7 @@ def test_config3_dgcnn_interaction_at_full_size():
     empty = torch.mean(data, dim=1, keepdim=True).expand(1, 1024, 3).contiguous()
     empty_logits = m(empty.permute(0, 2, 1).contiguous())[0]
     total, rng = 0, np.random.default_rng(1)
+    dense_orders_checked = []
     for ratio in interaction.DEFAULT_RATIOS:
         ctx = np.load(td + "/ratio%d_context_list.npy" % int(ratio * 100))
         with contextlib.redirect_stdout(io.StringIO()):
@@ -112,6 +113,21 @@ def test_config3_dgcnn_interaction_at_full_size():
         if ctx.shape[2] == 30:   # S + {i, j} = all regions: row 4k of every pair is the unmodified cloud
             assert torch.equal(flat[0::4], flat[0:1].expand(p * c4 // 4, -1))
             assert float((flat[0] - full_logits).abs().max()) < 1e-5 * scale
+        if ctx.shape[2] in (0, 30):
+            # the interactions of these two orders from four DENSE forwards per pair: the masked clouds materialised (all 1024
+            # rows, the masked ones sitting on the centre) and pushed through the model's plain forward, as the reference does
+            # (final_point_binary_interaction_logits.py:45-60), against the coalition path's region-reduced evaluation
+            assert c4 == 4                                   # C(30, 0) = C(30, 30) = 1 context per pair
+            rid_t = hip_ops.region_ids(region_id, dev(), 32)
+            clouds = hip_ops.mask_coalitions(data[0].contiguous(), rid_t, hip_ops.masks_to_tensor(keep, dev()),
+                                             torch.mean(data, dim=1).reshape(3).contiguous(), channel_first=True)      # (1200, 3, 1024)
+            dense = m(clouds).reshape(p, c4, -1)
+            i_dense = interaction.compute_order_interaction(dense, lbl, a)
+            i_got = interaction.compute_order_interaction(lg, lbl, a)
+            vmax = float(hip_ops.reward(dense.reshape(p * c4, -1).contiguous(), label).abs().max())
+            assert i_got.shape == (p, 1) and np.abs(i_got - i_dense).max() < RTOL * vmax, (ratio, np.abs(i_got - i_dense).max(), vmax)
+            assert float((lg - dense).abs().max()) < RTOL * scale
+            dense_orders_checked.append(int(ctx.shape[2]))
         # spot check against the oracle: one random context (4 coalitions) of this ratio
         for _ in range(1):
             pi, ci = int(rng.integers(0, p)), int(rng.integers(0, c4 // 4))
@@ -123,7 +139,7 @@ def test_config3_dgcnn_interaction_at_full_size():
             assert np.abs(got - want).max() < 2e-2 * np.abs(want).max(), (ratio, pi, ci)
             spot = np.abs(got - want).max() / np.abs(want).max()
             test_config3_dgcnn_interaction_at_full_size.errs.append(spot)
-    assert total == 1238400
+    assert total == 1238400 and dense_orders_checked == [0, 30]
     errs = np.array(test_config3_dgcnn_interaction_at_full_size.errs)
     assert np.median(errs) < 1e-5 and (errs < RTOL).sum() >= len(errs) - 2, errs
 

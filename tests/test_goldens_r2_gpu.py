@@ -206,8 +206,8 @@ def test_context_averaged_interactions_at_scale(name):
     figures are within 1e-4 (of max |logit| / max |v|) of the reference's float32 run.
     DGCNN: the reference's float32 run is itself off its float64 run by more than 1e-4 * max|v| on some (pair, order) means
     (a coalition on a kNN near-tie, see test_dgcnn_parity_rate_at_scale), so the yardstick is the reference's FLOAT64 result:
-    the two published per-order figures are within 1e-4 * max|v| of it, and the worst per-(pair, order) context mean is within
-    1e-4 * max|v| or, failing that, no farther from it than the reference's own float32 run is."""
+    the two published per-order figures and the worst per-(pair, order) context mean are within 1e-4 * max|v| of it (measured:
+    9.4e-6; the reference's own float32 run against the same yardstick is printed beside it)."""
     g, _, _, rows = _scale_logits(name)
     label = int(g["label"])
     lbl = torch.tensor([label], device=dev())
@@ -231,7 +231,7 @@ def test_context_averaged_interactions_at_scale(name):
     print("%s: context-averaged interactions, error in units of max |v|: published per-order figures %.2e, worst (pair, order) mean %.2e "
           "(the reference's float32 run against the same yardstick: %.2e)" % (name, worst_pub, worst_pair, worst_pair_ref))
     assert worst_pub < RTOL
-    assert worst_pair < max(RTOL, worst_pair_ref)
+    assert worst_pair < RTOL
 
 
 @pytest.mark.parametrize("name", ["pointnet2", "pointconv"])

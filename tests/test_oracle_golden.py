@@ -262,6 +262,30 @@ def test_oracle_dgcnn_on_a_slice_of_the_scale_fixture():
     assert n == 96 and sum(g["ratio%d_logits" % int(r * 100)].shape[0] * g["ratio%d_logits" % int(r * 100)].shape[1] for r in g["ratios"]) == 2016
 
 
+@pytest.mark.parametrize("name", ["dgcnn", "gcnn"])
+def test_oracle_dgcnn_fp64_on_a_slice_of_the_scale_fixture(name):
+    """The oracle RUN IN DOUBLE (float64 weights and cloud) is the yardstick of the DGCNN degenerate-cloud test
+    (tests/test_edge_cases_gpu.py::test_degenerate_clouds_other_models); here it is pinned: against the REFERENCE's own float64
+    run, stored in the scale fixtures as `*_logits_fp64` (tests/golden/gen_golden_dgcnn_scale.py), one pair per ratio, DGCNN and GCNN.
+    The fixture keeps the float64 logits rounded to float32, so the bar is float32 resolution of the largest logit."""
+    g = load_golden("%s_scale.npz" % name)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in synth.to_torch(synth.dgcnn_state_dict(0)).items()}
+    pts, _ = synth.make_cloud(int(g["cloud_id"]))
+    data = torch.from_numpy(pts).unsqueeze(0).double()
+    model = lambda x: O.dgcnn_forward(sd64, x, 20, name == "gcnn")  # noqa: E731
+    n = 0
+    for k, ratio in enumerate(g["ratios"]):
+        tag = "ratio%d" % int(ratio * 100)
+        p = 5 * k + 1
+        got = O.compute_order_interaction_logits(model, data, g["region_id"].astype(np.int64), g["pairs"][p:p + 1].astype(np.int64),
+                                                 g[tag + "_contexts"][p:p + 1].astype(np.int64), 6, is_pointnet=False)
+        assert got.dtype == torch.float64
+        want = g[tag + "_logits_fp64"][p:p + 1]
+        assert np.abs(got.numpy() - want).max() <= 2.0 ** -22 * np.abs(want).max()
+        n += got.shape[1]
+    assert n == 96
+
+
 @pytest.mark.parametrize("name", ["pointnet2", "pointconv"])
 def test_oracle_on_the_32_region_family_fixture(name):
     """families_r32.npz (reference CPU run, R = 32): the oracle's PointNet++ / PointConv on one interaction pair per ratio."""
