@@ -15,9 +15,9 @@ the generator state, the weights.  With N > 1 every rank works on its own cloud 
 per step brings the per-coalition logits to every rank, as the artefact writer on rank 0 needs them.
 IQ_FORCE_DIST=1 creates the process group (and runs the barrier / all-gather) at N = 1 too.  Rank 0 prints ONE JSON line.
 
-Timing: W warm-up steps, then `--repeats` (5) timed regions of EXACTLY K steps each (default K = 30: 2.1 s),
-every region bracketed by barrier + synchronize on both sides and reduced with MAX over ranks; `value` / `ms_per_step` are
-the MEDIAN region's.  The library's HIP-event profiler is OFF in the timed regions; kernel durations come from a separate
+Timing: W warm-up steps, then `--repeats` (5) timed regions of at least `--min-region-s` (2 s) each, whatever K
+is: a region is ceil(2 s / block time) back-to-back BLOCKS of EXACTLY K steps, every block bracketed by barrier + synchronize on
+both sides and reduced with MAX over ranks; `value` / `ms_per_step` are the MEDIAN block's (`timing.region_s` states the region).  The library's HIP-event profiler is OFF in the timed regions; kernel durations come from a separate
 profiled pass afterwards.
 
 `roofline` (dominant kernel = pn_chain_kernel, fp32 MFMA bound): `achieved` / `frac` hold what the kernel EXECUTES - the FLOP of
@@ -69,7 +69,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30, help="steps per timed region (30 x 70 ms = 2.1 s)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions; each is as many blocks of --steps steps as --min-region-s needs")
+    ap.add_argument("--min-region-s", type=float, default=2.0, help="seconds of work per timed region (SURVEY 8d: >= 2 s)")
     ap.add_argument("--scaling", choices=["weak", "strong", "sweep"], default="weak",
                     help="weak: one cloud per rank (headline); strong: one cloud's pose sweep + interaction setting sharded over the ranks; "
                          "sweep: BASELINE configs[4], all models x datasets through both pipelines (tools/sweep.py), --sweep-clouds each")
@@ -299,7 +300,7 @@ def measure_traffic():
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
-                   os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--repeats", "1", "--profile-steps", "1",
+                   os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--repeats", "1", "--min-region-s", "0", "--profile-steps", "1",
                    "--cpu-baseline", "0", "--other-models", "0", "--eager-baseline", "0", "--traffic", "0", "--strong-steps", "0"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -556,20 +557,35 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
 
     for _ in range(args.warmup):
         step()
-    regions_s = []
-    for _ in range(max(args.repeats, 1)):
+
+    def block():
+        """EXACTLY args.steps steps, barrier + synchronize on both sides, MAX over ranks -> seconds."""
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            phi_sum, logits, orders, keep = step()
+            out = step()
         fence()
         el = time.perf_counter() - t0
         if collectives:
             t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        regions_s.append(el)
-    elapsed = float(np.sort(regions_s)[len(regions_s) // 2])      # the median region
+        return el, out
+
+    # SURVEY 8d asks for >= 2 s of work per timed region whatever --steps is: a region is `blocks` back-to-back blocks of
+    # exactly --steps steps (each one bracketed as the contract says); the reported time is the MEDIAN BLOCK's.  The number
+    # of blocks comes from one untimed probe block (the same on every rank: its time is already the MAX over ranks).
+    probe_s, _ = block()
+    blocks = max(1, int(np.ceil(args.min_region_s / max(probe_s, 1e-6))))
+    regions_s, blocks_s = [], []
+    for _ in range(max(args.repeats, 1)):
+        this = []
+        for _ in range(blocks):
+            el, (phi_sum, logits, orders, keep) = block()
+            this.append(el)
+        blocks_s.extend(this)
+        regions_s.append(float(np.sum(this)))
+    elapsed = float(np.sort(blocks_s)[len(blocks_s) // 2])        # the median block of args.steps steps
     if collectives:
         # every rank's chunk of the gather must hold that rank's logits (rank r's own chunk is checkable locally)
         assert torch.equal(gathered[rank * n_coal:(rank + 1) * n_coal], logits), "all-gather returned a wrong chunk"
@@ -625,8 +641,11 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
                        "num_points": NUM_POINTS, "num_regions": R, "permutations": S,
                        "parallelism": "clouds sharded over %d GPU(s), one all_gather_into_tensor of the logits per step%s"
                                       % (world, " (forced single-rank RCCL group)" if force_dist and world == 1 else "")},
-            "timing": {"protocol": "median of %d regions of %d steps, barrier + synchronize around each, MAX over ranks; HIP-event "
-                                   "profiler off" % (len(regions_s), args.steps), "regions_s": regions_s},
+            "timing": {"protocol": "%d regions of %d block(s) of exactly %d steps; barrier + synchronize around every block, MAX over ranks; "
+                                   "value / ms_per_step = the median block; HIP-event profiler off"
+                                   % (len(regions_s), blocks, args.steps),
+                       "blocks_per_region": blocks, "region_s": float(np.median(regions_s)), "regions_s": regions_s,
+                       "blocks_s": blocks_s, "block_spread": float((max(blocks_s) - min(blocks_s)) / elapsed)},
             "roofline": {"bound": "mfma", "kernel": "pn_chain_kernel<fstn|trunk>", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "frac_basis": "executed",

@@ -420,8 +420,9 @@ int iq_debug_chain_occupancy(void);
  * used unless enabled).  enable != 0 arms and zeroes 8 counters; out_host (8 x u64 or NULL) receives
  * the counters accumulated so far. */
 int iq_debug_stamps(int enable, unsigned long long* out_host);
-/* Debug: counters of the kNN kernels while tuning key 4 = 3 (synchronises the device, reads and clears them): selection rounds, busy
- * lanes summed over rounds, waves, queries flagged as near-ties, queries re-ranked, their candidates, fall-backs to the full scan. */
+/* Debug: counters of the kNN kernels while tuning key 4 = 3 (synchronises the device, reads and clears them): [0] selection rounds,
+ * [1] busy lanes summed over rounds, [2] waves, [3] queries flagged as near-ties, [4] queries re-ranked (their 21 candidates each),
+ * [6] of those, zero-gap queries whose re-ranking covers ALL rows; [5] and [7] are not written (always 0). */
 int iq_debug_knn_counters(unsigned long long* out_host /*8, host*/);
 int iq_profile_read(int slot, double* total_ms, int* launches);
 

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64) void dg_walk_kernel(const int16_t* __restrict__
 // ---- kNN ------------------------------------------------------------------------------------------
 // (A variant with two query tiles per wave and a v_permlane32_swap of the accumulator halves - one top-K list per
 // query instead of two half lists - was measured and dropped: 8 % faster at C = 64, 7 % slower at C = 8, spills at 128.)
-__device__ unsigned long long g_knn_dbg[8];  // tuning key 4 = 3: rounds, busy lanes summed over rounds, waves | flagged queries, re-ranked queries, their candidates, fall-backs
+__device__ unsigned long long g_knn_dbg[8];  // tuning key 4 = 3: [0] rounds, [1] busy lanes summed over rounds, [2] waves | [3] flagged queries, [4] re-ranked queries, [6] of which zero-gap (all rows ranked); [5], [7] unused
 __global__ void knn_dbg_fetch_kernel(unsigned long long* dst) {
     for (int i = 0; i < 3; ++i) { dst[i] = g_knn_dbg[i]; g_knn_dbg[i] = 0; }   // (the op-level probe reads the selection counters only)
 }

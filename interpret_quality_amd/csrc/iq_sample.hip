@@ -28,6 +28,7 @@ constexpr int kMtWords = kMtBlocks * kMtN;        // 4992 words per batch
 constexpr int kMtThreads = 1024;
 constexpr int kMtMaxStarts = kMtWords + 1;        // (R = 2 draws at least one word per permutation)
 constexpr unsigned kMtInvalid = 0xffffu;
+constexpr unsigned kMtPoison = 0x7fffffffu;        // position word of a state no draw may continue from (a failed / refused call)
 
 __device__ inline uint32_t mt_mix(uint32_t hi, uint32_t lo, uint32_t far) {
     const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
@@ -56,6 +57,13 @@ __global__ __launch_bounds__(kMtThreads) void mt_permutations_kernel(uint32_t* _
     int pos = (int)state[kMtN];                    // 0..624
     int done = 0;                                  // permutations written so far (uniform)
     __syncthreads();
+    if ((unsigned)pos > (unsigned)kMtN) {
+        // a malformed state (np.random.set_state accepts any position) or one a failed call poisoned: draw nothing, write rows
+        // that every range check rejects, keep the state poisoned so that the host sees it (hip_ops.mt_state_to_host raises)
+        for (int e = tid; e < S * R; e += kMtThreads) orders[e] = -1;
+        if (tid == 0) state[kMtN] = kMtPoison;
+        return;
+    }
     while (done < S) {
         // (1) blocks 1..7 by twisting (three dependent thirds, each element-parallel); temper all
         for (int blk = 1; blk < kMtBlocks; ++blk) {
@@ -153,6 +161,10 @@ __global__ __launch_bounds__(kMtThreads) void mt_permutations_kernel(uint32_t* _
         if (n == 0 && kb == 0) break;   // no progress is only possible if one permutation needs more than 4368 words (p < 2^-4000)
     }
     for (int k = tid; k < kMtN; k += kMtThreads) state[k] = key[0][k];
+    if (done < S) {                     // gave up: the rows not drawn are marked, and so is the state (see the entry check)
+        for (int e = done * R + tid; e < S * R; e += kMtThreads) orders[e] = -1;
+        pos = (int)kMtPoison;
+    }
     if (tid == 0) state[kMtN] = (uint32_t)pos;
 }
 

@@ -85,6 +85,8 @@ def mt_state_to_device(device, state=None):
     st = np.random.get_state() if state is None else state
     if st[0] != "MT19937":
         raise _lib.IqError("the reference's sampling stream is NumPy's legacy MT19937 generator, got %r" % (st[0],))
+    if not 0 <= int(st[2]) <= 624:     # np.random.set_state accepts any position; the generator itself never leaves 0..624
+        raise _lib.IqError("MT19937 state with position %d outside 0..624" % int(st[2]))
     words = np.empty(625, dtype=np.uint32)
     words[:624], words[624] = st[1], st[2]
     return torch.from_numpy(words.view(np.int32)).to(device)
@@ -94,6 +96,9 @@ def mt_state_to_host(mt_state, set_global=True):
     """The advanced state back on the host (one device->host copy); ``set_global`` installs it as NumPy's global generator
     so that whatever the host draws next continues the reference's stream."""
     words = mt_state.cpu().numpy().view(np.uint32)
+    if int(words[624]) > 624:          # iq_sample_permutations marks a state it could not draw all permutations from
+        raise _lib.IqError("the device sampler did not complete (state position word %#x): the permutations of the last "
+                           "sample_permutations call on this state are not valid" % int(words[624]))
     cur = np.random.get_state()          # the device drew 32-bit words only: a cached Gaussian of the host generator stays as it is
     st = ("MT19937", words[:624].copy(), int(words[624]), cur[3], cur[4])
     if set_global:

@@ -133,7 +133,10 @@ def shap_sampling(model, dataloader, args, folder_name_list):
     """final_shapley_value.py:110-156."""
     with torch.no_grad():
         fps_indices = np.load(fps_index_path(args))
+        subset = getattr(args, "cloud_subset", None)
         for i, (data, lbl) in enumerate(dataloader):
+            if subset is not None and i > max(subset):
+                break      # nothing later in this call reads the stream: no need to draw the remaining clouds' permutations
             result_path = args.exp_folder + "%s/" % folder_name_list[i]
             if not iqdist.cloud_selected(args, i):
                 generate_all_orders(result_path, args, save=False)  # the stream runs on from cloud to cloud: draw, do not compute

@@ -27,12 +27,13 @@ CHILD = textwrap.dedent("""
         for name in ("p0", "p1"):
             q = sweep.PullQueue("run1/" + name, rank, world)
             mine = []
+            iqdist.group_barrier()                           # both start pulling together
             while True:
                 k = q.next()
                 if k >= 37:
                     break
                 mine.append(k)
-                time.sleep(0.001 * (1 + 3 * rank))      # a slow rank takes fewer
+                time.sleep(0.001 + 0.03 * rank)         # a slow rank takes fewer
             q.publish(name, {"rank": rank, "got": mine})
             iqdist.group_barrier()
             if rank == 0:

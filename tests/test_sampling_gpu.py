@@ -110,3 +110,22 @@ def test_gen_context_on_the_device_equals_the_host_loop(tmp_path):
         h = np.load(str(tmp_path) + "/host_ratio%d_context_list.npy" % int(ratio * 100))
         d = np.load(str(tmp_path) + "/dev_ratio%d_context_list.npy" % int(ratio * 100))
         assert h.shape == d.shape and h.dtype == d.dtype and np.array_equal(h, d), ratio
+
+
+def test_a_malformed_generator_state_is_refused_on_the_host_and_marked_on_the_device():
+    """np.random.set_state accepts any position word; the generator itself never leaves 0..624.  The host wrapper refuses such a
+    state; a device state tensor that carries one anyway (or that a failed call poisoned) makes iq_sample_permutations draw
+    nothing: rows of -1 (every range check rejects them) and a state that mt_state_to_host refuses."""
+    from interpret_quality_amd._lib import IqError
+    np.random.seed(5)
+    st = np.random.get_state()
+    with pytest.raises(IqError, match="outside 0..624"):
+        hip_ops.mt_state_to_device(dev(), ("MT19937", st[1], 700, st[3], st[4]))
+    state = hip_ops.mt_state_to_device(dev(), st)
+    state[624] = 1000
+    orders = hip_ops.sample_permutations(state, 7, 32)
+    assert bool((orders == -1).all())
+    with pytest.raises(IqError, match="did not complete"):
+        hip_ops.mt_state_to_host(state, set_global=False)
+    with pytest.raises(IqError):
+        hip_ops.check_index_range(orders, 0, 32, "orders")
