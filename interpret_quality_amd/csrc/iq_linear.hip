@@ -113,7 +113,12 @@ __global__ __launch_bounds__(kThreads) void pn_linear_kernel(const float* __rest
 // POOL: instead of the activations, every 32-row tile writes its column-wise maximum and row-weighted sum over the
 // rows with weight > 0 (out = (ceil(M/32), 2, Nout)): the input of a pooling layer without the round trip of the
 // (M, Nout) activations through HBM.
-template <int NT, bool POOL>
+// WN = waves across the columns (2: workgroup tile 128 rows x 2 NT 32 columns; 1: 256 rows x NT 32 columns - the shape for
+// 128 outputs, where WN = 2 leaves a wave only NT = 2 tiles, i.e. half the MFMAs per LDS fragment and per barrier:
+// PointConv's 2048 -> 128 layer ran at 0.64 of the peak on <2, 2> against 0.82-0.92 for the NT = 4 layers).
+// NT = 5 exists for 320 outputs (PointNet++ sa2's per-point projections, 64 + 128 + 128): on NT = 4 the second column
+// block held 2 real tiles of 8 and the launch issued 1.6 x the useful MFMAs.
+template <int NT, bool POOL, int WN = 2>
 __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* __restrict__ A, int lda,
                                                                   const float* __restrict__ wp,
                                                                   const float* __restrict__ bias, float* __restrict__ out,
@@ -122,42 +127,46 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
                                                                   const float* __restrict__ row_w,
                                                                   const int32_t* __restrict__ tile_nu, int rows_per_cloud) {
     constexpr int KC = 32, LDA = KC + 4;
-    __shared__ __attribute__((aligned(16))) float As[2][128 * LDA];
+    constexpr int TM = (4 / WN) * 64;            // rows of the workgroup tile
+    static_assert(WN == 1 || WN == 2, "WN");
+    static_assert(!POOL || WN == 2, "the pooling epilogue assumes 128-row tiles");
+    __shared__ __attribute__((aligned(16))) float As[2][TM * LDA];
     __shared__ float wrow[POOL ? 128 : 1];       // pooling weights of the tile's rows (read in the epilogue)
     if (m_dev) M = min(M, *m_dev);
-    const int m0 = blockIdx.x * 128;
+    const int m0 = blockIdx.x * TM;
     if (m0 >= M) return;
     if (tile_nu) {   // rows beyond a cloud's live count are not wanted: skip tiles that hold nothing else
         const int c = m0 / rows_per_cloud;
         if (m0 - c * rows_per_cloud >= tile_nu[c]) return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     if (POOL && tid < 128) wrow[tid] = m0 + tid < M ? row_w[m0 + tid] : 0.f;   // visible after the K loop's barriers
     const int KB = K >> 3, nchunks = K / KC;
     const int ntiles = (Nout + 31) >> 5;
-    const int nt0 = (blockIdx.y * 2 + wn) * NT;
+    const int nt0 = (blockIdx.y * WN + wn) * NT;
 
-    // chunk copy: 128 rows x 8 float4; thread t owns (row, c4) = (e >> 3, e & 7) for e = t + 256 i.  Buffer loads on a
+    // chunk copy: TM rows x 8 float4; thread t owns (row, c4) = (e >> 3, e & 7) for e = t + 256 i.  Buffer loads on a
     // resource based at this workgroup's first row: loop-invariant per-lane offsets, the K position is a scalar offset.
+    constexpr int NLD = TM * 8 / kThreads;       // float4 loads per thread and chunk
     const WBuf ab = wbuf_make(A + (size_t)m0 * lda, lane);
-    int aoffb[4];
-    int soff[4];
+    int aoffb[NLD];
+    int soff[NLD];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NLD; ++i) {
         const int e = tid + kThreads * i, row = e >> 3, c4 = e & 7;
         aoffb[i] = (min(row, M - 1 - m0) * lda + c4 * 4) * 4;
         soff[i] = row * LDA + c4 * 4;
     }
-    f32x4 stage[4];
+    f32x4 stage[NLD];
     auto load_chunk = [&](int kc) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NLD; ++i)
             stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ab.rsrc, aoffb[i], kc * KC * 4, 0));
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&As[buf][soff[i]]) = stage[i];
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<f32x4*>(&As[buf][soff[i]]) = stage[i];
     };
 
     const WBuf wb = wbuf_make(wp, lane);
@@ -288,7 +297,18 @@ int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* o
     const int ntiles = (L.cout + 31) / 32;
     if (tile_nu && (rows_per_cloud <= 0 || rows_per_cloud % 128 != 0)) tile_nu = nullptr;   // tiles must not straddle clouds
     if (M >= 2048 && ntiles >= 4 && L.cin % 32 == 0 && iq::tuning(iq::kTuneNoLdsGemm) == 0) {
-        if (ntiles >= 8 && (long long)((M + 127) / 128) * ((ntiles + 7) / 8) >= 2048) {
+        const int shape = iq::tuning(iq::kTuneExperiment);   // 5 = 30: round 3's choice of shapes (A/B runs)
+        if (ntiles % 10 == 0 && shape != 30 && (long long)((M + 127) / 128) * (ntiles / 10) >= 2048) {
+            // 320 / 640 ... outputs: column blocks of exactly 10 tiles (NT = 5), nothing padded
+            dim3 grid((M + 127) / 128, ntiles / 10);
+            hipLaunchKernelGGL((pn_gemm_lds_kernel<5, false>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
+                               L.cout, relu, m_dev, nullptr, tile_nu, rows_per_cloud);
+        } else if (ntiles == 4 && shape != 30 && (M + 255) / 256 >= 2048) {
+            // 128 outputs: 256-row workgroup tiles, every wave all four column tiles
+            dim3 grid((M + 255) / 256, 1);
+            hipLaunchKernelGGL((pn_gemm_lds_kernel<4, false, 1>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
+                               L.cout, relu, m_dev, nullptr, rows_per_cloud % 256 == 0 ? tile_nu : nullptr, rows_per_cloud);
+        } else if (ntiles >= 8 && (long long)((M + 127) / 128) * ((ntiles + 7) / 8) >= 2048) {
             dim3 grid((M + 127) / 128, (ntiles + 7) / 8);
             hipLaunchKernelGGL((pn_gemm_lds_kernel<4, false>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
                                L.cout, relu, m_dev, nullptr, tile_nu, rows_per_cloud);

@@ -303,7 +303,10 @@ def test_pointnet_multi_cloud_batch(model, oracle):
 # the shared dense layer (register-streaming and LDS-staged GEMM variants)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,cin,cout,act", [(5000, 512, 1024, 2), (4133, 64, 128, 0), (2048, 128, 512, 1), (3000, 1024, 160, 1),
-                                             (300, 256, 40, 0), (2500, 8, 128, 0)])
+                                             (300, 256, 40, 0), (2500, 8, 128, 0),
+                                             # [r4] the two large-M shapes with their own tilings: 320 outputs as column blocks of
+                                             # exactly 10 tiles (NT = 5), 128 outputs on 256-row workgroup tiles (WN = 1)
+                                             (262200, 320, 320, 1), (524400, 128, 128, 1), (525000, 64, 128, 0)])
 def test_linear_variants_agree_and_match_fp32_reference(m, cin, cout, act):
     from interpret_quality_amd import _lib
     rng = np.random.default_rng(m + cin)
