@@ -700,6 +700,127 @@ __global__ __launch_bounds__(kThreads) void pc_tab_group_kernel(const float* __r
             *reinterpret_cast<f32x4*>(o + i * 16 + w4 * 4) = (f32x4){acc[i][w4 * 4], acc[i][w4 * 4 + 1], acc[i][w4 * 4 + 2], acc[i][w4 * 4 + 3]};
 }
 
+
+// ---- sa1 from the pair table, contraction and the 2048 -> 128 layer in ONE kernel ------------------------------------------
+// pc_tab_group_kernel wrote the groups' (128 x 16) contractions as a (B, 512, 2048) tensor - 10.3 GB per 3300-coalition step
+// with the duplicate centroids skipped - and the dense layer behind it read them straight back (measured, rocprofv3
+// WRITE_SIZE / FETCH_SIZE: profiles/r04_pointconv_traffic.csv; 6.0 + 7.1 ms, the layer at 0.64 of the MFMA peak, waiting on
+// that stream).  Here a workgroup owns 32 consecutive centroids of one coalition and walks the 2048 contraction columns in 8
+// chunks of 16 channels x 16 WeightNet outputs = 256 columns:
+//   contraction of chunk j, wave w, its 8 groups: D[c][o] = sum_k h[row_k][16 j + c] sw[k][o] as 8 v_mfma_f32_16x16x4_f32 per
+//       group (A: one dword per lane straight from the table row - 16 lanes read 64 contiguous bytes of member 4 t + (lane >> 4);
+//       B: sw, chunk-invariant, 64 registers per lane for the 8 groups), the 16 x 16 result -> LDS tile Ds[32 groups][256];
+//   dense layer: acc[32 groups x 32 outputs of wave w] += Ds . W[256 j .. 256 j + 255] with the shared fp32 MFMA tile code
+//       (weights from the packed image through the register ring, the same order over k as iq::launch_linear: given the same
+//       contraction values the layer's result is bit-identical).
+// Ds is double-buffered; the table loads of chunk j + 1 are issued before the layer's MFMAs of chunk j and land behind them.
+// The contraction tensor never exists.  (The sum over the 32 members runs in 4-member MFMA steps here and sequentially in
+// pc_tab_group_kernel: equal up to rounding, as pc_group_kernel's.)
+struct PcFusedArgs {
+    const float* feat;         // (nc, n1*n1, 128) sa1 pair table
+    const float* msw;          // (B,S,32,16)
+    const int16_t* idx;        // (B,S,32)
+    const int32_t* fps;        // (B,S)
+    const uint32_t* kept;      // (B,32)
+    const int32_t* n_unique;   // (B)
+    const int32_t* cloud_of;
+    const float* w; const float* bias;   // the 2048 -> 128 layer, packed
+    float* out;                // (B,S,128)
+    int N, S, B, nclouds;
+};
+
+__global__ __launch_bounds__(kThreads, 2) void pc_tab_fused_kernel(PcFusedArgs a) {
+    constexpr int GT = 32, CH = 256, LD = CH + 4, KBC = CH / 8, NCH = 2048 / CH, KBT = 2048 / 8;
+    __shared__ __attribute__((aligned(16))) float Ds[2][GT * LD];
+    __shared__ __attribute__((aligned(16))) int rowoff[GT * 32];     // [group][member & 3][member >> 2]: byte offset of the member's table row
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int tiles = a.S / GT;
+    const int b = blockIdx.x / tiles, s0 = (blockIdx.x - b * tiles) * GT;
+    const int nu = min(a.S, a.n_unique[b]);
+    if (s0 >= nu) return;                                             // duplicate centroids only: filled afterwards
+    const int c = a.cloud_of ? a.cloud_of[b] : (a.nclouds == 1 ? 0 : b);
+    const uint32_t* kb = a.kept + (size_t)b * 32;
+    const int n1 = a.N + 1;
+    {   // member -> table row, for the 32 groups of the tile (a group beyond the live count stands in as group s0: its
+        // output is not stored, but its loads must stay inside the table)
+        const int gl = tid >> 3, s = s0 + gl < nu ? s0 + gl : s0;
+        const size_t g = (size_t)b * a.S + s;
+        const int pi = a.fps[g];
+        const int q = (kb[pi >> 5] >> (pi & 31)) & 1u ? pi : a.N;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = (tid & 7) * 4 + e;
+            const int p = a.idx[g * 32 + k];
+            const int row = ((unsigned)p < (unsigned)a.N && ((kb[p >> 5] >> (p & 31)) & 1u)) ? p : a.N;
+            rowoff[gl * 32 + (k & 3) * 8 + (k >> 2)] = (q * n1 + row) * 512;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t trsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.feat + (size_t)c * n1 * n1 * 128), 0, 0x7fffffff, 0x00020000);
+    // B operand of the contraction for this wave's 8 groups: sw[member 4 t + (lane >> 4)][lane & 15]
+    float swr[8][8];
+#pragma unroll
+    for (int gi = 0; gi < 8; ++gi) {
+        const int gl = wave * 8 + gi, s = s0 + gl < nu ? s0 + gl : s0;
+        const float* sw = a.msw + ((size_t)b * a.S + s) * 32 * 16 + (lane >> 4) * 16 + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) swr[gi][t] = sw[t * 64];
+    }
+    __syncthreads();
+    float hreg[8][8];
+    const int lane4 = (lane & 15) * 4;
+    auto load_h = [&](int j) {       // chunk j: channels 16 j .. 16 j + 15 of the 32 member rows of each of the wave's groups
+#pragma unroll
+        for (int gi = 0; gi < 8; ++gi) {
+            const int* ro = rowoff + (wave * 8 + gi) * 32 + (lane >> 4) * 8;
+            const int4 r0 = *reinterpret_cast<const int4*>(ro), r1 = *reinterpret_cast<const int4*>(ro + 4);
+            const int offs[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                hreg[gi][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(trsrc, offs[t] + lane4, j * 64, 0));
+        }
+    };
+    auto contract = [&](int buf) {   // hreg x swr -> Ds[buf]
+#pragma unroll
+        for (int gi = 0; gi < 8; ++gi) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) d = __builtin_amdgcn_mfma_f32_16x16x4f32(hreg[gi][t], swr[gi][t], d, 0, 0, 0);
+            // lane holds D[c = 4 (lane >> 4) + r][o = lane & 15] -> column c * 16 + o of the chunk
+            float* dst = Ds[buf] + (wave * 8 + gi) * LD + (lane >> 4) * 64 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[r * 16] = d[r];
+        }
+    };
+    const WBuf wb = wbuf_make(a.w, lane);
+    const int wbase = wave * KBT * kFragBytes;        // this wave's output tile: columns 32 wave .. 32 wave + 31
+    const float bias = a.bias[wave * 32 + (lane & 31)];
+    load_h(0);
+    contract(0);
+    load_h(1);
+    WRing ring;
+    wring_prime(ring, wb, wbase);
+    __syncthreads();
+    f32x16 acc = {0}, unused = {0};
+#pragma unroll 1
+    for (int j = 0; j < NCH; ++j) {
+        const float* abase = Ds[j & 1] + (lane & 31) * LD + 4 * (lane >> 5);
+        const int scur = wbase + j * KBC * kFragBytes;
+        mfma_ntile<LD, KBC, 1>(abase, wb, scur, j + 1 < NCH ? scur + KBC * kFragBytes : scur, ring, acc, unused);
+        if (j + 1 < NCH) {
+            contract((j + 1) & 1);
+            if (j + 2 < NCH) load_h(j + 2);
+        }
+        __syncthreads();
+    }
+    const int col = wave * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int s = s0 + c_row(i, lane);
+        if (s < nu) a.out[((size_t)b * a.S + s) * 128 + col] = fmaxf(acc[i] + bias, 0.f);
+    }
+}
+
 struct WsC {
     float *inv1, *inv2, *inv3;
     int32_t *fps1, *fps2, *nu1;
@@ -811,6 +932,7 @@ int run_pointconv(const iq_pointconv_weights* w, const float* xyz, float* logits
                   const PcWalk* walk) {
     int rc;
     constexpr int S1 = 512, S2 = 128;
+    bool fused_sa1 = false;
 
     // ---- sa1: 1024 -> 512 points, K = 32, 3 -> 64 -> 64 -> 128 ---------------------------------------------------
     {
@@ -833,13 +955,24 @@ int run_pointconv(const iq_pointconv_weights* w, const float* xyz, float* logits
             const TinyNets nets{w->sa[0].densitynet, w->sa[0].weightnet};
             hipLaunchKernelGGL(pc_member_kernel<32>, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, xyz, s.nx1,
                                s.idx1, s.inv1, nets, s.mrel, s.msw, N, S1, total, s.nu1);
-            hipLaunchKernelGGL(pc_tab_group_kernel, dim3((unsigned)(((size_t)B * S1 + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0,
-                               st, walk->feat_tab, s.msw, s.idx1, s.fps1, walk->kept, s.nu1, walk->cloud_of, s.g1, N, S1, B, walk->nclouds);
-            if ((rc = iq::check_launch("pc_tab_group_kernel"))) return rc;
+            const iq_dense_layer& lin = w->sa[0].linear;
+            if (lin.cin == 2048 && lin.cout == 128 && iq::tuning(iq::kTuneExperiment) != 31) {
+                // contraction + the 2048 -> 128 layer in one kernel (5 = 31: the two-kernel form, A/B runs and tests)
+                PcFusedArgs fa{walk->feat_tab, s.msw, s.idx1, s.fps1, walk->kept, s.nu1, walk->cloud_of, lin.w, lin.b, s.l1, N, S1, B,
+                               walk->nclouds};
+                hipLaunchKernelGGL(pc_tab_fused_kernel, dim3((unsigned)(B * (S1 / 32))), dim3(kThreads), 0, st, fa);
+                if ((rc = iq::check_launch("pc_tab_fused_kernel"))) return rc;
+                fused_sa1 = true;
+            } else {
+                hipLaunchKernelGGL(pc_tab_group_kernel, dim3((unsigned)(((size_t)B * S1 + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads),
+                                   0, st, walk->feat_tab, s.msw, s.idx1, s.fps1, walk->kept, s.nu1, walk->cloud_of, s.g1, N, S1, B,
+                                   walk->nclouds);
+                if ((rc = iq::check_launch("pc_tab_group_kernel"))) return rc;
+            }
         } else if ((rc = launch_pc_group(w->sa[0], xyz, s.nx1, s.idx1, s.inv1, nullptr, 0, s.g1, s, N, S1, 32, B, st, s.nu1))) {
             return rc;
         }
-        if ((rc = iq::launch_linear(s.g1, 2048, w->sa[0].linear, s.l1, 128, B * S1, 1, st, nullptr, s.nu1, S1))) return rc;
+        if (!fused_sa1 && (rc = iq::launch_linear(s.g1, 2048, w->sa[0].linear, s.l1, 128, B * S1, 1, st, nullptr, s.nu1, S1))) return rc;
         hipLaunchKernelGGL(pc_fill_dup_rows_kernel, dim3(S1, B), dim3(64), 0, st, s.l1, S1, 128, s.nu1);
         if ((rc = iq::check_launch("pc_fill_dup_rows_kernel"))) return rc;
     }

@@ -107,3 +107,15 @@ def test_coalitions_from_source_lists_equal_the_forward_on_masked_clouds(model):
     finally:
         lib.iq_set_tuning(5, 0)
     assert torch.equal(knn, want)      # the same kernels on the same masked clouds
+    # [r4] sa1's contraction and its 2048 -> 128 layer in one kernel (pc_tab_fused_kernel, the default) against the two-kernel
+    # form that writes the (B, 512, 2048) contractions (5 = 31): same table rows, same weights, the sum over a group's 32
+    # members in 4-member MFMA steps instead of sequentially
+    lib.iq_set_tuning(5, 31)
+    try:
+        two = model.coalition_logits(clouds, centers, rid.to(d), keep_t, co_t, num_regions=32)
+    finally:
+        lib.iq_set_tuning(5, 0)
+    assert rel_err(got.cpu().numpy(), two.cpu().numpy()) < 2e-6 and not torch.equal(two, want)
+    # a coalition's logits do not depend on what else is in the launch (the fused kernel's tiles are per coalition)
+    solo = model.coalition_logits(clouds, centers, rid.to(d), keep_t[5:6].contiguous(), co_t[5:6].contiguous(), num_regions=32)
+    assert torch.equal(solo[0], got[5])
