@@ -734,38 +734,54 @@ __global__ __launch_bounds__(kThreads, 2) void pc_tab_fused_kernel(PcFusedArgs a
     __shared__ __attribute__((aligned(16))) float Ds[2][GT * LD];
     __shared__ __attribute__((aligned(16))) int rowoff[GT * 32];     // [group][member & 3][member >> 2]: byte offset of the member's table row
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-    const int tiles = a.S / GT;
-    const int b = blockIdx.x / tiles, s0 = (blockIdx.x - b * tiles) * GT;
-    const int nu = min(a.S, a.n_unique[b]);
-    if (s0 >= nu) return;                                             // duplicate centroids only: filled afterwards
+    // Workgroups go round-robin over the 8 XCDs (blockIdx & 7).  XCD x owns the contiguous coalitions [x nb, (x + 1) nb),
+    // nb = ceil(B / 8), and walks them tile index by tile index (tile 0 of all its coalitions, then tile 1, ...): every XCD
+    // gets the same mix of small and large coalitions (a coalition's LIVE tiles are its first ones - with the plain order
+    // b * 16 + t most live workgroups landed on the low XCDs: 58 against 44 of every 408), and the workgroups resident on one
+    // L2 at a time are the same tile of neighbouring coalitions, whose centroids and members - table rows - largely coincide.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nb = (a.B + 7) >> 3;
+    const int b = xcd * nb + slot % nb, s0 = (slot / nb) * GT;
+    if (b >= a.B) return;
     const int c = a.cloud_of ? a.cloud_of[b] : (a.nclouds == 1 ? 0 : b);
-    const uint32_t* kb = a.kept + (size_t)b * 32;
     const int n1 = a.N + 1;
-    {   // member -> table row, for the 32 groups of the tile (a group beyond the live count stands in as group s0: its
-        // output is not stored, but its loads must stay inside the table)
-        const int gl = tid >> 3, s = s0 + gl < nu ? s0 + gl : s0;
-        const size_t g = (size_t)b * a.S + s;
-        const int pi = a.fps[g];
-        const int q = (kb[pi >> 5] >> (pi & 31)) & 1u ? pi : a.N;
+    // Everything the tile needs from memory before its first table load is requested in ONE round trip (the tile's 32 groups
+    // are read as they lie - the entries of a group beyond the live count are never written: they are clamped into the table
+    // below, the group's output is not stored - instead of centroid -> kept word -> members -> ... one after the other: five
+    // dependent misses took a third of a tile's time, profiles/r04_pointconv_fused_probes.txt)
+    const int nu_raw = a.n_unique[b];
+    const uint32_t kword = a.kept[(size_t)b * 32 + (lane & 31)];      // lane l (and l + 32) holds kept word l
+    const int gl0 = tid >> 3;
+    const size_t g0 = (size_t)b * a.S + s0 + gl0;
+    const int pi_raw = a.fps[g0];
+    int p_raw[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = (tid & 7) * 4 + e;
-            const int p = a.idx[g * 32 + k];
-            const int row = ((unsigned)p < (unsigned)a.N && ((kb[p >> 5] >> (p & 31)) & 1u)) ? p : a.N;
-            rowoff[gl * 32 + (k & 3) * 8 + (k >> 2)] = (q * n1 + row) * 512;
-        }
-    }
-    const __amdgpu_buffer_rsrc_t trsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.feat + (size_t)c * n1 * n1 * 128), 0, 0x7fffffff, 0x00020000);
+    for (int e = 0; e < 4; ++e) p_raw[e] = a.idx[g0 * 32 + (tid & 7) * 4 + e];
     // B operand of the contraction for this wave's 8 groups: sw[member 4 t + (lane >> 4)][lane & 15]
     float swr[8][8];
 #pragma unroll
     for (int gi = 0; gi < 8; ++gi) {
-        const int gl = wave * 8 + gi, s = s0 + gl < nu ? s0 + gl : s0;
-        const float* sw = a.msw + ((size_t)b * a.S + s) * 32 * 16 + (lane >> 4) * 16 + (lane & 15);
+        const float* sw = a.msw + ((size_t)b * a.S + s0 + wave * 8 + gi) * 32 * 16 + (lane >> 4) * 16 + (lane & 15);
 #pragma unroll
         for (int t = 0; t < 8; ++t) swr[gi][t] = sw[t * 64];
     }
+    const int nu = min(a.S, nu_raw);
+    if (s0 >= nu) return;                                             // duplicate centroids only: filled afterwards
+    {   // member -> table row for the 32 groups of the tile
+        auto kept_bit = [&](int p) { return (__shfl((int)kword, p >> 5, 64) >> (p & 31)) & 1; };
+        const int pi = min(max(pi_raw, 0), a.N - 1);
+        const int kq = kept_bit(pi);
+        const int q = kq ? pi : a.N;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = (tid & 7) * 4 + e;
+            const int p = min(max(p_raw[e], 0), a.N - 1);
+            const int kp = kept_bit(p);               // (every lane takes part in the shuffle)
+            const int row = ((unsigned)p_raw[e] < (unsigned)a.N && kp) ? p : a.N;
+            rowoff[gl0 * 32 + (k & 3) * 8 + (k >> 2)] = (q * n1 + row) * 512;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t trsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.feat + (size_t)c * n1 * n1 * 128), 0, 0x7fffffff, 0x00020000);
     __syncthreads();
     float hreg[8][8];
     const int lane4 = (lane & 15) * 4;
@@ -820,6 +836,7 @@ __global__ __launch_bounds__(kThreads, 2) void pc_tab_fused_kernel(PcFusedArgs a
         if (s < nu) a.out[((size_t)b * a.S + s) * 128 + col] = fmaxf(acc[i] + bias, 0.f);
     }
 }
+
 
 struct WsC {
     float *inv1, *inv2, *inv3;
@@ -960,7 +977,7 @@ int run_pointconv(const iq_pointconv_weights* w, const float* xyz, float* logits
                 // contraction + the 2048 -> 128 layer in one kernel (5 = 31: the two-kernel form, A/B runs and tests)
                 PcFusedArgs fa{walk->feat_tab, s.msw, s.idx1, s.fps1, walk->kept, s.nu1, walk->cloud_of, lin.w, lin.b, s.l1, N, S1, B,
                                walk->nclouds};
-                hipLaunchKernelGGL(pc_tab_fused_kernel, dim3((unsigned)(B * (S1 / 32))), dim3(kThreads), 0, st, fa);
+                hipLaunchKernelGGL(pc_tab_fused_kernel, dim3((unsigned)(8 * ((B + 7) / 8) * (S1 / 32))), dim3(kThreads), 0, st, fa);
                 if ((rc = iq::check_launch("pc_tab_fused_kernel"))) return rc;
                 fused_sa1 = true;
             } else {
