@@ -572,19 +572,19 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
             el = float(t.item())
         return el, out
 
-    # SURVEY 8d asks for >= 2 s of work per timed region whatever --steps is: a region is `blocks` back-to-back blocks of
-    # exactly --steps steps (each one bracketed as the contract says); the reported time is the MEDIAN BLOCK's.  The number
-    # of blocks comes from one untimed probe block (the same on every rank: its time is already the MAX over ranks).
-    probe_s, _ = block()
-    blocks = max(1, int(np.ceil(args.min_region_s / max(probe_s, 1e-6))))
-    regions_s, blocks_s = [], []
+    # SURVEY 8d asks for >= 2 s of work per timed region whatever --steps is: a region is as many back-to-back blocks of
+    # exactly --steps steps (each one bracketed as the contract says) as it takes to fill --min-region-s; the reported time is
+    # the MEDIAN BLOCK's.  Every rank sees the same block times (MAX over ranks), so all of them stop a region at the same block.
+    regions_s, blocks_s, blocks_per_region = [], [], []
     for _ in range(max(args.repeats, 1)):
         this = []
-        for _ in range(blocks):
+        while not this or sum(this) < args.min_region_s:
             el, (phi_sum, logits, orders, keep) = block()
             this.append(el)
         blocks_s.extend(this)
+        blocks_per_region.append(len(this))
         regions_s.append(float(np.sum(this)))
+    blocks = int(np.median(blocks_per_region))
     elapsed = float(np.sort(blocks_s)[len(blocks_s) // 2])        # the median block of args.steps steps
     if collectives:
         # every rank's chunk of the gather must hold that rank's logits (rank r's own chunk is checkable locally)
@@ -641,9 +641,9 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
                        "num_points": NUM_POINTS, "num_regions": R, "permutations": S,
                        "parallelism": "clouds sharded over %d GPU(s), one all_gather_into_tensor of the logits per step%s"
                                       % (world, " (forced single-rank RCCL group)" if force_dist and world == 1 else "")},
-            "timing": {"protocol": "%d regions of %d block(s) of exactly %d steps; barrier + synchronize around every block, MAX over ranks; "
-                                   "value / ms_per_step = the median block; HIP-event profiler off"
-                                   % (len(regions_s), blocks, args.steps),
+            "timing": {"protocol": "%d regions of >= %.1f s, each %d block(s) of exactly %d steps; barrier + synchronize around every block, "
+                                   "MAX over ranks; value / ms_per_step = the median block; HIP-event profiler off"
+                                   % (len(regions_s), args.min_region_s, blocks, args.steps),
                        "blocks_per_region": blocks, "region_s": float(np.median(regions_s)), "regions_s": regions_s,
                        "blocks_s": blocks_s, "block_spread": float((max(blocks_s) - min(blocks_s)) / elapsed)},
             "roofline": {"bound": "mfma", "kernel": "pn_chain_kernel<fstn|trunk>", "achieved": achieved,

@@ -294,7 +294,7 @@ __global__ void knn_dbg_fetch_kernel(unsigned long long* dst) {
 // is FLAGGED: near_tie[row] holds its 21st candidate (else -1), its neighbour list the other 20 as raw rows, and
 // knn_refine_kernel re-ranks the 21 in exact arithmetic (bit 20 of the word: the gap is exactly zero - identical rows, as in
 // a dense masked cloud, may hide further candidates - so all rows are ranked).
-template <int C, bool REFINE>
+template <int C, bool REFINE, int PF = 1>
 __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ xx,
                                                  int16_t* __restrict__ idx, int32_t* __restrict__ near_tie, Ragged rg, int B,
                                                  int tiles_per_cloud, int dbg) {
@@ -361,7 +361,11 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
         return (npairs - 1 - p0 > p0) ? p0 + (k - side) : p0 - (k - side);
     };
     int k = 0, pcur = p0, j = 0;                                    // pair number in the order, its index, tile within the pair
-    f32x4 an = key_frag(2 * p0, 0);
+    // key fragments PF k-blocks ahead of the MFMAs (PF = 1: the next one only, 256 MFMA cycles - less than an L2 round trip)
+    static_assert(PF >= 1 && PF <= KB && (PF & (PF - 1)) == 0 && KB % PF == 0, "prefetch depth");
+    f32x4 ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = key_frag(2 * p0, i);
     kxs[lane] = kx_pair(p0);                                       // wave-private: no barrier (one wave per workgroup)
     float kx_next = kx_pair(pair_at(1));
     // ONE loop (a small state machine) instead of rounds nested in the tile loop: the 20-entry list is then carried
@@ -390,8 +394,8 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
             f32x16 acc = {0};
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                const f32x4 a = an;
-                an = kb + 1 < KB ? key_frag(t, kb + 1) : key_frag(tn, 0);
+                const f32x4 a = ring[kb & (PF - 1)];
+                ring[kb & (PF - 1)] = kb + PF < KB ? key_frag(t, kb + PF) : key_frag(tn, kb + PF - KB);
                 acc = mfma4(a, qf[kb], acc);
             }
 #pragma unroll
@@ -1034,9 +1038,17 @@ int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, in
     else if (C == 64 && !refine) hipLaunchKernelGGL((knn_kernel<64, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
     else if (C == 128 && !refine) hipLaunchKernelGGL((knn_kernel<128, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
     else if (C == 64) {
+        const int pf = iq::tuning(iq::kTuneExperiment);   // 5 = 40 / 41: key fragments 2 / 4 k-blocks ahead (A/B)
+        if (pf == 40) hipLaunchKernelGGL((knn_kernel<64, true, 2>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
+        else if (pf == 41) hipLaunchKernelGGL((knn_kernel<64, true, 4>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
+        else
         hipLaunchKernelGGL((knn_kernel<64, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
         hipLaunchKernelGGL(knn_refine_kernel<64>, rgrid, dim3(64), 0, st, x, ldx, near_tie, idx, rg, B, slice_addr ? 1 : 0, (dbg & 3) == 3);
     } else if (C == 128) {
+        const int pf = iq::tuning(iq::kTuneExperiment);
+        if (pf == 40) hipLaunchKernelGGL((knn_kernel<128, true, 2>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
+        else if (pf == 41) hipLaunchKernelGGL((knn_kernel<128, true, 4>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
+        else
         hipLaunchKernelGGL((knn_kernel<128, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
         hipLaunchKernelGGL(knn_refine_kernel<128>, rgrid, dim3(64), 0, st, x, ldx, near_tie, idx, rg, B, slice_addr ? 1 : 0, (dbg & 3) == 3);
     } else return iq::fail(IQ_EUNSUPPORTED, "knn: C=%d has no kernel instantiation (8, 64, 128)", C);

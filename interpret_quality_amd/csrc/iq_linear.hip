@@ -133,12 +133,18 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
     __shared__ __attribute__((aligned(16))) float As[2][TM * LDA];
     __shared__ float wrow[POOL ? 128 : 1];       // pooling weights of the tile's rows (read in the epilogue)
     if (m_dev) M = min(M, *m_dev);
-    const int m0 = blockIdx.x * TM;
-    if (m0 >= M) return;
+    int m0 = blockIdx.x * TM;
     if (tile_nu) {   // rows beyond a cloud's live count are not wanted: skip tiles that hold nothing else
+        // A cloud's live tiles are its FIRST ones and workgroups go round-robin over the 8 XCDs: in plain order (4 tiles per
+        // cloud) every first tile lands on XCDs 0 and 4 and the XCDs that hold the last tiles idle (live workgroups 33 : 21 per
+        // 33 coalitions of a Shapley batch).  Walk the grid cloud-fastest instead: every XCD sees every tile index equally often.
+        const int ntc = rows_per_cloud / TM, nc = gridDim.x / ntc;
+        if (nc * ntc == (int)gridDim.x) m0 = ((blockIdx.x % nc) * ntc + blockIdx.x / nc) * TM;
+        if (m0 >= M) return;
         const int c = m0 / rows_per_cloud;
         if (m0 - c * rows_per_cloud >= tile_nu[c]) return;
     }
+    if (m0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     if (POOL && tid < 128) wrow[tid] = m0 + tid < M ? row_w[m0 + tid] : 0.f;   // visible after the K loop's barriers

@@ -1058,7 +1058,10 @@ struct WsW {   // coalition extras behind the forward's workspace
     size_t bytes;
 };
 
-constexpr int kTabClouds = 2;   // the pair table takes 0.54 GB per source cloud (+ 0.54 GB of layer outputs while it is built)
+// The pair table takes 0.54 GB per source cloud (+ 0.54 GB of layer outputs while ONE is built): 4.8 GB for the 8 poses a sweep
+// launch carries - nothing on a 288 GB part, and the table path (fused kernel) runs sa1 at 11.1 ms per 3300 coalitions against
+// 20.5 ms for the grouped MLP (round 3 stopped at 2 clouds).  Building a table costs ~0.4 ms per cloud and launch.
+constexpr int kTabClouds = 8;
 
 WsW carve_w(void* base, int B, int nc, int N) {
     WsW s{};

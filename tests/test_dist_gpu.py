@@ -100,7 +100,7 @@ def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     # >= 2 s per timed region whatever --steps is: several blocks of exactly --steps steps, the median block reported
     t = d["timing"]
-    assert t["blocks_per_region"] > 1 and t["region_s"] >= 1.9 and len(t["blocks_s"]) == t["blocks_per_region"]
+    assert t["blocks_per_region"] > 1 and t["region_s"] >= 2.0 and len(t["blocks_s"]) >= t["blocks_per_region"]
     assert abs(d["ms_per_step"] * d["steps"] * 1e-3 - sorted(t["blocks_s"])[len(t["blocks_s"]) // 2]) < 1e-9
     assert "clouds sharded over 2 GPU(s)" in d["config"]["parallelism"]
     # a node with fewer GPUs than ranks is refused up front (no rehearsal switch), before anything is started

@@ -68,26 +68,28 @@ def test_pointconv_raw_clouds_vs_oracle(model):
     assert_close_elementwise(got.cpu().numpy(), want.numpy())   # and element-wise, with an absolute floor (conftest.py)
 
 
-def test_coalitions_from_source_lists_equal_the_forward_on_masked_clouds(model):
+@pytest.mark.parametrize("nclouds", [2, 8])
+def test_coalitions_from_source_lists_equal_the_forward_on_masked_clouds(model, nclouds):
     """iq_pointconv_coalitions (masked clouds written inside; sa1 / sa2 groups from the source clouds' sorted neighbour
     lists, sa1's MLP rows from the per-cloud pair table) against iq_pointconv_forward on the materialised masked clouds
     (pc_knn_kernel, grouped MLP): the same groups up to ties
     and the choice among interchangeable masked points, so the logits agree to summation-order rounding - and the
     kNN-kernel path of the same entry point (tuning key 5 = 14) does too.  Nothing / few / many / everything masked, two
-    source clouds; 40 coalitions so that the lists are used (clouds * 8 <= coalitions)."""
+    source clouds (and [r4] eight - the poses of one sweep launch, each with its own pair table); 40 / 72 coalitions so that the
+    lists are used (clouds * 8 <= coalitions)."""
     from interpret_quality_amd import _lib
     lib = _lib.load()
     d = dev()
     rng = np.random.default_rng(8)
-    clouds = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in (0, 1)]).to(d)
-    rid = torch.empty((2, 1024), dtype=torch.int32)
-    for c in range(2):
+    clouds = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in range(nclouds)]).to(d)
+    rid = torch.empty((nclouds, 1024), dtype=torch.int32)
+    for c in range(nclouds):
         data = clouds[c:c + 1]
         rid[c] = hip_ops.region_assign(data[0].contiguous(), hip_ops.fps(data, 32)[0].contiguous()).cpu()
     centers = clouds.mean(dim=1)
     full = (1 << 32) - 1
-    keep = [full, 0, full ^ (1 << 7), 1 << 3, 0x0f0f0f0f, 0xffff, 7, full ^ 1] + [int(x) for x in rng.integers(0, 1 << 32, size=32)]
-    cloud_of = [i % 2 for i in range(len(keep))]
+    keep = [full, 0, full ^ (1 << 7), 1 << 3, 0x0f0f0f0f, 0xffff, 7, full ^ 1] + [int(x) for x in rng.integers(0, 1 << 32, size=8 * nclouds + 16)]
+    cloud_of = [i % nclouds for i in range(len(keep))]
     keep_t = hip_ops.masks_to_tensor(keep, d)
     co_t = torch.tensor(cloud_of, dtype=torch.int32, device=d)
     got = model.coalition_logits(clouds, centers, rid.to(d), keep_t, co_t, num_regions=32)
