@@ -162,6 +162,8 @@ class Runner:
     def release_models(self):
         """Drop the cached models (and with them their engines' workspaces) and hand the memory back to the device."""
         import gc
+        if not self.model_cache:
+            return                  # nothing cached: no collection (55 ms each, seven times per sweep)
         self.model_cache.clear()
         gc.collect()
         torch.cuda.empty_cache()
