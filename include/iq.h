@@ -386,14 +386,25 @@ int iq_pointconv_forward(const iq_pointconv_weights* w /*host struct of device p
  * (nclouds <= 8, or nclouds * 8 <= B) the K-nearest groups of sa1 and sa2 (models/pointconv.py:103-114) are read off per-source-cloud
  * sorted neighbour lists, built once per call with the kNN kernel's own distance expression: in xyz space neither the
  * distance between two points nor the centre depends on the coalition, only the candidate set does (the same point
- * sets as the kNN kernel up to ties; masked points are interchangeable).  With at most two source clouds sa1's MLP rows
+ * sets as the kNN kernel up to ties; masked points are interchangeable).  With at most eight source clouds sa1's MLP rows
  * - functions of (member point, centroid point) only, sa1 having no input features - come from a table of all (N+1)^2
- * pairs built once per call (1.1 GB of workspace per source cloud) and a group is 32 table rows contracted with the
- * members' density x WeightNet weights.  512 <= N <= 1024.  Asynchronous on `stream`. */
+ * pairs (0.54 GB of workspace per source cloud) and a group is 32 table rows contracted with the members' density x
+ * WeightNet weights, in one kernel with the 2048 -> 128 layer behind it.  512 <= N <= 1024.  Asynchronous on `stream`. */
 size_t iq_pointconv_coalitions_workspace_bytes(int B, int nclouds, int N);
 int iq_pointconv_coalitions(const iq_pointconv_weights* w, const float* clouds, const float* centers,
                             const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of, float* logits,
                             void* workspace, size_t workspace_bytes, int B, int nclouds, int N, iq_stream_t stream);
+/* The same call for several launches on the SAME source clouds (the chunks of one interaction setting,
+ * final_point_binary_interaction_logits.py:37-66; the batches of one pose, tools/final_common.py:78-96).  The per-cloud
+ * structures (padded rows, sorted neighbour lists, pair tables) occupy the first iq_pointconv_tables_bytes(nclouds, N) bytes of
+ * `workspace`, whatever B is.  `tables_state` (HOST int, in / out; NULL = build everything, keep nothing): bit 0 = the lists,
+ * bit 1 = the pair tables are already there for exactly these clouds, centers, nclouds and N - the caller's promise (same
+ * workspace base, bytes untouched since the call that set the bit).  Missing parts are built and their bits set. */
+size_t iq_pointconv_tables_bytes(int nclouds, int N);
+int iq_pointconv_coalitions_cached(const iq_pointconv_weights* w, const float* clouds, const float* centers,
+                                   const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of, float* logits,
+                                   void* workspace, size_t workspace_bytes, int B, int nclouds, int N, int* tables_state,
+                                   iq_stream_t stream);
 
 /* Optional HIP-event profiler (bench.py's roofline leg).  While enabled, iq_pointnet_coalitions
  * brackets its chain-kernel launches with hipEvents recorded on the launch stream.

@@ -112,6 +112,9 @@ SIGNATURES = {
     "iq_pointconv_forward": (_I, [ctypes.POINTER(PointConvWeights), _P, _P, _P, _SZ, _I, _I, _P]),
     "iq_pointconv_coalitions_workspace_bytes": (_SZ, [_I, _I, _I]),
     "iq_pointconv_coalitions": (_I, [ctypes.POINTER(PointConvWeights), _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
+    "iq_pointconv_tables_bytes": (_SZ, [_I, _I]),
+    "iq_pointconv_coalitions_cached": (_I, [ctypes.POINTER(PointConvWeights), _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I,
+                                          ctypes.POINTER(ctypes.c_int), _P]),
     "iq_profile_enable": (_I, [_I]),
     "iq_set_tuning": (_I, [_I, _I]),
     "iq_debug_chain_occupancy": (_I, []),

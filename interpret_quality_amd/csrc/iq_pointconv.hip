@@ -1063,8 +1063,26 @@ struct WsW {   // coalition extras behind the forward's workspace
 // 20.5 ms for the grouped MLP (round 3 stopped at 2 clouds).  Building a table costs ~0.4 ms per cloud and launch.
 constexpr int kTabClouds = 8;
 
-WsW carve_w(void* base, int B, int nc, int N) {
-    WsW s{};
+// Two parts.  `cloud` = what depends on the SOURCE clouds only (their padded rows, sorted neighbour lists, sa1 pair tables): it
+// sits at the very start of the workspace, at offsets that depend on (nc, N) alone, so that a caller that evaluates chunk after
+// chunk of coalitions of the same clouds can have it kept (iq_pointconv_coalitions_cached).  `rest` = per-coalition arrays and
+// the scratch of the table build; it follows the forward's own workspace.
+size_t carve_w_cloud(WsW& s, void* base, int nc, int N) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = iq::align_up(off + bytes, 256);
+        return reinterpret_cast<char*>(base) + o;
+    };
+    const size_t Nsp = (size_t)(N + 1 + 31) / 32 * 32, Nsl = (size_t)(N + 1 + 7) / 8 * 8;
+    s.xs = (float*)take((size_t)nc * Nsp * 8 * 4);
+    s.xxs = (float*)take((size_t)nc * Nsp * 4);
+    s.sorted = (int16_t*)take((size_t)nc * (N + 1) * Nsl * 2);
+    if (nc <= kTabClouds) s.feat = (float*)take((size_t)nc * (size_t)(N + 1) * (N + 1) * 128 * 4);
+    return off;
+}
+
+size_t carve_w_rest(WsW& s, void* base, int B, int nc, int N) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;
@@ -1073,10 +1091,7 @@ WsW carve_w(void* base, int B, int nc, int N) {
     };
     const size_t Nsp = (size_t)(N + 1 + 31) / 32 * 32, Nsl = (size_t)(N + 1 + 7) / 8 * 8;
     s.X = (float*)take((size_t)B * N * 3 * 4);
-    s.xs = (float*)take((size_t)nc * Nsp * 8 * 4);
-    s.xxs = (float*)take((size_t)nc * Nsp * 4);
     s.dmat = (float*)take((size_t)nc * Nsp * Nsp * 4);
-    s.sorted = (int16_t*)take((size_t)nc * (N + 1) * Nsl * 2);
     s.kept = (uint32_t*)take((size_t)B * 32 * 4);
     s.mfirst = (int16_t*)take((size_t)B * 64 * 2);
     s.mcount = (int32_t*)take((size_t)B * 4);
@@ -1086,10 +1101,8 @@ WsW carve_w(void* base, int B, int nc, int N) {
         const size_t rows = (size_t)(N + 1) * (N + 1);
         s.th1 = (float*)take(rows * 64 * 4);
         s.th2 = (float*)take(rows * 64 * 4);
-        s.feat = (float*)take((size_t)nc * rows * 128 * 4);
     }
-    s.bytes = off;
-    return s;
+    return off;
 }
 
 }  // namespace
@@ -1111,27 +1124,55 @@ extern "C" int iq_pointconv_forward(const iq_pointconv_weights* w, const float* 
 
 extern "C" size_t iq_pointconv_coalitions_workspace_bytes(int B, int nclouds, int N) {
     if (B < 0 || nclouds < 1 || N < 1) return 0;
-    return iq::align_up(carve_c(nullptr, B, N).bytes, 256) + carve_w(nullptr, B, nclouds, N).bytes;
+    WsW t{};
+    return carve_w_cloud(t, nullptr, nclouds, N) + iq::align_up(carve_c(nullptr, B, N).bytes, 256) + carve_w_rest(t, nullptr, B, nclouds, N);
+}
+
+extern "C" size_t iq_pointconv_tables_bytes(int nclouds, int N) {
+    if (nclouds < 1 || N < 1) return 0;
+    WsW t{};
+    return carve_w_cloud(t, nullptr, nclouds, N);
 }
 
 // Logits of B coalitions given as region bit masks over nclouds source clouds (same call as iq_pointnet2_coalitions): the
 // masked clouds are written into the workspace and run through the forward; when a few source clouds serve many coalitions
 // (nclouds * 8 <= B, N <= 1024) the K-nearest groups of sa1 / sa2 come from the source clouds' sorted neighbour lists.
+extern "C" int iq_pointconv_coalitions_cached(const iq_pointconv_weights* w, const float* clouds, const float* centers,
+                                              const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of, float* logits,
+                                              void* workspace, size_t workspace_bytes, int B, int nclouds, int N, int* tables_state,
+                                              iq_stream_t stream);
+
 extern "C" int iq_pointconv_coalitions(const iq_pointconv_weights* w, const float* clouds, const float* centers,
                                        const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of, float* logits,
                                        void* workspace, size_t workspace_bytes, int B, int nclouds, int N, iq_stream_t stream) {
+    return iq_pointconv_coalitions_cached(w, clouds, centers, region_id, keep, cloud_of, logits, workspace, workspace_bytes, B, nclouds, N,
+                                          nullptr, stream);
+}
+
+// The same call for a caller that evaluates several launches on the SAME source clouds (the chunks of an interaction setting, the
+// batches of a Shapley pose): `tables_state` (host int, in / out) says which per-cloud structures the first
+// iq_pointconv_tables_bytes(nclouds, N) bytes of `workspace` already hold - bit 0 the sorted neighbour lists, bit 1 the sa1 pair
+// tables - for exactly these clouds, centres, nclouds and N (the caller's promise: same workspace base, contents untouched);
+// what is missing is built and the bits are set.  Round 3 rebuilt both on every call (~1 GB of writes per source cloud).
+extern "C" int iq_pointconv_coalitions_cached(const iq_pointconv_weights* w, const float* clouds, const float* centers,
+                                              const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of, float* logits,
+                                              void* workspace, size_t workspace_bytes, int B, int nclouds, int N, int* tables_state,
+                                              iq_stream_t stream) {
     IQ_REQUIRE(B >= 0 && nclouds >= 1, "iq_pointconv_coalitions: B=%d nclouds=%d", B, nclouds);
     IQ_REQUIRE(w && clouds && centers && region_id && (B == 0 || (keep && logits)), "iq_pointconv_coalitions: null pointer");
     IQ_REQUIRE(N >= 512 && N <= kWalkMaxN, "iq_pointconv_coalitions: N=%d not in [512, %d]", N, kWalkMaxN);
     IQ_REQUIRE(cloud_of || nclouds == 1 || nclouds == B, "iq_pointconv_coalitions: cloud_of required when 1 < nclouds != B");
     IQ_REQUIRE(w->sa[0].nsample == 32 && w->sa[1].nsample == 64, "iq_pointconv_coalitions: nsample must be 32 / 64");
     if (B == 0) return IQ_OK;
+    WsW t{};
+    const size_t cloud_bytes = carve_w_cloud(t, workspace, nclouds, N);
     const size_t base_bytes = iq::align_up(carve_c(nullptr, B, N).bytes, 256);
-    const size_t need = base_bytes + carve_w(nullptr, B, nclouds, N).bytes;
+    const size_t need = cloud_bytes + base_bytes + carve_w_rest(t, nullptr, B, nclouds, N);
     if (!workspace || workspace_bytes < need)
         return iq::fail(IQ_EWORKSPACE, "iq_pointconv_coalitions: workspace %zu < %zu bytes", workspace_bytes, need);
-    WsC s = carve_c(workspace, B, N);
-    WsW t = carve_w(reinterpret_cast<char*>(workspace) + base_bytes, B, nclouds, N);
+    WsC s = carve_c(reinterpret_cast<char*>(workspace) + cloud_bytes, B, N);
+    carve_w_rest(t, reinterpret_cast<char*>(workspace) + cloud_bytes + base_bytes, B, nclouds, N);
+    int have = tables_state ? *tables_state : 0;          // bit 0: sorted lists, bit 1: pair tables (see above)
     hipStream_t st = iq::as_stream(stream);
     int rc;
     iq::ProfileSpan call_span(iq::kSlotCall, st);
@@ -1145,10 +1186,13 @@ extern "C" int iq_pointconv_coalitions(const iq_pointconv_weights* w, const floa
     const bool use_walk = (nclouds <= 8 || (long long)nclouds * 8 <= B) && iq::tuning(iq::kTuneExperiment) != 14;
     PcWalk walk{};
     if (use_walk) {
-        hipLaunchKernelGGL(sl_rows_kernel, dim3((Nsp + 255) / 256, nclouds), dim3(256), 0, st, clouds, centers, t.xs, t.xxs, N, Nsp);
-        hipLaunchKernelGGL(sl_dist_kernel<1>, dim3(Nsp / 32, nclouds), dim3(64), 0, st, t.xs, t.xxs, t.dmat, Nsp);
-        hipLaunchKernelGGL(sl_sort_kernel, dim3(N + 1, nclouds), dim3(256), 0, st, t.dmat, t.sorted, N, Nsp, Nsl);
-        if ((rc = iq::check_launch("sl_sort_kernel"))) return rc;
+        if (!(have & 1)) {
+            hipLaunchKernelGGL(sl_rows_kernel, dim3((Nsp + 255) / 256, nclouds), dim3(256), 0, st, clouds, centers, t.xs, t.xxs, N, Nsp);
+            hipLaunchKernelGGL(sl_dist_kernel<1>, dim3(Nsp / 32, nclouds), dim3(64), 0, st, t.xs, t.xxs, t.dmat, Nsp);
+            hipLaunchKernelGGL(sl_sort_kernel, dim3(N + 1, nclouds), dim3(256), 0, st, t.dmat, t.sorted, N, Nsp, Nsl);
+            if ((rc = iq::check_launch("sl_sort_kernel"))) return rc;
+            have |= 1;
+        }
         walk = PcWalk{t.sorted, t.kept, t.mfirst, t.mcount, t.src1, t.pos, cloud_of, nclouds, Nsl, Nsl, nullptr};
         const iq_pointconv_sa& sa = w->sa[0];
         // (whatever B is: a coalition's logits must not depend on how many others share its launch)
@@ -1156,15 +1200,17 @@ extern "C" int iq_pointconv_coalitions(const iq_pointconv_weights* w, const floa
             iq::tuning(iq::kTuneExperiment) != 15) {   // 5 = 15: the grouped MLP (A/B runs, tests)
             const int n1 = N + 1;
             const size_t rows = (size_t)n1 * n1;
-            for (int c = 0; c < nclouds; ++c) {
+            for (int c = 0; c < nclouds && !(have & 2); ++c) {
                 hipLaunchKernelGGL(pc_tab_l1_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, t.xs + (size_t)c * Nsp * 8,
                                    sa.w1x, t.th1, n1);
                 if ((rc = iq::check_launch("pc_tab_l1_kernel"))) return rc;
                 if ((rc = iq::launch_linear(t.th1, 64, sa.l2, t.th2, 64, (int)rows, 1, st))) return rc;
                 if ((rc = iq::launch_linear(t.th2, 64, sa.l3, t.feat + (size_t)c * rows * 128, 128, (int)rows, 1, st))) return rc;
             }
+            have |= 2;
             walk.feat_tab = t.feat;
         }
     }
+    if (tables_state) *tables_state = have;
     return run_pointconv(w, t.X, logits, s, B, N, st, use_walk ? &walk : nullptr);
 }

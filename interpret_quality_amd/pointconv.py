@@ -77,12 +77,14 @@ class PointConvEngine:
         self.device = torch.device(device)
         self.weights = PackedWeightsC(state_dict, self.device)
         self._ws = None
+        self._tab = {}      # which source clouds the tables at the head of the workspace belong to (coalition_logits)
 
     def forward_points(self, xyz):
         if not xyz.is_cuda or xyz.dtype != torch.float32 or not xyz.is_contiguous():
             raise _lib.IqError("xyz must be a contiguous float32 GPU tensor (B,N,3)")
         b, n, _ = xyz.shape
         workspace.ensure(self, self.lib.iq_pointconv_workspace_bytes(b, n))
+        self._tab = {}              # the dense forward's arrays start at the head of the workspace, where the coalition path keeps its tables
         logits = torch.empty((b, self.weights.num_classes), dtype=torch.float32, device=self.device)
         rc = self.lib.iq_pointconv_forward(ctypes.byref(self.weights.struct), ctypes.c_void_p(xyz.data_ptr()),
                                            ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(self._ws.data_ptr()),
@@ -104,11 +106,28 @@ class PointConvEngine:
         workspace.ensure(self, self.lib.iq_pointconv_coalitions_workspace_bytes(b, nc, n))
         logits = torch.empty((b, self.weights.num_classes), dtype=torch.float32, device=self.device)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
-        rc = self.lib.iq_pointconv_coalitions(ctypes.byref(self.weights.struct), p(clouds), p(centers), p(region_id), p(keep),
-                                              p(cloud_of), p(logits), p(self._ws), self._ws.numel(), b, nc, n,
-                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        state = ctypes.c_int(self._tables_state(clouds, centers, nc, n))
+        rc = self.lib.iq_pointconv_coalitions_cached(ctypes.byref(self.weights.struct), p(clouds), p(centers), p(region_id), p(keep),
+                                                     p(cloud_of), p(logits), p(self._ws), self._ws.numel(), b, nc, n,
+                                                     ctypes.byref(state), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "iq_pointconv_coalitions")
+        self._tab["state"] = state.value
         return logits
+
+    def _tables_state(self, clouds, centers, nc, n):
+        """Which per-cloud structures (sorted lists, sa1 pair tables) the head of the workspace still holds for THESE clouds:
+        the same workspace allocation, the same (nc, N), and the same `clouds` / `centers` TENSORS at the same version (torch
+        counts every in-place write) as the call that built them - an identity test, no read-back, no synchronisation (comparing
+        the coordinates on the device cost a host sync per launch: 4.8 ms of exposed launch latency per 3300-coalition step).
+        The two tensors are held, so their memory cannot be handed to other data meanwhile.  The launches of one driver call
+        (the chunks of an interaction ratio, the batches of a pose) pass the same tensors and re-use the tables; round 3 rebuilt
+        ~1 GB per source cloud on every launch.  (Writing into a held tensor behind torch's back - a raw pointer - is not seen.)"""
+        t = self._tab
+        key = (self._ws.data_ptr(), nc, n, clouds.data_ptr(), clouds._version, centers.data_ptr(), centers._version)
+        if t.get("key") == key and t.get("state", 0) and t["clouds"] is clouds and t["centers"] is centers:
+            return int(t["state"])
+        self._tab = {"key": key, "clouds": clouds, "centers": centers, "state": 0}
+        return 0
 
 
 def _tiny_holder(dims):

@@ -56,6 +56,8 @@ def ensure(eng, nbytes):
     """The engine's workspace, at least nbytes; the old one is dropped BEFORE the new one is allocated (never both alive)."""
     if eng._ws is None or eng._ws.numel() < nbytes:
         eng._ws = None
+        if hasattr(eng, "_tab"):
+            eng._tab = {}           # whatever the old workspace cached (PointConv's per-cloud tables) is gone
         eng._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=eng.device)
     return eng._ws
 

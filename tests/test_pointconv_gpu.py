@@ -121,3 +121,48 @@ def test_coalitions_from_source_lists_equal_the_forward_on_masked_clouds(model, 
     # a coalition's logits do not depend on what else is in the launch (the fused kernel's tiles are per coalition)
     solo = model.coalition_logits(clouds, centers, rid.to(d), keep_t[5:6].contiguous(), co_t[5:6].contiguous(), num_regions=32)
     assert torch.equal(solo[0], got[5])
+
+
+def test_per_cloud_tables_are_kept_across_launches_and_never_go_stale(model):
+    """iq_pointconv_coalitions_cached: the sorted lists and sa1 pair tables of the source clouds stay at the head of the workspace
+    between launches that pass the same cloud / centre tensors (chunks of an interaction ratio, batches of a pose).  Same logits,
+    bit for bit, as an engine that builds them for every launch; a dense forward in between (it overwrites the head), other
+    tensors, an in-place write into the same tensor, a different number of coalitions (every B-dependent offset moves) and a
+    larger workspace (re-allocation) are all noticed."""
+    d = dev()
+    rng = np.random.default_rng(3)
+    eng = model.engine()
+
+    def setup(ids):
+        clouds = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in ids]).to(d)
+        rid = torch.stack([hip_ops.region_assign(clouds[c].contiguous(), hip_ops.fps(clouds[c:c + 1], 32)[0].contiguous()) for c in range(len(ids))])
+        return clouds, clouds.mean(dim=1).contiguous(), rid.contiguous()
+
+    def fresh(clouds, centers, rid, keep, co):
+        eng._tab = {}
+        return model.coalition_logits(clouds, centers, rid, keep, co, num_regions=32)
+
+    a = setup((2, 3))
+    keep = hip_ops.masks_to_tensor([int(x) for x in rng.integers(0, 1 << 32, size=48)], d)
+    co = torch.tensor([i % 2 for i in range(48)], dtype=torch.int32, device=d)
+    first = fresh(*a, keep, co)
+    assert eng._tab.get("state") == 3                                   # lists and pair tables built and remembered
+    again = model.coalition_logits(*a, keep, co, num_regions=32)        # re-used
+    assert eng._tab.get("state") == 3 and torch.equal(first, again)
+    part = model.coalition_logits(*a, keep[:17].contiguous(), co[:17].contiguous(), num_regions=32)   # another B: re-used too
+    assert torch.equal(part, first[:17])
+    model.forward_points(a[0])                                          # the dense forward takes the head of the workspace
+    assert eng._tab == {}
+    assert torch.equal(model.coalition_logits(*a, keep, co, num_regions=32), first)
+    b = setup((4, 5))                                                   # other clouds in new tensors
+    got_b = model.coalition_logits(*b, keep, co, num_regions=32)
+    assert torch.equal(got_b, fresh(*b, keep, co)) and not torch.equal(got_b, first)
+    a[0][1, 7, 0] += 0.25                                               # the same tensor, one coordinate changed in place
+    rid1 = hip_ops.region_assign(a[0][1].contiguous(), hip_ops.fps(a[0][1:2], 32)[0].contiguous())
+    a2 = (a[0], a[0].mean(dim=1).contiguous(), torch.stack([a[2][0], rid1]).contiguous())
+    moved = model.coalition_logits(*a2, keep, co, num_regions=32)
+    assert torch.equal(moved, fresh(*a2, keep, co)) and not torch.equal(moved, first)
+    big = hip_ops.masks_to_tensor([int(x) for x in rng.integers(0, 1 << 32, size=4000)], d)   # a larger workspace: re-allocated
+    cob = torch.tensor([i % 2 for i in range(4000)], dtype=torch.int32, device=d)
+    model.coalition_logits(*a2, big, cob, num_regions=32)
+    assert torch.equal(model.coalition_logits(*a2, keep, co, num_regions=32), moved)
