@@ -294,16 +294,16 @@ __global__ void knn_dbg_fetch_kernel(unsigned long long* dst) {
 // is FLAGGED: near_tie[row] holds its 21st candidate (else -1), its neighbour list the other 20 as raw rows, and
 // knn_refine_kernel re-ranks the 21 in exact arithmetic (bit 20 of the word: the gap is exactly zero - identical rows, as in
 // a dense masked cloud, may hide further candidates - so all rows are ranked).
-template <int C, bool REFINE, int PF = 1>
-__global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ xx,
+template <int C, bool REFINE, int PF = 1, int QCAP = 16>
+__global__ __launch_bounds__(64, C == 128 ? (QCAP < 16 ? 3 : 2) : (QCAP < 16 ? 4 : 3)) void knn_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ xx,
                                                  int16_t* __restrict__ idx, int32_t* __restrict__ near_tie, Ragged rg, int B,
                                                  int tiles_per_cloud, int dbg) {
     constexpr int KB = C / 8;
     constexpr int KL = REFINE ? kK + 1 : kK;   // list length
     // REFINE: the integer list with tagged indices (iq_topk.h: TaggedTopK) - its 32-ulp buckets lie far inside the band that
     // knn_refine_kernel re-ranks exactly; the exact-only kernel keeps the packed fp64 list
-    using Sel = std::conditional_t<REFINE, TaggedTopK<KL, 16>, QueuedTopK<KL, 16>>;
-    constexpr int kSelLds = REFINE ? TaggedTopK<KL, 16>::kLdsBytes : 17 * 64 * 8;   // queue: 16 slots per lane + the overflow slot of push()
+    using Sel = std::conditional_t<REFINE, TaggedTopK<KL, QCAP>, QueuedTopK<KL, 16>>;
+    constexpr int kSelLds = REFINE ? TaggedTopK<KL, QCAP>::kLdsBytes : 17 * 64 * 8;   // queue: QCAP slots per lane + the overflow slot of push()
     __shared__ __attribute__((aligned(16))) unsigned char queue[kSelLds];
     __shared__ __attribute__((aligned(16))) float kxs[2 * 64];   // |key|^2 of two pairs of key tiles (double-buffered)
     const int lane = threadIdx.x;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64, C == 128 ? 2 : 3) void knn_kernel(const float* 
     for (;;) {
         const unsigned long long busy = __ballot(sel.cnt > 0);
         const bool last = half == 2 && k == npairs;
-        if (busy != 0 && (last || __popcll(busy) >= kRoundLanes || __any(sel.cnt > 8))) {
+        if (busy != 0 && (last || __popcll(busy) >= kRoundLanes || __any(sel.cnt > (REFINE ? QCAP : 16) - 8))) {
             if ((dbg & 3) == 3) { ++dbg_rounds; dbg_work += __popcll(busy); }
             sel.round(lane);
             continue;
@@ -1038,17 +1038,16 @@ int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, in
     else if (C == 64 && !refine) hipLaunchKernelGGL((knn_kernel<64, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
     else if (C == 128 && !refine) hipLaunchKernelGGL((knn_kernel<128, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
     else if (C == 64) {
-        const int pf = iq::tuning(iq::kTuneExperiment);   // 5 = 40 / 41: key fragments 2 / 4 k-blocks ahead (A/B)
-        if (pf == 40) hipLaunchKernelGGL((knn_kernel<64, true, 2>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
-        else if (pf == 41) hipLaunchKernelGGL((knn_kernel<64, true, 4>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
+        // 12 queue slots per lane instead of 16: 10 KB of LDS per wave, FOUR waves per SIMD (116 VGPRs) - the selection's VALU
+        // work of one wave overlaps with the MFMAs of more neighbours: 28.0 -> 26.7 ms in a same-call A/B (5 = 44: 16 slots, three
+        // waves).  Measured and not adopted: key fragments 2 / 4 k-blocks ahead instead of 1 (27.9 / 27.8 ms), 10 slots (27.0 ms),
+        // the C = 128 kernel at three waves per SIMD (no change)
+        if (iq::tuning(iq::kTuneExperiment) == 44)
+            hipLaunchKernelGGL((knn_kernel<64, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
         else
-        hipLaunchKernelGGL((knn_kernel<64, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
+            hipLaunchKernelGGL((knn_kernel<64, true, 1, 12>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
         hipLaunchKernelGGL(knn_refine_kernel<64>, rgrid, dim3(64), 0, st, x, ldx, near_tie, idx, rg, B, slice_addr ? 1 : 0, (dbg & 3) == 3);
     } else if (C == 128) {
-        const int pf = iq::tuning(iq::kTuneExperiment);
-        if (pf == 40) hipLaunchKernelGGL((knn_kernel<128, true, 2>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
-        else if (pf == 41) hipLaunchKernelGGL((knn_kernel<128, true, 4>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
-        else
         hipLaunchKernelGGL((knn_kernel<128, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
         hipLaunchKernelGGL(knn_refine_kernel<128>, rgrid, dim3(64), 0, st, x, ldx, near_tie, idx, rg, B, slice_addr ? 1 : 0, (dbg & 3) == 3);
     } else return iq::fail(IQ_EUNSUPPORTED, "knn: C=%d has no kernel instantiation (8, 64, 128)", C);
