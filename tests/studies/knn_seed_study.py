@@ -2,7 +2,8 @@
 clouds of 8 / 16 / 24 / 32 kept regions, per feature-space layer: the number of keys per query that pass tau = the farthest of the
 query's 20 previous neighbours, measured in this layer's features (20 must pass), and how many of the previous neighbours are
 neighbours again.  Result (profiles/r04_knn_seeded.txt): 27-35 pass on average, p99 42-77; 16.3-18.0 of 20 stay."""
-import sys; sys.path.insert(0,'/root/repo')
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # (under tests/: the oracle is test infrastructure)
 import numpy as np, torch
 from oracle import ref_cpu as O
 from interpret_quality_amd import synth
