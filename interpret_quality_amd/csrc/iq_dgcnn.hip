@@ -839,7 +839,7 @@ __device__ __forceinline__ unsigned long long edge_clock() {
     return t;
 }
 
-template <int KB>   // Cin / 8
+template <int KB, int NBR = kK>   // Cin / 8; NBR < kK: timing probe (half of the neighbours: the gather's instructions halved, results wrong)
 __global__ __launch_bounds__(kGlThreads, 4) void edge_fused_kernel(const float* __restrict__ x, int ldx,
                                                                    const float* __restrict__ wp, const float* __restrict__ bias,
                                                                    int Co, const int16_t* __restrict__ idx,
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(kGlThreads, 4) void edge_fused_kernel(const float* 
             auto rd = [&](unsigned a) { return *reinterpret_cast<const f32x4*>(sb + a); };
             f32x4 m0 = rd(nb[0] ^ hx), m1 = rd(nb[0] ^ hx ^ 32u);
 #pragma unroll
-            for (int j = 1; j < kK; ++j) {
+            for (int j = 1; j < NBR; ++j) {
                 const unsigned a = nb[j] ^ hx;
                 const f32x4 v0 = rd(a), v1 = rd(a ^ 32u);
 #pragma unroll
@@ -1219,6 +1219,10 @@ int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, i
                 const iq_dense_layer& L = w->pq[l];
                 if (cin == 8)
                     hipLaunchKernelGGL(edge_fused_kernel<1>, grid, dim3(kGlThreads), 0, st, src, ld, L.w, L.b, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud, knob == 10);
+                else if (cin == 64 && knob == 47)
+                    hipLaunchKernelGGL((edge_fused_kernel<8, 10>), grid, dim3(kGlThreads), 0, st, src, ld, L.w, L.b, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud, 0);
+                else if (cin == 128 && knob == 47)
+                    hipLaunchKernelGGL((edge_fused_kernel<16, 10>), grid, dim3(kGlThreads), 0, st, src, ld, L.w, L.b, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud, 0);
                 else if (cin == 64)
                     hipLaunchKernelGGL(edge_fused_kernel<8>, grid, dim3(kGlThreads), 0, st, src, ld, L.w, L.b, co, s.idx, s.xc + col, 512, rg, B, wgs_per_cloud, knob == 10);
                 else
