@@ -38,6 +38,17 @@ __host__ __device__ inline bool keep_bit(unsigned long long keep, int rid) {
     return (unsigned)rid < 64u && ((keep >> rid) & 1ull);
 }
 
+// The cloud a workgroup of an XCD-aware grid works on.  Workgroups go round-robin over the 8 XCDs (blockIdx & 7); all
+// workgroups of a cloud sit on one XCD (they share its rows through one L2), clouds c = 8 k + xcd.  A batch whose work has
+// period 4 in the cloud index - the four masked clouds S+{i,j}, S+{i}, S+{j}, S of every interaction context, largest first
+// (final_point_binary_interaction_logits.py:48-52) - would put every largest cloud on XCDs 0 and 4 and every smallest on 3 and
+// 7 (kNN work ~ rows^2: 9.6 % above the mean over the 13 ratios, 2x for the low orders): the low two bits of the cloud index
+// are rotated by the group-of-eight number, so each XCD sees all four kinds equally often.  A bijection on every full group of 4.
+__device__ inline int xcd_cloud(int block, int wgs_per_cloud, int B) {
+    const int c = ((block >> 3) / wgs_per_cloud) * 8 + (block & 7);
+    return (c | 3) < B ? (c & ~3) | ((c + (c >> 3)) & 3) : c;
+}
+
 }  // namespace iq
 
 #define IQ_REQUIRE(cond, ...) \

@@ -309,8 +309,8 @@ __global__ __launch_bounds__(64, C == 128 ? (QCAP < 16 ? 3 : 2) : (QCAP < 16 ? 4
     const int lane = threadIdx.x;
     // workgroups go round-robin over the 8 XCDs: give each XCD whole clouds, so that the ~17 waves which stream the same
     // keys share one L2 (and often one L1) instead of pulling the cloud into all eight
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int b = (slot / tiles_per_cloud) * 8 + xcd;
+    const int slot = blockIdx.x >> 3;
+    const int b = iq::xcd_cloud(blockIdx.x, tiles_per_cloud, B);
     if (b >= B) return;
     const int base = rg.roff[b];
     const int N = rg.roff[b + 1] - base;          // padded rows of this cloud (multiple of 32)
@@ -673,8 +673,8 @@ __global__ __launch_bounds__(kThreads) void gather_max_kernel(const float* __res
     // cloud were pulled into all eight L2s: FETCH_SIZE showed 4-9x the bytes of the PQ matrix per launch at 57 % L2 hit
     // rate and the kernel ran at the fabric's 6.4 TB/s (profiles/r02_stream_kernels.csv).  Adjacent clouds run on
     // adjacent XCDs at the same time, so the eight row streams stay close together in memory.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int b = (slot / wgs_per_cloud) * 8 + xcd;
+    const int slot = blockIdx.x >> 3;
+    const int b = iq::xcd_cloud(blockIdx.x, wgs_per_cloud, B);
     if (b >= B) return;
     const int base = rg.roff[b];
     const int pt = base + (slot % wgs_per_cloud) * (kThreads / per) + threadIdx.x / per;
@@ -728,8 +728,8 @@ __global__ __launch_bounds__(kGlThreads, 4) void gather_lds_kernel(const float* 
                                                                 const int16_t* __restrict__ idx, float* __restrict__ out,
                                                                 int ldo, Ragged rg, int B, int wgs_per_cloud) {
     __shared__ f32x4 slice[kGlFloats / 4];
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;   // whole clouds per XCD, as in gather_max_kernel
-    const int b = (slot / wgs_per_cloud) * 8 + xcd;
+    const int slot = blockIdx.x >> 3;   // whole clouds per XCD, as in gather_max_kernel
+    const int b = iq::xcd_cloud(blockIdx.x, wgs_per_cloud, B);
     if (b >= B) return;
     const int base = rg.roff[b];
     const int D = rg.roff[b + 1] - base;
@@ -851,8 +851,8 @@ __global__ __launch_bounds__(kGlThreads, 4) void edge_fused_kernel(const float* 
     __shared__ f32x4 wl[KB * 64];                             // weight fragments [kb][lane]
     unsigned long long ts[5];
     if (stamps) ts[0] = edge_clock();
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;   // whole clouds per XCD, as in gather_max_kernel
-    const int b = (slot / wgs_per_cloud) * 8 + xcd;
+    const int slot = blockIdx.x >> 3;   // whole clouds per XCD, as in gather_max_kernel
+    const int b = iq::xcd_cloud(blockIdx.x, wgs_per_cloud, B);
     if (b >= B) return;
     const int base = rg.roff[b];
     const int D = rg.roff[b + 1] - base;                      // multiple of 32, <= kGlMaxRows (host)

@@ -84,8 +84,8 @@ __global__ __launch_bounds__(kThreads, 1) void pc_knn_kernel(const float* __rest
     __shared__ float kxx[2][32];
     __shared__ double queue[kThreads / 64][16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;   // XCD-aware: a cloud's workgroups share one L2
-    const int b = (slot / wgs_per_cloud) * 8 + xcd;
+    const int slot = blockIdx.x >> 3;   // XCD-aware: a cloud's workgroups share one L2
+    const int b = iq::xcd_cloud(blockIdx.x, wgs_per_cloud, B);
     if (b >= B) return;
     if (n_unique && (slot % wgs_per_cloud) * 128 >= n_unique[b]) return;   // duplicate centroids (copies of centroid 0): filled later
     const float* kb = keys8 + (size_t)b * N * 8;
@@ -255,8 +255,8 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_kernel(PcGroupArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 1-D grid; workgroups go round-robin over the 8 XCDs: keep all workgroups of a cloud on one XCD (one L2 holds its
     // U rows and member records)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int b = (slot / a.wgs_per_cloud) * 8 + xcd;
+    const int slot = blockIdx.x >> 3;
+    const int b = iq::xcd_cloud(blockIdx.x, a.wgs_per_cloud, a.B);
     if (b >= a.B) return;
     const int K = a.K;                                   // 32 or 64
     const int live_groups = a.n_unique ? min(a.S, a.n_unique[b]) : a.S;

@@ -228,8 +228,8 @@ __global__ __launch_bounds__(kThreads, WPS) void pn2_group_kernel(GroupArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 1-D grid, workgroups round-robin over the 8 XCDs: all workgroups of a cloud on one XCD (its U rows, coordinates and
     // indices are then fetched into one L2)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int b = (slot / a.wgs_per_cloud) * 8 + xcd;
+    const int slot = blockIdx.x >> 3;
+    const int b = iq::xcd_cloud(blockIdx.x, a.wgs_per_cloud, a.B);
     if (b >= a.B) return;
     const int K = a.K;
     const int32_t* bstart = a.block_start + (size_t)b * (a.S + 1);
@@ -811,8 +811,8 @@ __global__ __launch_bounds__(kThreads) void pt_gather_kernel(GatherArgs a) {
     const int t = threadIdx.x, gl = t / per, c4 = t - gl * per;
     // XCD-aware: a coalition's groups on one XCD (its index lists and the cloud's table rows stay in one L2)
     const int wgs_per_cloud = (a.S + gpb - 1) / gpb;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int b = (slot / wgs_per_cloud) * 8 + xcd;
+    const int slot = blockIdx.x >> 3;
+    const int b = iq::xcd_cloud(blockIdx.x, wgs_per_cloud, a.B);
     if (b >= a.B) return;
     const int s = (slot % wgs_per_cloud) * gpb + gl;
     if (s >= a.S || s >= a.n_unique[b]) return;     // duplicate centroids are filled from group 0 afterwards
