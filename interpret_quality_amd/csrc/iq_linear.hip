@@ -125,21 +125,34 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
                                                                   int ldo, int M, int K, int Nout, int relu,
                                                                   const int32_t* __restrict__ m_dev,
                                                                   const float* __restrict__ row_w,
-                                                                  const int32_t* __restrict__ tile_nu, int rows_per_cloud) {
+                                                                  const int32_t* __restrict__ tile_nu, int rows_per_cloud,
+                                                                  int col_blocks) {
     constexpr int KC = 32, LDA = KC + 4;
     constexpr int TM = (4 / WN) * 64;            // rows of the workgroup tile
     static_assert(WN == 1 || WN == 2, "WN");
     static_assert(!POOL || WN == 2, "the pooling epilogue assumes 128-row tiles");
     __shared__ __attribute__((aligned(16))) float As[2][TM * LDA];
     __shared__ float wrow[POOL ? 128 : 1];       // pooling weights of the tile's rows (read in the epilogue)
+    // col_blocks > 0: a 1-D grid in which the column blocks of one row tile are neighbours ON THE SAME XCD (workgroups go
+    // round-robin over the 8 XCDs): id = ((tile / 8) * col_blocks + column block) * 8 + tile % 8.  In a (tiles, column blocks)
+    // grid the workgroups that read the same 128 rows of A sit a whole grid row apart, on whichever XCDs - each pulls the rows
+    // from HBM into its own L2 (conv5: 12.7 GB of activations read four times per step).
+    const int row_tiles = (M + TM - 1) / TM;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (col_blocks > 0) {
+        const int per = 8 * col_blocks, grp = blockIdx.x / per, r = blockIdx.x - grp * per;
+        bx = grp * 8 + (r & 7);
+        by = r >> 3;
+        if (bx >= row_tiles) return;
+    }
     if (m_dev) M = min(M, *m_dev);
-    int m0 = blockIdx.x * TM;
+    int m0 = bx * TM;
     if (tile_nu) {   // rows beyond a cloud's live count are not wanted: skip tiles that hold nothing else
         // A cloud's live tiles are its FIRST ones and workgroups go round-robin over the 8 XCDs: in plain order (4 tiles per
         // cloud) every first tile lands on XCDs 0 and 4 and the XCDs that hold the last tiles idle (live workgroups 33 : 21 per
         // 33 coalitions of a Shapley batch).  Walk the grid cloud-fastest instead: every XCD sees every tile index equally often.
-        const int ntc = rows_per_cloud / TM, nc = gridDim.x / ntc;
-        if (nc * ntc == (int)gridDim.x) m0 = ((blockIdx.x % nc) * ntc + blockIdx.x / nc) * TM;
+        const int ntc = rows_per_cloud / TM, nc = row_tiles / ntc;
+        if (nc * ntc == row_tiles) m0 = ((bx % nc) * ntc + bx / nc) * TM;
         if (m0 >= M) return;
         const int c = m0 / rows_per_cloud;
         if (m0 - c * rows_per_cloud >= tile_nu[c]) return;
@@ -150,7 +163,7 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
     if (POOL && tid < 128) wrow[tid] = m0 + tid < M ? row_w[m0 + tid] : 0.f;   // visible after the K loop's barriers
     const int KB = K >> 3, nchunks = K / KC;
     const int ntiles = (Nout + 31) >> 5;
-    const int nt0 = (blockIdx.y * WN + wn) * NT;
+    const int nt0 = (by * WN + wn) * NT;
 
     // chunk copy: TM rows x 8 float4; thread t owns (row, c4) = (e >> 3, e & 7) for e = t + 256 i.  Buffer loads on a
     // resource based at this workgroup's first row: loop-invariant per-lane offsets, the K position is a scalar offset.
@@ -308,20 +321,21 @@ int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* o
             // 320 / 640 ... outputs: column blocks of exactly 10 tiles (NT = 5), nothing padded
             dim3 grid((M + 127) / 128, ntiles / 10);
             hipLaunchKernelGGL((pn_gemm_lds_kernel<5, false>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
-                               L.cout, relu, m_dev, nullptr, tile_nu, rows_per_cloud);
+                               L.cout, relu, m_dev, nullptr, tile_nu, rows_per_cloud, 0);
         } else if (ntiles == 4 && shape != 30 && (M + 255) / 256 >= 2048) {
             // 128 outputs: 256-row workgroup tiles, every wave all four column tiles
             dim3 grid((M + 255) / 256, 1);
             hipLaunchKernelGGL((pn_gemm_lds_kernel<4, false, 1>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
-                               L.cout, relu, m_dev, nullptr, rows_per_cloud % 256 == 0 ? tile_nu : nullptr, rows_per_cloud);
+                               L.cout, relu, m_dev, nullptr, rows_per_cloud % 256 == 0 ? tile_nu : nullptr, rows_per_cloud, 0);
         } else if (ntiles >= 8 && (long long)((M + 127) / 128) * ((ntiles + 7) / 8) >= 2048) {
-            dim3 grid((M + 127) / 128, (ntiles + 7) / 8);
-            hipLaunchKernelGGL((pn_gemm_lds_kernel<4, false>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
-                               L.cout, relu, m_dev, nullptr, tile_nu, rows_per_cloud);
+            const int gx = (M + 127) / 128, gy = (ntiles + 7) / 8;
+            const bool flat = gy > 1 && shape != 48;       // column blocks of a row tile side by side on one XCD (see the kernel)
+            hipLaunchKernelGGL((pn_gemm_lds_kernel<4, false>), flat ? dim3((unsigned)((gx + 7) / 8 * 8 * gy)) : dim3(gx, gy), dim3(kThreads), 0,
+                               st, A, lda, L.w, L.b, out, ldo, M, L.cin, L.cout, relu, m_dev, nullptr, tile_nu, rows_per_cloud, flat ? gy : 0);
         } else {
             dim3 grid((M + 127) / 128, (ntiles + 3) / 4);
             hipLaunchKernelGGL((pn_gemm_lds_kernel<2, false>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
-                               L.cout, relu, m_dev, nullptr, tile_nu, rows_per_cloud);
+                               L.cout, relu, m_dev, nullptr, tile_nu, rows_per_cloud, 0);
         }
         return iq::check_launch("pn_gemm_lds_kernel");
     }
@@ -383,9 +397,14 @@ int iq::launch_linear_pool(const float* A, int lda, const iq_dense_layer& L, flo
     const int ntiles = (L.cout + 31) / 32;
     if (L.cin % 32 != 0 || ntiles < 8 || L.cout % 32 != 0)
         return iq::fail(IQ_EUNSUPPORTED, "dense layer + pool: cin=%d cout=%d", L.cin, L.cout);
-    dim3 grid((M + 127) / 128, (ntiles + 7) / 8);
-    hipLaunchKernelGGL((pn_gemm_lds_kernel<4, true>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, partial, 0, M, L.cin, L.cout,
-                       relu, m_dev, row_w, nullptr, 0);
+    const int gy = (ntiles + 7) / 8, gx = (M + 127) / 128;
+    if (iq::tuning(iq::kTuneExperiment) == 48) {   // 5 = 48: the (tiles, column blocks) grid of rounds 1-3 (A/B)
+        hipLaunchKernelGGL((pn_gemm_lds_kernel<4, true>), dim3(gx, gy), dim3(kThreads), 0, st, A, lda, L.w, L.b, partial, 0, M, L.cin, L.cout,
+                           relu, m_dev, row_w, nullptr, 0, 0);
+    } else {
+        hipLaunchKernelGGL((pn_gemm_lds_kernel<4, true>), dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda, L.w, L.b,
+                           partial, 0, M, L.cin, L.cout, relu, m_dev, row_w, nullptr, 0, gy);
+    }
     return iq::check_launch("pn_gemm_lds_kernel<pool>");
 }
 
