@@ -205,6 +205,12 @@ int iq_linear(const float* A, int lda, const iq_dense_layer* L, float* out, int 
 size_t iq_packed_floats(int cout, int cin);
 int iq_padded_cout(int cout);
 int iq_pack_weight(const float* w_host /*cout,cin*/, float* out_host, int cout, int cin);
+/* The same weight as THREE bf16 terms (h = bf16(w), m = bf16(w - h), l = bf16(w - h - m), round to nearest even: 24 mantissa bits)
+ * in the fragment order of v_mfma_f32_32x32x16_bf16: [term][n-tile][k-step of 16][lane][8], iq_packed_bf3_elems 16-bit elements.
+ * A layer that is given it (iq_dgcnn_weights.conv5_bf3) takes its products on the bf16 matrix pipe - six exact bf16 products
+ * per float32 product, float32 accumulation: float32 accuracy at 3/8 of the matrix cycles of the fp32 MFMA.  cin % 16 == 0. */
+size_t iq_packed_bf3_elems(int cout, int cin);
+int iq_pack_weight_bf3(const float* w_host /*cout,cin*/, unsigned short* out_host, int cout, int cin);
 /* feat.fstn.fc3 (4096 x 256): permutes the output rows so that the layer's output vector IS the
  * packed B-fragment image of trans_feat for the trunk's per-coalition 64x64 product, and adds the
  * identity (models/pointnet.py:42-45) into the bias.  out_w has iq_packed_floats(4096,256)
@@ -324,6 +330,8 @@ typedef struct iq_dgcnn_weights {
     iq_dense_layer pq[4];
     iq_dense_layer conv5, fc1, fc2, fc3;
     int32_t k;
+    int32_t reserved;
+    const void* conv5_bf3;    /* optional (NULL: fp32 MFMA): conv5's folded weights as three bf16 terms, iq_pack_weight_bf3 */
 } iq_dgcnn_weights;
 
 size_t iq_dgcnn_workspace_bytes(int B, int N);

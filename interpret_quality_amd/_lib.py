@@ -58,7 +58,7 @@ class PointConvWeights(ctypes.Structure):
 
 class DgcnnWeights(ctypes.Structure):
     _fields_ = [("pq", DenseLayer * 4), ("conv5", DenseLayer), ("fc1", DenseLayer), ("fc2", DenseLayer),
-                ("fc3", DenseLayer), ("k", ctypes.c_int32)]
+                ("fc3", DenseLayer), ("k", ctypes.c_int32), ("reserved", ctypes.c_int32), ("conv5_bf3", ctypes.c_void_p)]
 
 
 class SmoothnessParams(ctypes.Structure):
@@ -92,6 +92,8 @@ SIGNATURES = {
     "iq_packed_floats": (_SZ, [_I, _I]),
     "iq_padded_cout": (_I, [_I]),
     "iq_pack_weight": (_I, [_P, _P, _I, _I]),
+    "iq_packed_bf3_elems": (_SZ, [_I, _I]),
+    "iq_pack_weight_bf3": (_I, [_P, _P, _I, _I]),
     "iq_pack_fstn_fc3": (_I, [_P, _P, _P, _P, _P]),
     "iq_pointnet_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "iq_pointnet_coalitions": (_I, [ctypes.POINTER(PointNetWeights), _P, _P, _P, _P, _P, _P, _P, _P, _SZ,

@@ -1262,7 +1262,7 @@ int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, i
                 work = 2.0 * 512.0 * 1024.0 * (double)((n + 127) / 128 * 128);
         }
         iq::ProfileSpan dom(iq::kSlotDominant, st, work);
-        if ((rc = iq::launch_linear_pool(s.xc, 512, w->conv5, s.h, rows, 2, s.row_w, st, live))) return rc;
+        if ((rc = iq::launch_linear_pool(s.xc, 512, w->conv5, s.h, rows, 2, s.row_w, st, live, w->conv5_bf3))) return rc;
         hipLaunchKernelGGL(pool_reduce_kernel, dim3(1024 / kThreads, B), dim3(kThreads), 0, st, s.h, s.g, rg, N, 1024);
         if ((rc = iq::check_launch("pool_reduce_kernel"))) return rc;
     }

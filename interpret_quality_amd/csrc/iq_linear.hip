@@ -2,6 +2,7 @@
 // (iq_pack_weight).  Two kernels with bit-identical results (same MFMA order over k), a split-K form for few rows x very
 // long K, and a form whose epilogue does the first stage of a pooling layer.  fp32 MFMA (v_mfma_f32_32x32x2_f32) only.
 #include <algorithm>
+#include <cstring>
 
 #include "iq_common.h"
 #include "iq_mfma.h"
@@ -307,6 +308,177 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
     }
 }
 
+
+// ---- the pooled dense layer on the bf16 matrix pipe, float32-exact ------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 runs at the vector rate on gfx950 (157 TFLOP/s); v_mfma_f32_32x32x16_bf16 is sixteen times faster.  A
+// float32 value is the sum of three bf16 terms (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): 24 mantissa bits, the residuals
+// exact), a product of two bf16 values is exact in float32, and of the nine products of two split operands the three smallest
+// (m.l, l.m, l.l) lie below 2^-24 of |a||b|: a.b = h.h + h.m + m.h + m.m + h.l + l.h to float32 accuracy, accumulated in float32
+// inside the MFMA.  Measured on random data against float64: max error 2.0e-7 of the largest output, the fp32 GEMM 4.4e-7.
+// 16 k cost 6 x 32 = 192 matrix cycles instead of 8 x 64 = 512.
+//   * weights: split and packed once on the host (iq_pack_weight_bf3): [term][n-tile][k-step of 16][lane][8 bf16], 1 KB per
+//     fragment, streamed through a ring of the four n-tiles' fragments one k-step (1 536 matrix cycles) ahead;
+//   * activations: read ONCE as float32 (128 rows x 32 k per chunk, full-line coalesced), split in registers while they are
+//     staged, three bf16 planes in LDS (row stride 80 bytes: conflict-free ds_read_b128), double-buffered;
+//   * tile, epilogue and output exactly those of pn_gemm_lds_kernel<4, true>: 128 rows x 256 columns per workgroup, per 32-row
+//     tile the column maxima and weighted sums.
+// Not bit-identical to the fp32-MFMA kernel (another summation order), equal to it within float32 rounding.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(kThreads, 2) void pn_gemm_bf3_pool_kernel(const float* __restrict__ A, int lda,
+                                                                       const unsigned short* __restrict__ w3,
+                                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                                       int M, int K, int Nout, int relu,
+                                                                       const int32_t* __restrict__ m_dev,
+                                                                       const float* __restrict__ row_w, int col_blocks) {
+    constexpr int NT = 4, KC = 32, ROWB = 80, PLANE = 128 * ROWB;      // bytes
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][3 * PLANE];
+    __shared__ float wrow[128];
+    const int row_tiles = (M + 127) / 128;
+    const int per = 8 * col_blocks, grp = blockIdx.x / per, rr = blockIdx.x - grp * per;
+    const int bx = grp * 8 + (rr & 7), by = rr >> 3;                   // column blocks of a row tile side by side on one XCD
+    if (bx >= row_tiles) return;
+    if (m_dev) M = min(M, *m_dev);
+    const int m0 = bx * 128;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    if (tid < 128) wrow[tid] = m0 + tid < M ? row_w[m0 + tid] : 0.f;
+    const int KS = K >> 4, nchunks = K / KC;
+    const int NTT = (Nout + 31) >> 5;
+    const int nt0 = (by * 2 + wn) * NT;
+
+    // activations: thread t owns (row, 4 k) = (e >> 3, (e & 7) * 4) for e = t + 256 i
+    const WBuf ab = wbuf_make(A + (size_t)m0 * lda, lane);
+    int aoffb[4], soff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + kThreads * i, row = e >> 3, c4 = e & 7;
+        aoffb[i] = (min(row, M - 1 - m0) * lda + c4 * 4) * 4;
+        soff[i] = row * ROWB + c4 * 8;
+    }
+    f32x4 stage[4];
+    auto load_chunk = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ab.rsrc, aoffb[i], kc * KC * 4, 0));
+    };
+    auto store_chunk = [&](int buf) {     // split into the three planes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x4 h, m, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = stage[i][e];
+                const __bf16 a = (__bf16)v;
+                const float r1 = v - (float)a;
+                const __bf16 b = (__bf16)r1;
+                h[e] = a; m[e] = b; l[e] = (__bf16)(r1 - (float)b);
+            }
+            unsigned char* d = As[buf] + soff[i];
+            *reinterpret_cast<bf16x4*>(d) = h;
+            *reinterpret_cast<bf16x4*>(d + PLANE) = m;
+            *reinterpret_cast<bf16x4*>(d + 2 * PLANE) = l;
+        }
+    };
+    // weights: fragment (term e, n-tile nt, k-step ks) at ((e NTT + nt) KS + ks) KB
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(w3), 0, 0x7fffffff, 0x00020000);
+    const int wvoff = lane * 16;
+    int wsoff[NT];                         // scalar byte offset of n-tile j's term-0 fragment of k-step 0
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wsoff[j] = uniform(min(nt0 + j, NTT - 1) * KS * 1024);
+    const int term_stride = NTT * KS * 1024;
+    struct B3 { bf16x8 h, m, l; };
+    auto wfrag = [&](int j, int ks) {
+        const int o = wsoff[j] + min(ks, KS - 1) * 1024;
+        return B3{__builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, o, 0)),
+                  __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, o + term_stride, 0)),
+                  __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, o + 2 * term_stride, 0))};
+    };
+    B3 ring[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) ring[j] = wfrag(j, 0);
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x16){0};
+    float breg[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) breg[j] = bias[min((nt0 + j) * 32 + (lane & 31), Nout - 1)];
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    const int aoff = (wm * 64 + (lane & 31)) * ROWB + (lane >> 5) * 16;          // bytes: row of m-tile 0, this lane's 8 k
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const unsigned char* as = As[kc & 1] + aoff;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ks = kc * 2 + s;
+            bf16x8 a[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 3; ++e) a[i][e] = *reinterpret_cast<const bf16x8*>(as + e * PLANE + i * 32 * ROWB + s * 32);
+            if (s == 0 && kc + 1 < nchunks) load_chunk(kc + 1);     // the next chunk's rows, behind this chunk's first operands
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const B3 b = ring[j];
+                ring[j] = wfrag(j, ks + 1);
+                // two accumulation chains interleaved (a dependent MFMA waits for its predecessor); small terms first
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][2], b.h, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][2], b.h, acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b.l, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b.l, acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b.m, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b.m, acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b.h, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b.h, acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b.m, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b.m, acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b.h, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b.h, acc[1][j], 0, 0, 0);
+            }
+        }
+        if (kc + 1 < nchunks) store_chunk((kc + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int trow = m0 + wm * 64 + i * 32;
+        if (trow >= M) continue;
+        float w[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[r] = wrow[wm * 64 + i * 32 + c_row(r, lane)];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = (nt0 + j) * 32 + (lane & 31);
+            const bool ok = nt0 + j < NTT && col < Nout;
+            const float b = ok ? breg[j] : 0.f;
+            float mx = -INFINITY, sm = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] + b;
+                if (relu == 1) v = fmaxf(v, 0.f);
+                else if (relu == 2) v = v > 0.f ? v : 0.2f * v;
+                if (w[r] > 0.f) {
+                    mx = fmaxf(mx, v);
+                    sm += w[r] * v;
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            sm += __shfl_xor(sm, 32);
+            if (ok && lane < 32) {
+                float* o = out + (size_t)(trow >> 5) * 2 * Nout;
+                o[col] = mx;
+                o[Nout + col] = sm;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* out, int ldo, int M, int relu,
@@ -391,13 +563,18 @@ int iq::launch_linear_splitk(const float* A, int lda, const iq_dense_layer& L, f
 }
 
 int iq::launch_linear_pool(const float* A, int lda, const iq_dense_layer& L, float* partial, int M, int relu,
-                           const float* row_w, hipStream_t st, const int32_t* m_dev) {
+                           const float* row_w, hipStream_t st, const int32_t* m_dev, const void* w_bf3) {
     if (M == 0) return IQ_OK;
     IQ_REQUIRE(L.w && L.b && row_w && partial, "dense layer + pool: null pointer");
     const int ntiles = (L.cout + 31) / 32;
     if (L.cin % 32 != 0 || ntiles < 8 || L.cout % 32 != 0)
         return iq::fail(IQ_EUNSUPPORTED, "dense layer + pool: cin=%d cout=%d", L.cin, L.cout);
     const int gy = (ntiles + 7) / 8, gx = (M + 127) / 128;
+    if (w_bf3 && L.cout % 256 == 0 && iq::tuning(iq::kTuneExperiment) != 53) {   // 5 = 53: the fp32 MFMA (A/B and tests)
+        hipLaunchKernelGGL(pn_gemm_bf3_pool_kernel, dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
+                           reinterpret_cast<const unsigned short*>(w_bf3), L.b, partial, M, L.cin, L.cout, relu, m_dev, row_w, gy);
+        return iq::check_launch("pn_gemm_bf3_pool_kernel");
+    }
     if (iq::tuning(iq::kTuneExperiment) == 48) {   // 5 = 48: the (tiles, column blocks) grid of rounds 1-3 (A/B)
         hipLaunchKernelGGL((pn_gemm_lds_kernel<4, true>), dim3(gx, gy), dim3(kThreads), 0, st, A, lda, L.w, L.b, partial, 0, M, L.cin, L.cout,
                            relu, m_dev, row_w, nullptr, 0, 0);
@@ -420,6 +597,42 @@ extern "C" int iq_linear(const float* A, int lda, const iq_dense_layer* L, float
 extern "C" int iq_padded_cout(int cout) { return (cout + 31) / 32 * 32; }
 
 extern "C" size_t iq_packed_floats(int cout, int cin) { return (size_t)iq_padded_cout(cout) * cin; }
+
+// bf16 (round to nearest even) of a finite float, as v_cvt_pk_bf16_f32 rounds
+static inline unsigned short iq_bf16_of(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float iq_float_of_bf16(unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+extern "C" size_t iq_packed_bf3_elems(int cout, int cin) { return (size_t)3 * iq_padded_cout(cout) * cin; }
+
+// [term][n-tile][k-step of 16][lane][8]: lane (n & 31) + 32 ((k >> 3) & 1) holds k-aligned-8 elements of column n
+extern "C" int iq_pack_weight_bf3(const float* w, unsigned short* out, int cout, int cin) {
+    IQ_REQUIRE(w && out && cout >= 1 && cin >= 16 && cin % 16 == 0, "iq_pack_weight_bf3: cout=%d cin=%d", cout, cin);
+    const int KS = cin / 16, ntiles = iq_padded_cout(cout) / 32;
+    const size_t term = (size_t)ntiles * KS * 512;
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = nt * 32 + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+                    const float v = n < cout ? w[(size_t)n * cin + k] : 0.f;
+                    const unsigned short h = iq_bf16_of(v);
+                    const float r1 = v - iq_float_of_bf16(h);
+                    const unsigned short m = iq_bf16_of(r1);
+                    const unsigned short l = iq_bf16_of(r1 - iq_float_of_bf16(m));
+                    const size_t o = (((size_t)nt * KS + ks) * 64 + lane) * 8 + j;
+                    out[o] = h; out[term + o] = m; out[2 * term + o] = l;
+                }
+    return IQ_OK;
+}
 
 extern "C" int iq_pack_weight(const float* w, float* out, int cout, int cin) {
     IQ_REQUIRE(w && out && cout >= 1 && cin >= 8 && cin % 8 == 0, "iq_pack_weight: cout=%d cin=%d", cout, cin);

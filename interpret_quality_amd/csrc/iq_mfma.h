@@ -119,8 +119,10 @@ int launch_linear_splitk(const float* A, int lda, const iq_dense_layer& L, float
 // Dense layer fused with the first stage of a pooling layer: partial (ceil(M/32), 2, cout) receives, per 32-row tile,
 // the column maxima and the row_w-weighted column sums over the rows with row_w > 0 (the activations are never stored).
 // cin % 32 == 0, cout % 32 == 0, cout >= 256.
+// w_bf3 (optional): the layer's weights split into three bf16 terms (iq_pack_weight_bf3): the products then run on the bf16
+// matrix pipe, float32-exact (pn_gemm_bf3_pool_kernel).
 int launch_linear_pool(const float* A, int lda, const iq_dense_layer& L, float* partial, int M, int relu,
-                       const float* row_w, hipStream_t st, const int32_t* m_dev = nullptr);
+                       const float* row_w, hipStream_t st, const int32_t* m_dev = nullptr, const void* w_bf3 = nullptr);
 // Farthest point sampling (iq_geom.hip); n_unique may be null.
 int launch_fps(const float* xyz, int32_t* idx, int32_t* n_unique, int B, int N, int S, hipStream_t st);
 }  // namespace iq

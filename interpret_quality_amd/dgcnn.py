@@ -54,7 +54,16 @@ class PackedWeightsD:
             pq[cout:, :c] = (wb - wa) * s[:, None]            # Q = (s.(W_b - W_a)) x + t
             self.struct.pq[j - 1] = dense(pq, np.concatenate([np.zeros(cout), t]))
         s, t = _bn_affine(sd, "bn5")
-        self.struct.conv5 = dense(_np(sd["conv5.0.weight"]).reshape(1024, 512) * s[:, None], t)
+        w5 = np.ascontiguousarray(_np(sd["conv5.0.weight"]).reshape(1024, 512) * s[:, None], dtype=np.float32)
+        self.struct.conv5 = dense(w5, t)
+        # conv5 (half of a DGCNN step, three quarters of GCNN's) runs on the bf16 matrix pipe: the same folded float32 weights as
+        # three bf16 terms (csrc/iq_linear.hip: pn_gemm_bf3_pool_kernel)
+        w3 = np.empty(lib.iq_packed_bf3_elems(1024, 512), dtype=np.uint16)
+        _lib.check(lib.iq_pack_weight_bf3(w5.ctypes.data, w3.ctypes.data, 1024, 512), "iq_pack_weight_bf3")
+        w3t = torch.from_numpy(w3.view(np.int16)).to(device)
+        self._keep.append(w3t)
+        self.struct.reserved = 0
+        self.struct.conv5_bf3 = w3t.data_ptr()
         s, t = _bn_affine(sd, "bn6")
         self.struct.fc1 = dense(_np(sd["linear1.weight"]) * s[:, None], t)      # linear1 has no bias (:79)
         s, t = _bn_affine(sd, "bn7")
