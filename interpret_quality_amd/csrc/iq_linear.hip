@@ -332,7 +332,9 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_bf3_pool_kernel(const flo
                                                                        int M, int K, int Nout, int relu,
                                                                        const int32_t* __restrict__ m_dev,
                                                                        const float* __restrict__ row_w, int col_blocks) {
-    constexpr int NT = 4, KC = 32, ROWB = 80, PLANE = 128 * ROWB;      // bytes
+    // wave tile: ALL 128 rows (MT = 4 m-tiles) x 64 columns (NT = 2): a weight fragment feeds four m-tiles - with 64 x 128 wave
+    // tiles (two m-tiles per fragment) the weight stream alone asked the L2 for 19 TB/s at full matrix rate
+    constexpr int MT = 4, NT = 2, KC = 32, ROWB = 80, PLANE = 128 * ROWB;      // bytes
     __shared__ __attribute__((aligned(16))) unsigned char As[2][3 * PLANE];
     __shared__ float wrow[128];
     const int row_tiles = (M + 127) / 128;
@@ -343,11 +345,10 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_bf3_pool_kernel(const flo
     const int m0 = bx * 128;
     if (m0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
     if (tid < 128) wrow[tid] = m0 + tid < M ? row_w[m0 + tid] : 0.f;
     const int KS = K >> 4, nchunks = K / KC;
     const int NTT = (Nout + 31) >> 5;
-    const int nt0 = (by * 2 + wn) * NT;
+    const int nt0 = (by * 4 + wave) * NT;
 
     // activations: thread t owns (row, 4 k) = (e >> 3, (e & 7) * 4) for e = t + 256 i
     const WBuf ab = wbuf_make(A + (size_t)m0 * lda, lane);
@@ -396,12 +397,12 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_bf3_pool_kernel(const flo
                   __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, o + term_stride, 0)),
                   __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, o + 2 * term_stride, 0))};
     };
-    B3 ring[NT];
+    B3 ring[2][NT];                        // two k-steps (3 072 matrix cycles) ahead
 #pragma unroll
-    for (int j = 0; j < NT; ++j) ring[j] = wfrag(j, 0);
-    f32x16 acc[2][NT];
+    for (int j = 0; j < NT; ++j) { ring[0][j] = wfrag(j, 0); ring[1][j] = wfrag(j, 1); }
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x16){0};
     float breg[NT];
@@ -411,47 +412,47 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_bf3_pool_kernel(const flo
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
-    const int aoff = (wm * 64 + (lane & 31)) * ROWB + (lane >> 5) * 16;          // bytes: row of m-tile 0, this lane's 8 k
+    const int aoff = (lane & 31) * ROWB + (lane >> 5) * 16;          // bytes: row of m-tile 0, this lane's 8 k
     for (int kc = 0; kc < nchunks; ++kc) {
         const unsigned char* as = As[kc & 1] + aoff;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int ks = kc * 2 + s;
-            bf16x8 a[2][3];
+            bf16x8 a[MT][3];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int e = 0; e < 3; ++e) a[i][e] = *reinterpret_cast<const bf16x8*>(as + e * PLANE + i * 32 * ROWB + s * 32);
             if (s == 0 && kc + 1 < nchunks) load_chunk(kc + 1);     // the next chunk's rows, behind this chunk's first operands
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const B3 b = ring[j];
-                ring[j] = wfrag(j, ks + 1);
-                // two accumulation chains interleaved (a dependent MFMA waits for its predecessor); small terms first
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][2], b.h, acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][2], b.h, acc[1][j], 0, 0, 0);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b.l, acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b.l, acc[1][j], 0, 0, 0);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b.m, acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b.m, acc[1][j], 0, 0, 0);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b.h, acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b.h, acc[1][j], 0, 0, 0);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b.m, acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b.m, acc[1][j], 0, 0, 0);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b.h, acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b.h, acc[1][j], 0, 0, 0);
+                const B3 b = ring[s][j];                            // (k-step parity = s: two steps per chunk)
+                ring[s][j] = wfrag(j, ks + 2);
+                // four accumulation chains interleaved (a dependent MFMA waits for its predecessor); small terms first
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b.h, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b.l, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b.m, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b.h, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b.m, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b.h, acc[i][j], 0, 0, 0);
             }
         }
         if (kc + 1 < nchunks) store_chunk((kc + 1) & 1);
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int trow = m0 + wm * 64 + i * 32;
+    for (int i = 0; i < MT; ++i) {
+        const int trow = m0 + i * 32;
         if (trow >= M) continue;
         float w[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) w[r] = wrow[wm * 64 + i * 32 + c_row(r, lane)];
+        for (int r = 0; r < 16; ++r) w[r] = wrow[i * 32 + c_row(r, lane)];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int col = (nt0 + j) * 32 + (lane & 31);
