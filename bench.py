@@ -20,10 +20,12 @@ is: a region is ceil(2 s / block time) back-to-back BLOCKS of EXACTLY K steps, e
 both sides and reduced with MAX over ranks; `value` / `ms_per_step` are the MEDIAN block's (`timing.region_s` states the region).  The library's HIP-event profiler is OFF in the timed regions; kernel durations come from a separate
 profiled pass afterwards.
 
-`roofline` (dominant kernel = pn_chain_kernel, fp32 MFMA bound): `achieved` / `frac` hold what the kernel EXECUTES - the FLOP of
-the MFMA tiles it issues over its HIP-event launch time (`frac_basis: "executed"`); `frac_useful` counts the coalitions'
-distinct rows only (no tile padding); `frac_algorithmic` is SURVEY 8d's figure, the dense reference layers over all 1024
-rows of every coalition - above 1 because the kernel skips duplicate points, exactly.
+`roofline` (dominant kernel = pn_chain_kernel, matrix-pipe bound): `achieved` = the float32 FLOP of the MFMA tiles it issues over
+its HIP-event launch time; `peak` = the matrix pipe's float32-equivalent rate for the kernel's instruction mix (layers 1-2 on the
+fp32 MFMA at 157.3 TF, layer 3 as six exact bf16 products per float32 product on the bf16 MFMA at 16 x 157.3 TF: `peak_basis`);
+`frac` = achieved / peak (`frac_basis: "executed"`); `frac_useful` counts the coalitions' distinct rows only (no tile padding);
+`frac_algorithmic` is SURVEY 8d's figure, the dense reference layers over all 1024 rows of every coalition (the kernel skips
+duplicate points, exactly: DESIGN.md 3).
 
 Every default line also carries `strong_scaling` (`--strong-steps`, default 1 step after the headline measurement): the same
 workload as `--scaling strong` at this rank count, so the driver's N = 1, 2, 4, 8 runs hold a strong-scaling curve too.
@@ -59,6 +61,8 @@ sys.path.insert(0, REPO)
 
 NUM_POINTS, NUM_REGIONS, NUM_PERMS = 1024, 32, 1000
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak (no xf32/TF32 on gfx950)
+PEAK_BF16_MFMA_TFLOPS = 16 * 157.3   # same table: the bf16 MFMA runs 16 x the fp32 one (~2.5 PF dense)
+BF3_PRODUCTS = 6              # bf16 products per float32 product when both operands are split in three bf16 terms
 CHAIN_MAC_PER_ROW = 143360.0  # 64*64 + 64*128 + 128*1024: the MFMA layers of one chain-kernel row
 CHAIN_MAC_L12, CHAIN_MAC_L3 = 64 * 64 + 64 * 128, 128 * 1024   # layers 1-2 run in 32-row tiles, layer 3 ends on a 16-row tile
 SLOT_DOMINANT = 5
@@ -152,8 +156,8 @@ def _read_slot(lib, slot):
 # dominates its step here
 OTHER_MODELS = {
     "pointnet2": {"config": "BASELINE configs[2]", "dense_gflop": 7.83, "kernel": "pn2_group_kernel<128,128,256> (sa2, r=0.8)"},
-    "dgcnn": {"config": "BASELINE configs[3]", "dense_gflop": 5.33, "kernel": "pn_gemm_lds_kernel<4,pool> (conv5 + max/mean pool)"},
-    "gcnn": {"config": "BASELINE configs[3] (gcnn)", "dense_gflop": 4.79, "kernel": "pn_gemm_lds_kernel<4,pool> (conv5 + max/mean pool)"},
+    "dgcnn": {"config": "BASELINE configs[3]", "dense_gflop": 5.33, "kernel": "pn_gemm_bf3_pool_kernel (conv5 + max/mean pool)", "bf3": True},
+    "gcnn": {"config": "BASELINE configs[3] (gcnn)", "dense_gflop": 4.79, "kernel": "pn_gemm_bf3_pool_kernel (conv5 + max/mean pool)", "bf3": True},
     "pointconv": {"config": "Shapley shape of configs[2]", "dense_gflop": None, "kernel": "pc_group_kernel<128,128,256> (sa2)"},
 }
 
@@ -265,9 +269,12 @@ def other_models(dev, lib, regions=32):
                     _read_slot(lib, s)                      # forget the other spans
                 spec = OTHER_MODELS[name]
                 achieved = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                # conv5 of DGCNN / GCNN runs on the bf16 matrix pipe, six exact bf16 products per float32 product
+                peak = PEAK_BF16_MFMA_TFLOPS / BF3_PRODUCTS if spec.get("bf3") else PEAK_F32_MFMA_TFLOPS
                 out[name] = {"value": n / dt, "unit": "coalitions/s", "steps": steps, "workload": workload, "config": spec["config"],
-                             "roofline": {"bound": "mfma", "kernel": spec["kernel"], "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                             "roofline": {"bound": "mfma", "kernel": spec["kernel"], "achieved": achieved, "peak": peak,
+                                          "unit": "TFLOP/s", "frac": achieved / peak, "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+                                          "traffic": None,
                                           "avg_launch_ms": ms / max(launches, 1), "launches": launches,
                                           "executed_flop_per_launch": work / max(launches, 1),
                                           "algorithmic_tflops_whole_step": spec["dense_gflop"] * 1e9 * (n / dt) / 1e12,
@@ -522,6 +529,8 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
     from interpret_quality_amd.pointnet import PointNetCls
 
     lib = _lib.load()
+    if os.environ.get("IQ_BENCH_FP32_L3") == "1":
+        lib.iq_set_tuning(5, 54)      # layer 3 of the chains on the fp32 MFMA (round 3's kernel), for A/B runs
     R, S = args.regions, args.perms
     model = PointNetCls(None)
     model.load_state_dict(synth.to_torch(synth.pointnet_state_dict(0)))
@@ -618,14 +627,24 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
         # DISTINCT rows (kept points + the centre), in 32-row MFMA tiles, 143 360 MAC per row
         rows = np.concatenate([rows_of(k.cpu().numpy().view(np.uint64), sizes, R) for k in keeps])
         rows32 = (rows + 31) // 32 * 32
-        rows_l3 = np.where((rows - 1) % 32 < 16, (rows + 15) // 16 * 16, rows32)   # l3_tail16: a last tile of <= 16 rows is a 16-row tile
+        # layer 3 (91 % of a row's MACs) runs on the bf16 matrix pipe, float32-exact (six bf16 products per float32 product), in
+        # 32-row tiles; layers 1-2 on the fp32 MFMA.  (IQ_BENCH_FP32_L3=1 / tuning key 5 = 54: layer 3 on the fp32 MFMA too, with
+        # 16-row tail tiles - round 3's kernel.)
+        bf3 = os.environ.get("IQ_BENCH_FP32_L3") != "1"
+        rows_l3 = rows32 if bf3 else np.where((rows - 1) % 32 < 16, (rows + 15) // 16 * 16, rows32)
         per_launch = 2.0 / len(keeps)                              # FLOP per MAC, averaged over the profiled steps
-        executed_flop = per_launch * (CHAIN_MAC_L12 * float(rows32.sum()) + CHAIN_MAC_L3 * float(rows_l3.sum()))
+        l12_flop = per_launch * CHAIN_MAC_L12 * float(rows32.sum())
+        l3_flop = per_launch * CHAIN_MAC_L3 * float(rows_l3.sum())
+        executed_flop = l12_flop + l3_flop
         useful_flop = per_launch * CHAIN_MAC_PER_ROW * float(rows.sum())
         algorithmic_flop = 2.0 * CHAIN_MAC_PER_ROW * NUM_POINTS * n_coal          # the dense reference layers: all 1024 rows
         avg_launch_s = launch_s / max(launches, 1)
         tf = lambda flop: flop / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0  # noqa: E731
         achieved = tf(executed_flop)
+        # the matrix pipe's minimum time for what the kernel issues: fp32 MFMAs at 157.3 TF, bf16 MFMAs at 16 x that, six per product
+        t_min = l12_flop / (PEAK_F32_MFMA_TFLOPS * 1e12) + (BF3_PRODUCTS * l3_flop / (PEAK_BF16_MFMA_TFLOPS * 1e12) if bf3
+                                                              else l3_flop / (PEAK_F32_MFMA_TFLOPS * 1e12))
+        peak_mix = executed_flop / t_min / 1e12
         step_flops = lib.iq_pointnet_flops_per_coalition(NUM_POINTS) * n_coal
         traffic, traffic_detail = (None, "not measured (N > 1 or --traffic 0)")
         if world == 1 and args.traffic and not force_dist:
@@ -647,10 +666,15 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
                        "blocks_per_region": blocks, "region_s": float(np.median(regions_s)), "regions_s": regions_s,
                        "blocks_s": blocks_s, "block_spread": float((max(blocks_s) - min(blocks_s)) / elapsed)},
             "roofline": {"bound": "mfma", "kernel": "pn_chain_kernel<fstn|trunk>", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "peak": peak_mix, "unit": "TFLOP/s", "frac": achieved / peak_mix,
                          "frac_basis": "executed",
-                         "frac_useful": tf(useful_flop) / PEAK_F32_MFMA_TFLOPS,
-                         "frac_algorithmic": tf(algorithmic_flop) / PEAK_F32_MFMA_TFLOPS,
+                         "peak_basis": ("float32-equivalent TFLOP/s of the matrix pipe for this kernel's instruction mix: layers 1-2 (9 % of the "
+                                        "MACs) on v_mfma_f32_32x32x2_f32 at 157.3 TF, layer 3 as six exact bf16 products per float32 product on "
+                                        "v_mfma_f32_32x32x16_bf16 at 16 x 157.3 / 6 = 419 TF") if bf3 else "dense fp32 MFMA peak",
+                         "layer3_on": "bf16 matrix pipe, three-term split, float32-exact" if bf3 else "fp32 MFMA",
+                         "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "frac_useful": tf(useful_flop) / peak_mix,
+                         "frac_algorithmic": tf(algorithmic_flop) / peak_mix,
                          "traffic": traffic, "traffic_detail": traffic_detail,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                          "executed_flop_per_launch": executed_flop,
@@ -658,11 +682,12 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
                          "algorithmic_flop_per_launch": algorithmic_flop,
                          "mean_rows_per_coalition": {"distinct": float(rows.mean()), "in_32_row_tiles": float(rows32.mean()),
                                                      "layer3_tiles_16_row_tail": float(rows_l3.mean()), "dense": NUM_POINTS},
-                         "note": "frac_basis executed: achieved / frac = FLOP of the fp32 MFMA tiles the kernel issues (32-row tiles; layer 3, 91 % "
-                                 "of the work, ends on a 16-row tile when the last tile holds <= 16 rows) / HIP-event launch time (separate "
-                                 "profiled pass) / dense fp32 MFMA peak.  frac_useful: the coalitions' distinct rows "
+                         "note": "frac_basis executed: achieved = float32 FLOP of the MFMA tiles the kernel issues (32-row tiles) / HIP-event "
+                                 "launch time (separate profiled pass); frac = achieved / peak, i.e. the matrix pipe's minimum time for "
+                                 "the issued instructions (see peak_basis) / the launch time.  frac_of_fp32_mfma_peak: achieved / 157.3 - "
+                                 "above 1 because layer 3 no longer runs on the fp32 MFMA.  frac_useful: the coalitions' distinct rows "
                                  "only (no tile padding).  frac_algorithmic: SURVEY 8d's figure, the dense reference layers this kernel "
-                                 "implements (every coalition, all 1024 rows) - above 1: the kernel evaluates each coalition's distinct "
+                                 "implements (every coalition, all 1024 rows): the kernel evaluates each coalition's distinct "
                                  "points only, an exact skip (DESIGN.md 3).  traffic: HBM bytes per launch from rocprofv3 FETCH_SIZE x2 "
                                  "(MI355X_MICROARCH.md: the counter reports half of wide coalesced reads on gfx950) + WRITE_SIZE of this "
                                  "same script, measured now",

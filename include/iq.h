@@ -191,6 +191,10 @@ typedef struct iq_pointnet_weights {
     iq_dense_layer fstn_c1, fstn_c2, fstn_c3, fstn_fc1, fstn_fc2, fstn_fc3; /* fc3: iq_pack_fstn_fc3.  feature_transform = False
         (models/pointnet.py:62-63): fstn_c1.w = NULL and fstn_fc3.b = the packed identity (iq_pack_fstn_fc3 of a zero layer) */
     iq_dense_layer feat_c2, feat_c3, cls_fc1, cls_fc2, cls_fc3;
+    /* optional (NULL: fp32 MFMA): the folded 128 -> 1024 layers of the feature STN and of the trunk as three bf16 terms
+     * (iq_pack_weight_bf3): layer 3 of the coalition chains - 91 % of their work - then runs on the bf16 matrix pipe, float32-exact */
+    const void* fstn_c3_bf3;
+    const void* feat_c3_bf3;
 } iq_pointnet_weights;
 
 /* out (M,ldo) = act(A (M,lda) . W^T + b): the dense layer every model kernel shares (1x1 convolutions and

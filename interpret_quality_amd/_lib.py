@@ -32,6 +32,7 @@ class PointNetWeights(ctypes.Structure):
         ("fstn_fc2", DenseLayer), ("fstn_fc3", DenseLayer),
         ("feat_c2", DenseLayer), ("feat_c3", DenseLayer), ("cls_fc1", DenseLayer), ("cls_fc2", DenseLayer),
         ("cls_fc3", DenseLayer),
+        ("fstn_c3_bf3", ctypes.c_void_p), ("feat_c3_bf3", ctypes.c_void_p),
     ]
 
 

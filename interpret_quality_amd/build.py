@@ -18,6 +18,15 @@ ARCH = "gfx950"
 # Index-valued kernels (FPS, ball query, region assignment) need individually rounded operations:
 # hipcc's default -ffp-contract=fast fuses a*b+c into fma even through the __f*_rn intrinsics.
 NO_CONTRACT = ("iq_geom.hip", "iq_pointnet2.hip", "iq_dgcnn.hip", "iq_pointconv.hip", "iq_smooth.hip")
+# The smoothness enumeration is built without the SLP vectoriser, i.e. without packed float32 instructions (v_pk_mul_f32,
+# v_pk_add_f32, v_pk_fma_f32).  Measured on MI355X (tools/dbg_smooth_det.py, profiles/r04_shared_gpu_determinism.txt): while a
+# SECOND process ran the PointNet chain kernel with layer 3 on the bf16 matrix pipe on the same GPU, 40 % of the smoothness
+# launches differed from the launch before (first by a few ulp in a few lanes, then amplified by the iteration up to 2e-3);
+# with scalar float32 instructions none did, and no other neighbour (copies, rocBLAS float32, hipBLASLt bf16, DGCNN with the
+# bf16x3 conv5, the chain kernel with layer 3 on the fp32 MFMA) had any effect.  No wave was preempted or moved (HW_ID, step
+# gaps), the kernel uses no scratch and no global memory inside its loop.  One process per GPU - the product's layout - never
+# meets this; the two-ranks-on-one-GPU tests do.
+NO_PACKED_FP32 = ("iq_smooth.hip",)
 
 
 def sources():
@@ -50,6 +59,8 @@ def build(force=False, verbose=True, extra_flags=()):
                    "-Wall", "-Wno-unused-function"] + list(extra_flags)
             if os.path.basename(src) in NO_CONTRACT:
                 cmd.append("-ffp-contract=off")
+            if os.path.basename(src) in NO_PACKED_FP32:
+                cmd.append("-fno-slp-vectorize")
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -54,6 +54,7 @@ struct ChainArgs {
     const float* b2;
     const float* w3;
     const float* b3;
+    const unsigned short* w3_bf3;   // layer 3's weights as three bf16 terms (iq_pack_weight_bf3) or null: L3 on the bf16 matrix pipe (L3V = 3)
     float* out;                // (items,1024)
     int32_t* argrow;           // (items,1024) point index of the row that attains each column maximum, or null [ARGMAX trunk only]
     int N, R, items, nclouds, with_centre;
@@ -160,6 +161,96 @@ __device__ __forceinline__ void l3_pass_v2(const WBuf& w3, const float* abase, i
     }
 }
 
+// ---- Variant 3: L3 on the bf16 matrix pipe, float32-exact -----------------------------------------------------------------------
+// (csrc/iq_linear.hip, pn_gemm_bf3_pool_kernel, has the arithmetic: a float32 is three bf16 terms, a product the six largest of the
+// nine term products, each exact, accumulated in float32; 16 k cost 192 matrix cycles instead of 512.)  act2 lives in LDS as three
+// bf16 planes [64][136] (row stride 272 bytes = 68 dwords: the same conflict-free ds_read_b128 pattern as the float image), written
+// split by layer 2's epilogue; the weights come split and packed from the host (iq_pack_weight_bf3: fragment (term, n-tile, k-step)
+// at ((term 32 + n-tile) 8 + k-step) KB), through a ring four k-steps (1 536 matrix cycles) ahead that rolls over n-tile and chunk
+// boundaries like BRing.  A row's result does not depend on the tile or chunk it sits in, so the pooled maxima are those of the
+// same rows in any arrangement (fused = materialised, bitwise, as before).  16-row tail tiles are not used here (a 32-row tile).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kLdB = 272;                 // bytes per act2 row of one bf16 plane
+constexpr int kPlaneB = kMC * kLdB;       // bytes per plane
+struct B3 { bf16x8 h, m, l; };
+// Two float32 -> two bf16 (round to nearest even) in one dword, and back: the chain kernels write act2's bf16 planes with
+// these, one dword per store.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16_pair(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+struct B3Ring { B3 r[4]; };
+
+__device__ __forceinline__ B3 b3_load(const __amdgpu_buffer_rsrc_t& rs, int voff, int step, int wave_s) {
+    // step = q * 8 + ks (mod 64): n-tile q * 4 + wave, k-step ks
+    const int o = ((((step >> 3) & 7) * 4 + wave_s) * 8 + (step & 7)) * 1024;
+    return B3{__builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, o, 0)),
+              __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, o + 32 * 8 * 1024, 0)),
+              __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, o + 2 * 32 * 8 * 1024, 0))};
+}
+
+template <int MTS, bool ARGMAX = false>
+__device__ __forceinline__ void l3_pass_bf3(const __amdgpu_buffer_rsrc_t& rs, int voff, const unsigned char* abase, int wave_s,
+                                            float (&runmax)[8], B3Ring& ring, int (&runarg)[8], int rowbase = 0, int fh = 0) {
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {
+        f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            bf16x8 a0[3], a1[3];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                a0[e] = *reinterpret_cast<const bf16x8*>(abase + e * kPlaneB + s * 32);
+                if (MTS == 2) a1[e] = *reinterpret_cast<const bf16x8*>(abase + e * kPlaneB + 32 * kLdB + s * 32);
+            }
+            const B3 b = ring.r[s & 3];
+            ring.r[s & 3] = b3_load(rs, voff, q * 8 + s + 4, wave_s);
+            // small terms first; with two m-tiles the two accumulation chains alternate
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[2], b.h, acc0, 0, 0, 0);
+            if (MTS == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[2], b.h, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b.l, acc0, 0, 0, 0);
+            if (MTS == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b.l, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], b.m, acc0, 0, 0, 0);
+            if (MTS == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], b.m, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], b.h, acc0, 0, 0, 0);
+            if (MTS == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], b.h, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b.m, acc0, 0, 0, 0);
+            if (MTS == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b.m, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b.h, acc0, 0, 0, 0);
+            if (MTS == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b.h, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);     // one k-step at a time: left alone the scheduler hoists every step's operand
+                                                   // reads to the top of the n-tile (256 registers, one wave per SIMD)
+        }
+        if (ARGMAX) {   // as l3_pass_v2
+            float m = -INFINITY;
+            int r = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (acc0[i] > m) { m = acc0[i]; r = rowbase + c_row_i(i) + 4 * fh; }
+            }
+            if (MTS == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (acc1[i] > m) { m = acc1[i]; r = rowbase + 32 + c_row_i(i) + 4 * fh; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool better = (i == q) && m > runmax[i];
+                runarg[i] = better ? r : runarg[i];
+                runmax[i] = better ? m : runmax[i];
+            }
+        } else {
+            float m = max16(acc0);
+            if (MTS == 2) m = fmaxf(m, max16(acc1));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? fmaxf(runmax[i], m) : runmax[i];
+        }
+    }
+}
+
 // L3 for a LAST m-tile of at most 16 rows (rows row0 .. row0 + 15 of act2): v_mfma_f32_16x16x4_f32 instead of a 32-row tile
 // of which half would be padding (a coalition's row count is uniform mod 32, so this saves a quarter tile per coalition and
 // chain on average: 1.5 % of the kernel).  BIT-IDENTICAL to the 32x32x2 path: that instruction accumulates its two k values
@@ -235,7 +326,8 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 
 template <int MODE, int L3V, bool STAMP = false, bool ARGMAX = false>
 __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
-    __shared__ __attribute__((aligned(16))) float bufA[kMC * kLd2];  // act0 (ld 68) then act2 (ld 132)
+    // act0 (ld 68) then act2: float image (ld 132), or - L3V = 3 - three bf16 planes of 272-byte rows
+    __shared__ __attribute__((aligned(16))) float bufA[L3V == 3 ? 3 * kPlaneB / 4 : kMC * kLd2];
     __shared__ __attribute__((aligned(16))) float bufB[kMC * kLd1];  // act1
     __shared__ __attribute__((aligned(16))) float xs[kMC * 4];       // transformed inputs of the chunk (x,y,z,-)
 
@@ -296,6 +388,13 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
 
     BRing ring;
     if (L3V == 2) bring_init(ring, w3b, wave_s);
+    [[maybe_unused]] B3Ring ring3;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t w3rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(L3V == 3 ? a.w3_bf3 : nullptr), 0, 0x7fffffff, 0x00020000);
+    if (L3V == 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ring3.r[i] = b3_load(w3rs, lane * 16, i, wave_s);
+    }
     unsigned tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? stamp_now() : 0ull;
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -382,8 +481,30 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     const float bias = a.b2[nt0 * 32 + pass * 64 + frag_lane];
+                    if (L3V == 3) {   // act2 as three bf16 terms (h + m + l = the float32 value exactly)
+                        // Two lanes (columns c, c+1) trade one of each pair of rows and write whole dwords: 24 ds_write_b32 per pass
+                        // instead of 48 ds_write_b16.
+                        const int odd = lane & 1;
+                        unsigned char* d32 = reinterpret_cast<unsigned char*>(bufA) + (mt * 32 + 4 * frag_h + odd) * kLdB
+                                             + (nt0 * 32 + pass * 64 + (frag_lane & ~1)) * 2;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) dst[c_row_i(i) * kLd2 + pass * 64] = fmaxf(acc[i] + bias, 0.f);
+                        for (int i = 0; i < 16; i += 2) {
+                            const float v0 = fmaxf(acc[i] + bias, 0.f), v1 = fmaxf(acc[i + 1] + bias, 0.f);   // rows r, r+1 of column c
+                            const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                                0, __builtin_bit_cast(int, odd ? v0 : v1), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false));
+                            const float lo = odd ? got : v0, hi = odd ? v1 : got;                            // columns c&~1, c|1 of row r+odd
+                            const unsigned h = bf16_pair(lo, hi);
+                            const float rl = lo - bf16_lo(h), rh = hi - bf16_hi(h);
+                            const unsigned m = bf16_pair(rl, rh);
+                            unsigned char* o = d32 + c_row_i(i) * kLdB;
+                            *reinterpret_cast<unsigned*>(o) = h;
+                            *reinterpret_cast<unsigned*>(o + kPlaneB) = m;
+                            *reinterpret_cast<unsigned*>(o + 2 * kPlaneB) = bf16_pair(rl - bf16_lo(m), rh - bf16_hi(m));
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) dst[c_row_i(i) * kLd2 + pass * 64] = fmaxf(acc[i] + bias, 0.f);
+                    }
                 }
             }
         }
@@ -391,7 +512,11 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
         __syncthreads();
         IQ_STAMP(3);
         // ---- L3: 128 -> 1024, running column max -------------------------------------------
-        if (L3V == 0) {
+        if (L3V == 3) {
+            const unsigned char* ab3 = reinterpret_cast<const unsigned char*>(bufA) + frag_lane * kLdB + frag_h * 16;
+            if (mts == 2) l3_pass_bf3<2, ARGMAX>(w3rs, lane * 16, ab3, wave_s, runmax, ring3, runarg, ch * kMC, frag_h);
+            else          l3_pass_bf3<1, ARGMAX>(w3rs, lane * 16, ab3, wave_s, runmax, ring3, runarg, ch * kMC, frag_h);
+        } else if (L3V == 0) {
             if (mts == 2) l3_pass_v0<2>(w3b, a2base, wave_s, runmax);
             else          l3_pass_v0<1>(w3b, a2base, wave_s, runmax);
         } else {
@@ -600,12 +725,18 @@ __global__ __launch_bounds__(kThreads) void pn_fill_rows_kernel(float* __restric
 template <int MODE>
 void launch_chain(const ChainArgs& a, hipStream_t st) {
     const size_t extra_lds = (size_t)iq::tuning(iq::kTuneExtraLds);  // experiment: lower the occupancy
+    const int knob = iq::tuning(iq::kTuneExperiment);
+    const bool fp32_l3 = knob == 54 || knob == 55;   // layer 3 on the fp32 MFMA (round 3's kernel; A/B and tests), 55: without tail16
     if (a.stamps && MODE == kFstn)
         hipLaunchKernelGGL((pn_chain_kernel<kFstn, 2, true>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
     else if (iq::tuning(iq::kTuneL3Variant) == 0)
         hipLaunchKernelGGL((pn_chain_kernel<MODE, 0>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
+    else if (MODE == kTrunk && a.argrow && a.w3_bf3 && !fp32_l3)
+        hipLaunchKernelGGL((pn_chain_kernel<kTrunk, 3, false, true>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
     else if (MODE == kTrunk && a.argrow)
         hipLaunchKernelGGL((pn_chain_kernel<kTrunk, 2, false, true>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
+    else if (MODE != kPrepool && a.w3_bf3 && !fp32_l3)
+        hipLaunchKernelGGL((pn_chain_kernel<MODE, 3>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
     else
         hipLaunchKernelGGL((pn_chain_kernel<MODE, 2>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
 }
@@ -765,7 +896,7 @@ extern "C" int iq_pointnet_coalitions_crt(const iq_pointnet_weights* w, const fl
     a.item_order = nullptr;
     a.N = N; a.R = R; a.nclouds = nclouds; a.with_centre = with_centre;
     a.stamps = g_stamps;
-    a.tail16 = iq::tuning(iq::kTuneExperiment) != 16;   // 16: 32-row tiles only (A/B and tests)
+    a.tail16 = iq::tuning(iq::kTuneExperiment) != 16 && iq::tuning(iq::kTuneExperiment) != 55;   // 16, 55: 32-row tiles only
 
     // 1. input-STN chain, pre-pooled per (cloud, region) [+ centre]
     a.cloud_of = nullptr; a.trans = nullptr;
@@ -799,7 +930,7 @@ extern "C" int iq_pointnet_coalitions_crt(const iq_pointnet_weights* w, const fl
     if (w->fstn_c1.w) {
         a.w1 = w->fstn_c1.w; a.b1 = w->fstn_c1.b;
         a.w2 = w->fstn_c2.w; a.b2 = w->fstn_c2.b;
-        a.w3 = w->fstn_c3.w; a.b3 = w->fstn_c3.b;
+        a.w3 = w->fstn_c3.w; a.b3 = w->fstn_c3.b; a.w3_bf3 = reinterpret_cast<const unsigned short*>(w->fstn_c3_bf3);
         {
             iq::ProfileSpan span(iq::kSlotFstn, st);
             launch_chain<kFstn>(a, st);
@@ -821,7 +952,7 @@ extern "C" int iq_pointnet_coalitions_crt(const iq_pointnet_weights* w, const fl
     a.argrow = crt_points;
     a.w1 = tfp; a.b1 = nullptr;
     a.w2 = w->feat_c2.w; a.b2 = w->feat_c2.b;
-    a.w3 = w->feat_c3.w; a.b3 = w->feat_c3.b;
+    a.w3 = w->feat_c3.w; a.b3 = w->feat_c3.b; a.w3_bf3 = reinterpret_cast<const unsigned short*>(w->feat_c3_bf3);
     {
         iq::ProfileSpan span(iq::kSlotTrunk, st);
         launch_chain<kTrunk>(a, st);

@@ -55,30 +55,39 @@ __device__ void eigh3(const double a_in[3][3], double w[3], double V[3][3]) {
                 }
             }
     }
-    int idx[3] = {0, 1, 2};
-    for (int i = 1; i < 3; ++i)
-        for (int j = i; j > 0 && a[idx[j]][idx[j]] < a[idx[j - 1]][idx[j - 1]]; --j) {
-            const int t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t;
-        }
-    double Vs[3][3];
-    for (int k = 0; k < 3; ++k) {
-        w[k] = a[idx[k]][idx[k]];
-        for (int i = 0; i < 3; ++i) Vs[i][k] = V[i][idx[k]];
+    // ascending order of the diagonal (insertion sort, stable); no array is indexed by a run-time value, so none lives in scratch
+    const double d0 = a[0][0], d1 = a[1][1], d2 = a[2][2];
+    auto diag = [&](int i) { return i == 0 ? d0 : (i == 1 ? d1 : d2); };
+    int i0 = 0, i1 = 1, i2 = 2;
+    if (diag(i1) < diag(i0)) { const int t = i1; i1 = i0; i0 = t; }
+    if (diag(i2) < diag(i1)) {
+        const int t = i2; i2 = i1; i1 = t;
+        if (diag(i1) < diag(i0)) { const int u = i1; i1 = i0; i0 = u; }
     }
-    for (int i = 0; i < 3; ++i)
-        for (int k = 0; k < 3; ++k) V[i][k] = Vs[i][k];
+    auto col = [&](int r, int i) { return i == 0 ? V[r][0] : (i == 1 ? V[r][1] : V[r][2]); };
+    w[0] = diag(i0); w[1] = diag(i1); w[2] = diag(i2);
+    double Vs[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { Vs[r][0] = col(r, i0); Vs[r][1] = col(r, i1); Vs[r][2] = col(r, i2); }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) V[r][k] = Vs[r][k];
 }
 
 // np.argsort of three values (final_smoothness_center_enum_all.py:85-99): stable, NaN last.
+// (no array is indexed by a run-time value: pick3 keeps everything in registers)
+__device__ inline float pick3(const float v[3], int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); }
+__device__ inline bool pick3b(const bool v[3], int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); }
+__device__ inline bool less_nan_last(float a, float b) { return (a < b) || (b != b && a == a); }
 __device__ inline void argsort3(const float v[3], int idx[3]) {
-    idx[0] = 0; idx[1] = 1; idx[2] = 2;
-    for (int i = 1; i < 3; ++i)
-        for (int j = i; j > 0; --j) {
-            const float a = v[idx[j]], b = v[idx[j - 1]];
-            const bool less = (a < b) || (b != b && a == a);
-            if (!less) break;
-            const int t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t;
-        }
+    int i0 = 0, i1 = 1, i2 = 2;                      // insertion sort, as before: element 1, then element 2
+    if (less_nan_last(pick3(v, i1), pick3(v, i0))) { const int t = i1; i1 = i0; i0 = t; }
+    if (less_nan_last(pick3(v, i2), pick3(v, i1))) {
+        const int t = i2; i2 = i1; i1 = t;
+        if (less_nan_last(pick3(v, i1), pick3(v, i0))) { const int u = i1; i1 = i0; i0 = u; }
+    }
+    idx[0] = i0; idx[1] = i1; idx[2] = i2;
 }
 
 struct Vars { float var[3]; float mean[3]; };
@@ -118,6 +127,9 @@ __global__ __launch_bounds__(kWave) void smooth_enum_kernel(
     const float* __restrict__ cloud, const float* __restrict__ origin, const int32_t* __restrict__ region_id, int N, int R,
     int mode, int objective, iq_smoothness_params prm, float* __restrict__ data_out, float* __restrict__ smooth_out,
     float* __restrict__ var_out, float* __restrict__ orig_out, int32_t* __restrict__ stop_epoch) {
+    // One wave per region, everything in LDS and registers (no scratch: the argsort permutation is applied with selects).
+    // This file is built WITHOUT packed float32 instructions - see NO_PACKED_FP32 in build.py: up to epochs x max_iteration
+    // gradient steps amplify a one-ulp difference, and beside one particular neighbour on a shared GPU packed float32 did differ.
     __shared__ float cur[kMaxRegionPoints * 3];
     __shared__ float org[kMaxRegionPoints * 3];
     __shared__ int32_t pidx[kMaxRegionPoints];
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(kWave) void smooth_enum_kernel(
     for (int k = 0; k < 3; ++k) { ub[k] = v0.var[k] + vth; lb[k] = v0.var[k] - vth; }
     int si[3];
     argsort3(v0.var, si);
-    float smooth = smoothness_of(mode, v0.var[si[0]], v0.var[si[1]], v0.var[si[2]]);
+    float smooth = smoothness_of(mode, pick3(v0.var, si[0]), pick3(v0.var, si[1]), pick3(v0.var, si[2]));
     if (lane == 0) {
         for (int k = 0; k < 3; ++k) orig_out[r * 4 + k] = v0.var[k];
         orig_out[r * 4 + 3] = smooth;
@@ -218,27 +230,28 @@ __global__ __launch_bounds__(kWave) void smooth_enum_kernel(
                     lastvar[k] = v.var[k];
                 }
                 argsort3(v.var, si);
-                const float smin = v.var[si[0]], smid = v.var[si[1]], smax = v.var[si[2]];
+                const float smin = pick3(v.var, si[0]), smid = pick3(v.var, si[1]), smax = pick3(v.var, si[2]);
+                const bool lmin = pick3b(live, si[0]), lmid = pick3b(live, si[1]), lmax = pick3b(live, si[2]);
                 sm = smoothness_of(mode, smin, smid, smax);
                 // d smoothness / d var, zero through a detached variance
                 float cmin, cmid, cmax;
                 bool has_grad;
                 if (mode == 0) {
                     cmin = 0.f; cmid = -1.f / smax; cmax = 1.f / smax - (smax - smid) / (smax * smax);
-                    has_grad = live[si[2]] || live[si[1]];
+                    has_grad = lmax || lmid;
                 } else if (mode == 1) {
                     cmin = -1.f / smax; cmid = 1.f / smax; cmax = -(smid - smin) / (smax * smax);
-                    has_grad = live[si[2]] || live[si[1]] || live[si[0]];
+                    has_grad = lmax || lmid || lmin;
                 } else {
                     cmin = 1.f / smax; cmid = 0.f; cmax = -smin / (smax * smax);
-                    has_grad = live[si[2]] || live[si[0]];
+                    has_grad = lmax || lmin;
                 }
                 const bool grad_none = !has_grad;
                 if (has_grad) {  // gradient_descent (:121-138)
                     float ck[3];
-                    ck[si[0]] = live[si[0]] ? cmin : 0.f;
-                    ck[si[1]] = live[si[1]] ? cmid : 0.f;
-                    ck[si[2]] = live[si[2]] ? cmax : 0.f;
+                    const float kmin = lmin ? cmin : 0.f, kmid = lmid ? cmid : 0.f, kmax = lmax ? cmax : 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) ck[k] = (k == si[0]) ? kmin : ((k == si[1]) ? kmid : kmax);
                     const float two_over = 2.f / (float)(S - 1);
                     float n2 = 0.f;
                     for (int i = lane; i < S; i += kWave) {

@@ -357,10 +357,13 @@ def test_pointnet_without_feature_transform():
 
 
 def test_chain_tail_tiles_are_bit_identical_for_every_row_count(model):
-    """The 16-row tail tiles of the chain kernel (l3_tail16: v_mfma_f32_16x16x4_f32 fed in the k order of the 32x32x2 fragments)
-    against 32-row tiles only (tuning key 5 = 16): bit-identical logits and packed feature transforms for coalitions whose
-    distinct-row counts cover every residue mod 32 - 64 regions of 1 to 31 points, 400 random coalitions, plus the dense
-    forward (1024 rows: no tail) on the materialised clouds of a few of them."""
+    """Layer 3 of the chain kernel, for coalitions whose distinct-row counts cover every residue mod 32 (64 regions of 1 to 31
+    points, 400 random coalitions):
+    - the fp32-MFMA kernel (tuning key 5 = 54) with its 16-row tail tiles (l3_tail16: v_mfma_f32_16x16x4_f32 fed in the k order
+      of the 32x32x2 fragments) against 32-row tiles only (5 = 55): bit-identical logits and packed feature transforms;
+    - the default kernel (layer 3 as six bf16 products per float32 product, float32 accumulation) against the fp32-MFMA one:
+      the same logits to float32 rounding (measured 3e-7 of the largest logit; the two sum k in different orders);
+    - and the dense forward (1024 rows) on the materialised clouds of a few coalitions, bitwise against the coalition path."""
     from interpret_quality_amd import _lib
     d = dev()
     rng = np.random.default_rng(3)
@@ -384,12 +387,17 @@ def test_chain_tail_tiles_are_bit_identical_for_every_row_count(model):
     assert len(set((rows % 32).tolist())) == 32                      # every residue occurs
     got, tf = eng.coalition_logits(data, center, rid_t, keep_t, None, num_regions=64, return_trans_feat=True)
     lib = _lib.load()
-    lib.iq_set_tuning(5, 16)
     try:
+        lib.iq_set_tuning(5, 54)
+        f32, tf_f32 = eng.coalition_logits(data, center, rid_t, keep_t, None, num_regions=64, return_trans_feat=True)
+        lib.iq_set_tuning(5, 55)
         ref, tf_ref = eng.coalition_logits(data, center, rid_t, keep_t, None, num_regions=64, return_trans_feat=True)
     finally:
         lib.iq_set_tuning(5, 0)
-    assert torch.equal(got, ref) and torch.equal(tf, tf_ref)
+    assert torch.equal(f32, ref) and torch.equal(tf_f32, tf_ref)
+    assert not torch.equal(got, f32)                                  # two different kernels did run
+    assert (got - f32).abs().max().item() < 2e-6 * f32.abs().max().item()
+    assert (tf - tf_f32).abs().max().item() < 2e-6 * tf_f32.abs().max().item()
     sel = [0, 57, 211, 398, 399]
     dense = hip_ops.mask_coalitions(data[0].contiguous(), rid_t[0].contiguous(), keep_t[sel].contiguous(), center.reshape(3).contiguous(),
                                     channel_first=True)

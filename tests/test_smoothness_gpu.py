@@ -159,3 +159,15 @@ def test_project_to_bound_option_keeps_points_inside():
     assert np.linalg.norm(p - pts[None], axis=2).max() < smoothness.DIST_THRESHOLD * (1 + 1e-5)
     ref = hip_ops.smoothness_enum(torch.from_numpy(pts).to(d), hip_ops.as_i32(g["region_id"], d), 32, "planarity", "inc")
     assert np.linalg.norm(ref["data"].cpu().numpy() - pts[None], axis=2).max() > smoothness.DIST_THRESHOLD  # as the reference
+
+
+def test_enumeration_is_reproducible_beside_a_second_process_on_the_gpu():
+    """Two ranks on ONE GPU (what the sweep tests do on a one-GPU box): the smoothness kernel must give the same bits while
+    another process runs the PointNet chain kernel beside it.  With packed float32 instructions in the kernel it did not
+    (40 % of the launches differed; interpret_quality_amd/build.py NO_PACKED_FP32)."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "shared_gpu_determinism.py")
+    r = subprocess.run([sys.executable, tool, "--load", "pointnet", "--seconds", "8"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches {'fps': 0, 'region_assign': 0, 'smoothness': 0}" in r.stdout, r.stdout[-2000:]
