@@ -195,6 +195,9 @@ typedef struct iq_pointnet_weights {
      * (iq_pack_weight_bf3): layer 3 of the coalition chains - 91 % of their work - then runs on the bf16 matrix pipe, float32-exact */
     const void* fstn_c3_bf3;
     const void* feat_c3_bf3;
+    /* optional, used together with the two above: the 64 -> 128 layers before them, likewise */
+    const void* fstn_c2_bf3;
+    const void* feat_c2_bf3;
 } iq_pointnet_weights;
 
 /* out (M,ldo) = act(A (M,lda) . W^T + b): the dense layer every model kernel shares (1x1 convolutions and
@@ -285,6 +288,10 @@ typedef struct iq_pointnet2_weights {
     iq_pn2_scale sa2[3];
     iq_dense_layer sa3_l1, sa3_l2, sa3_l3;  /* 643 (zero-padded to 648: [xyz, features]) -> 256 -> 512 -> 1024 */
     iq_dense_layer fc1, fc2, fc3;
+    /* optional (NULL: fp32 MFMA): layers 2 and 3 of an sa2 scale as three bf16 terms (iq_pack_weight_bf3); a 128-128-256 scale
+     * that has both runs its grouped MLP on the bf16 matrix pipe, float32-exact (pn2_group_bf3_kernel) */
+    const void* sa2_l2_bf3[3];
+    const void* sa2_l3_bf3[3];
 } iq_pointnet2_weights;
 
 size_t iq_pointnet2_workspace_bytes(int B);

@@ -33,6 +33,7 @@ class PointNetWeights(ctypes.Structure):
         ("feat_c2", DenseLayer), ("feat_c3", DenseLayer), ("cls_fc1", DenseLayer), ("cls_fc2", DenseLayer),
         ("cls_fc3", DenseLayer),
         ("fstn_c3_bf3", ctypes.c_void_p), ("feat_c3_bf3", ctypes.c_void_p),
+        ("fstn_c2_bf3", ctypes.c_void_p), ("feat_c2_bf3", ctypes.c_void_p),
     ]
 
 
@@ -44,7 +45,8 @@ class Pn2Scale(ctypes.Structure):
 class PointNet2Weights(ctypes.Structure):
     _fields_ = [("sa1", Pn2Scale * 3), ("sa2_u", DenseLayer), ("sa2", Pn2Scale * 3),
                 ("sa3_l1", DenseLayer), ("sa3_l2", DenseLayer), ("sa3_l3", DenseLayer),
-                ("fc1", DenseLayer), ("fc2", DenseLayer), ("fc3", DenseLayer)]
+                ("fc1", DenseLayer), ("fc2", DenseLayer), ("fc3", DenseLayer),
+                ("sa2_l2_bf3", ctypes.c_void_p * 3), ("sa2_l3_bf3", ctypes.c_void_p * 3)]
 
 
 class PointConvSa(ctypes.Structure):

@@ -20,6 +20,7 @@
 #include "iq_common.h"
 #include "iq_profile.h"
 
+#include "iq_bf3.h"
 #include "iq_mfma.h"
 
 namespace {
@@ -55,6 +56,7 @@ struct ChainArgs {
     const float* w3;
     const float* b3;
     const unsigned short* w3_bf3;   // layer 3's weights as three bf16 terms (iq_pack_weight_bf3) or null: L3 on the bf16 matrix pipe (L3V = 3)
+    const unsigned short* w2_bf3;   // layer 2's, likewise (L3V = 3 needs both)
     float* out;                // (items,1024)
     int32_t* argrow;           // (items,1024) point index of the row that attains each column maximum, or null [ARGMAX trunk only]
     int N, R, items, nclouds, with_centre;
@@ -169,20 +171,19 @@ __device__ __forceinline__ void l3_pass_v2(const WBuf& w3, const float* abase, i
 // at ((term 32 + n-tile) 8 + k-step) KB), through a ring four k-steps (1 536 matrix cycles) ahead that rolls over n-tile and chunk
 // boundaries like BRing.  A row's result does not depend on the tile or chunk it sits in, so the pooled maxima are those of the
 // same rows in any arrangement (fused = materialised, bitwise, as before).  16-row tail tiles are not used here (a 32-row tile).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kLdB = 272;                 // bytes per act2 row of one bf16 plane
 constexpr int kPlaneB = kMC * kLdB;       // bytes per plane
-struct B3 { bf16x8 h, m, l; };
-// Two float32 -> two bf16 (round to nearest even) in one dword, and back: the chain kernels write act2's bf16 planes with
-// these, one dword per store.
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned bf16_pair(float lo, float hi) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
-}
-__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 struct B3Ring { B3 r[4]; };
+constexpr int kLd1B = 144;                // bytes per act1 row of one bf16 plane (64 k; 36 dwords: conflict-free ds_read_b128)
+constexpr int kPlane1B = kMC * kLd1B;
+
+// layer 2's weight fragment (n-tile nt of 4, k-step ks of 4) as three terms: iq_pack_weight_bf3 of a (128,64) matrix
+__device__ __forceinline__ B3 b3_load_l2(const __amdgpu_buffer_rsrc_t& rs, int voff, int nt, int ks) {
+    const int o = (nt * 4 + ks) * 1024;
+    return B3{__builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, o, 0)),
+              __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, o + 16 * 1024, 0)),
+              __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, o + 2 * 16 * 1024, 0))};
+}
 
 __device__ __forceinline__ B3 b3_load(const __amdgpu_buffer_rsrc_t& rs, int voff, int step, int wave_s) {
     // step = q * 8 + ks (mod 64): n-tile q * 4 + wave, k-step ks
@@ -325,10 +326,10 @@ __device__ __forceinline__ unsigned long long stamp_now() {
     } while (0)
 
 template <int MODE, int L3V, bool STAMP = false, bool ARGMAX = false>
-__global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
+__global__ __launch_bounds__(kThreads, L3V == 3 ? 2 : 3) void pn_chain_kernel(ChainArgs a) {
     // act0 (ld 68) then act2: float image (ld 132), or - L3V = 3 - three bf16 planes of 272-byte rows
     __shared__ __attribute__((aligned(16))) float bufA[L3V == 3 ? 3 * kPlaneB / 4 : kMC * kLd2];
-    __shared__ __attribute__((aligned(16))) float bufB[kMC * kLd1];  // act1
+    __shared__ __attribute__((aligned(16))) float bufB[L3V == 3 ? 3 * kPlane1B / 4 : kMC * kLd1];  // act1 (L3V = 3: three bf16 planes)
     __shared__ __attribute__((aligned(16))) float xs[kMC * 4];       // transformed inputs of the chunk (x,y,z,-)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -391,6 +392,8 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
     [[maybe_unused]] B3Ring ring3;
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t w3rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(L3V == 3 ? a.w3_bf3 : nullptr), 0, 0x7fffffff, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t w2rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(L3V == 3 ? a.w2_bf3 : nullptr), 0, 0x7fffffff, 0x00020000);
     if (L3V == 3) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) ring3.r[i] = b3_load(w3rs, lane * 16, i, wave_s);
@@ -448,18 +451,55 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const float bias = (MODE == kFstn) ? a.b1[nt * 32 + frag_lane] : 0.f;
-                float* dst = c1base + mt * 32 * kLd1 + nt * 32;
+                if (L3V == 3) {   // act1 as three bf16 planes for layer 2
+                    c_tile_to_planes<kLd1B, kPlane1B>(reinterpret_cast<unsigned char*>(bufB) + mt * 32 * kLd1B + nt * 64, lane, [&](int i) {
+                        const float v = acc[i] + bias;
+                        return (MODE == kFstn) ? fmaxf(v, 0.f) : v;
+                    });
+                } else {
+                    float* dst = c1base + mt * 32 * kLd1 + nt * 32;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float v = acc[i] + bias;
-                    if (MODE == kFstn) v = fmaxf(v, 0.f);
-                    dst[c_row_i(i) * kLd1] = v;
+                    for (int i = 0; i < 16; ++i) {
+                        float v = acc[i] + bias;
+                        if (MODE == kFstn) v = fmaxf(v, 0.f);
+                        dst[c_row_i(i) * kLd1] = v;
+                    }
                 }
             }
         }
         // ---- L2: 64 -> 128 (+bn, relu): two passes (n-tiles nt0, nt0+2); the second pass's weights
         //      are requested while the first pass computes ------------------------------------
-        {
+        if (L3V == 3) {   // on the bf16 matrix pipe: act1 and the weights as three bf16 terms, six products each (float32-exact)
+            const int mt = wave & 1, nt0 = wave >> 1, nts = wave_s >> 1;
+            constexpr int PF = ARGMAX ? 2 : 4;   // weight fragments in flight (the arg-max variant has no registers to spare)
+            B3 bw[PF];
+#pragma unroll
+            for (int ks = 0; ks < PF; ++ks) bw[ks] = b3_load_l2(w2rs, lane * 16, nts, ks);
+            IQ_STAMP(4);
+            __syncthreads();
+            IQ_STAMP(3);
+            if (mt < mts) {
+                const unsigned char* arow = reinterpret_cast<const unsigned char*>(bufB) + (mt * 32 + frag_lane) * kLd1B + frag_h * 16;
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    f32x16 acc = {0};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        bf16x8 af[3];
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) af[e] = *reinterpret_cast<const bf16x8*>(arow + e * kPlane1B + ks * 32);
+                        const int t = pass * 4 + ks, nx = t + PF;
+                        const B3 b = bw[t % PF];
+                        if (nx < 8) bw[t % PF] = b3_load_l2(w2rs, lane * 16, nts + 2 * (nx >> 2), nx & 3);
+                        acc = mfma_bf3(af, b, acc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const float bias = a.b2[nt0 * 32 + pass * 64 + frag_lane];
+                    c_tile_to_planes<kLdB, kPlaneB>(reinterpret_cast<unsigned char*>(bufA) + mt * 32 * kLdB + (nt0 * 32 + pass * 64) * 2, lane,
+                                                    [&](int i) { return fmaxf(acc[i] + bias, 0.f); });
+                }
+            }
+        } else {
             const int mt = wave & 1, nt0 = wave >> 1;
             const int wq0 = (wave_s >> 1) * 8 * kFragBytes;
             f32x4 bw[8];
@@ -481,30 +521,8 @@ __global__ __launch_bounds__(kThreads, 3) void pn_chain_kernel(ChainArgs a) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     const float bias = a.b2[nt0 * 32 + pass * 64 + frag_lane];
-                    if (L3V == 3) {   // act2 as three bf16 terms (h + m + l = the float32 value exactly)
-                        // Two lanes (columns c, c+1) trade one of each pair of rows and write whole dwords: 24 ds_write_b32 per pass
-                        // instead of 48 ds_write_b16.
-                        const int odd = lane & 1;
-                        unsigned char* d32 = reinterpret_cast<unsigned char*>(bufA) + (mt * 32 + 4 * frag_h + odd) * kLdB
-                                             + (nt0 * 32 + pass * 64 + (frag_lane & ~1)) * 2;
 #pragma unroll
-                        for (int i = 0; i < 16; i += 2) {
-                            const float v0 = fmaxf(acc[i] + bias, 0.f), v1 = fmaxf(acc[i + 1] + bias, 0.f);   // rows r, r+1 of column c
-                            const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-                                0, __builtin_bit_cast(int, odd ? v0 : v1), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false));
-                            const float lo = odd ? got : v0, hi = odd ? v1 : got;                            // columns c&~1, c|1 of row r+odd
-                            const unsigned h = bf16_pair(lo, hi);
-                            const float rl = lo - bf16_lo(h), rh = hi - bf16_hi(h);
-                            const unsigned m = bf16_pair(rl, rh);
-                            unsigned char* o = d32 + c_row_i(i) * kLdB;
-                            *reinterpret_cast<unsigned*>(o) = h;
-                            *reinterpret_cast<unsigned*>(o + kPlaneB) = m;
-                            *reinterpret_cast<unsigned*>(o + 2 * kPlaneB) = bf16_pair(rl - bf16_lo(m), rh - bf16_hi(m));
-                        }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) dst[c_row_i(i) * kLd2 + pass * 64] = fmaxf(acc[i] + bias, 0.f);
-                    }
+                    for (int i = 0; i < 16; ++i) dst[c_row_i(i) * kLd2 + pass * 64] = fmaxf(acc[i] + bias, 0.f);
                 }
             }
         }
@@ -731,11 +749,11 @@ void launch_chain(const ChainArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((pn_chain_kernel<kFstn, 2, true>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
     else if (iq::tuning(iq::kTuneL3Variant) == 0)
         hipLaunchKernelGGL((pn_chain_kernel<MODE, 0>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
-    else if (MODE == kTrunk && a.argrow && a.w3_bf3 && !fp32_l3)
+    else if (MODE == kTrunk && a.argrow && a.w3_bf3 && a.w2_bf3 && !fp32_l3)
         hipLaunchKernelGGL((pn_chain_kernel<kTrunk, 3, false, true>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
     else if (MODE == kTrunk && a.argrow)
         hipLaunchKernelGGL((pn_chain_kernel<kTrunk, 2, false, true>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
-    else if (MODE != kPrepool && a.w3_bf3 && !fp32_l3)
+    else if (MODE != kPrepool && a.w3_bf3 && a.w2_bf3 && !fp32_l3)
         hipLaunchKernelGGL((pn_chain_kernel<MODE, 3>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
     else
         hipLaunchKernelGGL((pn_chain_kernel<MODE, 2>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
@@ -931,6 +949,7 @@ extern "C" int iq_pointnet_coalitions_crt(const iq_pointnet_weights* w, const fl
         a.w1 = w->fstn_c1.w; a.b1 = w->fstn_c1.b;
         a.w2 = w->fstn_c2.w; a.b2 = w->fstn_c2.b;
         a.w3 = w->fstn_c3.w; a.b3 = w->fstn_c3.b; a.w3_bf3 = reinterpret_cast<const unsigned short*>(w->fstn_c3_bf3);
+        a.w2_bf3 = reinterpret_cast<const unsigned short*>(w->fstn_c2_bf3);
         {
             iq::ProfileSpan span(iq::kSlotFstn, st);
             launch_chain<kFstn>(a, st);
@@ -953,6 +972,7 @@ extern "C" int iq_pointnet_coalitions_crt(const iq_pointnet_weights* w, const fl
     a.w1 = tfp; a.b1 = nullptr;
     a.w2 = w->feat_c2.w; a.b2 = w->feat_c2.b;
     a.w3 = w->feat_c3.w; a.b3 = w->feat_c3.b; a.w3_bf3 = reinterpret_cast<const unsigned short*>(w->feat_c3_bf3);
+    a.w2_bf3 = reinterpret_cast<const unsigned short*>(w->feat_c2_bf3);
     {
         iq::ProfileSpan span(iq::kSlotTrunk, st);
         launch_chain<kTrunk>(a, st);

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "iq_common.h"
+#include "iq_bf3.h"
 #include "iq_mfma.h"
 #include "iq_profile.h"
 
@@ -169,6 +170,8 @@ struct GroupArgs {
     const float* w1x;        // [C1][4] = (wx0, wx1, wx2, bias)
     const float* w2; const float* b2;  // packed C1->C2
     const float* w3; const float* b3;  // packed C2->C3
+    const unsigned short* w2_bf3;      // the same two layers as three bf16 terms (iq_pack_weight_bf3) or null:
+    const unsigned short* w3_bf3;      // 128-128-256 scales then run pn2_group_bf3_kernel
     float* out;              // (B,S,ldo) at the scale's column offset, zero-initialised
     int ldo;
     int N, S, K, blocks_per_wg;
@@ -415,6 +418,209 @@ __global__ __launch_bounds__(kThreads, WPS) void pn2_group_kernel(GroupArgs a) {
     for (int q = 0; q < NQ; ++q) flush_group(q);
 }
 
+// ---- the 128-128-256 scale on the bf16 matrix pipe: bf16x3, float32-exact (iq_bf3.h) ---------------------------
+// Same blocks, groups, stage 0 and pooling as pn2_group_kernel; layers 2 and 3 as six bf16 products per float32 product.
+// The bf16 pipe is 2.67x faster per float32 MAC, so operand delivery decides the shape: 64-row chunks (a weight fragment - three
+// 1 KiB terms from L2 - feeds two m-tiles; with 32-row chunks the four waves would ask the L1 path for 64 B / clk, all it has),
+// layer 3 as 2 x 2 tiles per wave (the A terms of a k-step are read from LDS once for both n-tiles).  Activations live in LDS as
+// three bf16 planes of 272-byte rows (conflict-free ds_read_b128), split where they are produced; act1 and act2 SHARE one
+// 52 KB image - layer 2 keeps its two tiles in registers until every wave has read act1 - so that two workgroups fit a CU and
+// fill each other's barriers and stage-0 phases (four barriers per chunk instead of two).
+template <int MTS>
+__device__ __forceinline__ void gb_layer2(const unsigned char* abase, const __amdgpu_buffer_rsrc_t& rs, int voff, int nt,
+                                          B3 (&ring)[4], f32x16 (&acc)[MTS][1]) {
+    constexpr int ROWB = 272, PLANEB = 64 * ROWB, TS = 4 * 8 * 1024;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        bf16x8 af[MTS][3];
+#pragma unroll
+        for (int i = 0; i < MTS; ++i) a3_load<PLANEB>(af[i], abase + i * 32 * ROWB, ks);
+        const B3 b[1] = {ring[ks & 3]};
+        if (ks + 4 < 8) ring[ks & 3] = b3_load_at(rs, voff, (nt * 8 + ks + 4) * 1024, TS);
+        mfma_bf3_block<MTS, 1>(af, b, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+struct B3x2 { B3 b[2]; };
+template <int MTS>
+__device__ __forceinline__ void gb_layer3(const unsigned char* abase, const __amdgpu_buffer_rsrc_t& rs, int voff, int nt0,
+                                          B3x2 (&ring)[2], f32x16 (&acc)[MTS][2]) {
+    constexpr int ROWB = 272, PLANEB = 64 * ROWB, TS = 8 * 8 * 1024;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        bf16x8 af[MTS][3];
+#pragma unroll
+        for (int i = 0; i < MTS; ++i) a3_load<PLANEB>(af[i], abase + i * 32 * ROWB, ks);
+        const B3 b[2] = {ring[ks & 1].b[0], ring[ks & 1].b[1]};
+        if (ks + 2 < 8) {
+            ring[ks & 1].b[0] = b3_load_at(rs, voff, (nt0 * 8 + ks + 2) * 1024, TS);
+            ring[ks & 1].b[1] = b3_load_at(rs, voff, ((nt0 + 4) * 8 + ks + 2) * 1024, TS);
+        }
+        mfma_bf3_block<MTS, 2>(af, b, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a) {
+    constexpr int C1 = 128, kMC = 64, ROWB = 272, PLANEB = kMC * ROWB, BPC = kMC / kBlk;
+    __shared__ __attribute__((aligned(16))) unsigned char planes[3 * PLANEB];   // act1, then act2: three bf16 planes [64][136]
+    __shared__ __attribute__((aligned(16))) float rel[2 * kMC * 4];             // dx,dy,dz, member index (bits); double-buffered
+    __shared__ int blk_group[2 * BPC];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = blockIdx.x >> 3;
+    const int b = iq::xcd_cloud(blockIdx.x, a.wgs_per_cloud, a.B);
+    if (b >= a.B) return;
+    const int K = a.K;
+    const int32_t* bstart = a.block_start + (size_t)b * (a.S + 1);
+    const int nblocks = bstart[a.S];
+    const int j0 = (slot % a.wgs_per_cloud) * a.blocks_per_wg;
+    if (j0 >= nblocks) return;
+    const int jend = min(nblocks, j0 + a.blocks_per_wg);
+    const int nchunks = (jend - j0 + BPC - 1) / BPC;
+    const uint16_t* bmap = a.blockmap + (size_t)b * a.maxblocks;
+
+    const int fl = lane & 31, fh = lane >> 5;
+    const unsigned char* abase = planes + fl * ROWB + 16 * fh;
+
+    constexpr int Q1 = C1 / 4, NR = kMC * Q1 / kThreads;   // stage 0b: a thread owns 4 consecutive channels of NR rows
+    const int c4 = tid % Q1, rsub = tid / Q1;
+    f32x4 w1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w1[e] = *reinterpret_cast<const f32x4*>(a.w1x + (c4 * 4 + e) * 4);
+    const __amdgpu_buffer_rsrc_t ursrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.U ? a.U + (size_t)b * a.N * a.ldu : a.w1x), 0, 0x7fffffff, 0x00020000);
+    f32x4 ureg[NR];
+    auto stage0a = [&](int ch, int buf) {   // as pn2_group_kernel
+        if (tid < kMC) {
+            int j = j0 + ch * BPC + tid / kBlk;
+            const bool live = j < jend;
+            if (!live) j = jend - 1;
+            const int g = bmap[j];
+            int m = (j - bstart[g]) * kBlk + (tid % kBlk);
+            if (m >= a.cnt[(size_t)b * a.S + g]) m = 0;
+            const int p = a.idx[((size_t)b * a.S + g) * K + m];
+            const float* x = a.xyz + ((size_t)b * a.N + p) * a.ldx;
+            const float* c = a.new_xyz + ((size_t)b * a.S + g) * a.ldc;
+            f32x4 v;
+            v[0] = x[0] - c[0]; v[1] = x[1] - c[1]; v[2] = x[2] - c[2];
+            v[3] = __int_as_float(p);
+            *reinterpret_cast<f32x4*>(rel + (buf * kMC + tid) * 4) = v;
+            if (tid % kBlk == 0) blk_group[buf * BPC + tid / kBlk] = live ? g : -1;
+        }
+    };
+    auto gather_u = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = rsub + i * (kThreads / Q1);
+            const int p = __float_as_int(rel[(buf * kMC + r) * 4 + 3]);
+            if (a.U) ureg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (p * a.ldu + c4 * 4) * 4, 0, 0));
+            else ureg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    stage0a(0, 0);
+    __syncthreads();
+    gather_u(0);
+
+    int run_g[2] = {-1, -1};
+    float run_v[2] = {0.f, 0.f};
+    auto flush_group = [&](int q) {   // as pn2_group_kernel: one store per group, an atomic max only across workgroups
+        const int g = run_g[q];
+        if (g < 0 || fh != 0) return;
+        float* dst = a.out + ((size_t)b * a.S + g) * a.ldo + (q * 4 + wave) * 32 + fl;
+        if (bstart[g] >= j0 && bstart[g + 1] <= jend) *dst = run_v[q];
+        else merge_max(dst, run_v[q]);
+    };
+    auto feed = [&](int q, int g, float v) {
+        if (g < 0) return;
+        if (g != run_g[q]) {
+            flush_group(q);
+            run_g[q] = g;
+            run_v[q] = v;
+        } else {
+            run_v[q] = fmaxf(run_v[q], v);
+        }
+    };
+    const int wave_s = uniform(wave), voff = lane * 16;
+    const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w2_bf3), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w3_bf3), 0, 0x7fffffff, 0x00020000);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cur = ch & 1, nxt = cur ^ 1;
+        const int mts = (jend - (j0 + ch * BPC)) > BPC / 2 ? 2 : 1;
+        int gq[BPC];
+#pragma unroll
+        for (int i = 0; i < BPC; ++i) gq[i] = blk_group[cur * BPC + i];
+        B3 ring2[4];                                 // layer 2's weights (n-tile = wave), in flight across stage 0b
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ring2[i] = b3_load_at(w2rs, voff, (wave_s * 8 + i) * 1024, 4 * 8 * 1024);
+        // ---- stage 0b: layer 1 -> act1 (three planes) ----------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = rsub + i * (kThreads / Q1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rel + (cur * kMC + r) * 4);
+            f32x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                h[e] = fmaxf(fmaf(w1[e][2], v[2], fmaf(w1[e][1], v[1], w1[e][0] * v[0])) + w1[e][3] + ureg[i][e], 0.f);
+            row4_to_planes<PLANEB>(planes + r * ROWB + c4 * 8, h);
+        }
+        __syncthreads();  // act1 complete
+        // ---- layer 2: 128 -> 128, tiles (m-tile 0..1, n-tile = wave) kept in registers -------------------
+        f32x16 acc2[2][1] = {{{0}}, {{0}}};
+        if (mts == 2) {
+            gb_layer2<2>(abase, w2rs, voff, wave_s, ring2, acc2);
+        } else {
+            f32x16 one[1][1] = {{{0}}};
+            gb_layer2<1>(abase, w2rs, voff, wave_s, ring2, one);
+            acc2[0][0] = one[0][0];
+        }
+        B3x2 ring3[2];                               // layer 3's weights (n-tiles wave, wave + 4), in flight across the epilogue
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ring3[i].b[0] = b3_load_at(w3rs, voff, (wave_s * 8 + i) * 1024, 8 * 8 * 1024);
+            ring3[i].b[1] = b3_load_at(w3rs, voff, ((wave_s + 4) * 8 + i) * 1024, 8 * 8 * 1024);
+        }
+        if (ch + 1 < nchunks) stage0a(ch + 1, nxt);
+        __syncthreads();  // every wave has read act1: the image is free
+        {
+            const float bias = a.b2[wave * 32 + fl];
+            c_tile_to_planes<ROWB, PLANEB>(planes + wave * 64, lane, [&](int i) { return fmaxf(acc2[0][0][i] + bias, 0.f); });
+            if (mts == 2)
+                c_tile_to_planes<ROWB, PLANEB>(planes + 32 * ROWB + wave * 64, lane, [&](int i) { return fmaxf(acc2[1][0][i] + bias, 0.f); });
+        }
+        __syncthreads();  // act2 complete; rel[nxt] visible
+        if (ch + 1 < nchunks) gather_u(nxt);  // consumed after layer 3
+        // ---- layer 3: 128 -> 256, 2 x 2 tiles per wave, block maxima merged into the owning groups -------
+        if (mts == 2) {
+            f32x16 acc3[2][2] = {{{0}, {0}}, {{0}, {0}}};
+            gb_layer3<2>(abase, w3rs, voff, wave_s, ring3, acc3);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float bias = a.b3[(q * 4 + wave) * 32 + fl];
+                const TileMax m0 = reduce_tile(acc3[0][q], bias);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) feed(q, gq[i], m0.v[i]);
+                const TileMax m1 = reduce_tile(acc3[1][q], bias);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) feed(q, gq[(BPC - 4) + i], m1.v[i]);
+            }
+        } else {
+            f32x16 acc3[1][2] = {{{0}, {0}}};
+            gb_layer3<1>(abase, w3rs, voff, wave_s, ring3, acc3);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float bias = a.b3[(q * 4 + wave) * 32 + fl];
+                const TileMax m0 = reduce_tile(acc3[0][q], bias);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) feed(q, gq[i], m0.v[i]);
+            }
+        }
+        __syncthreads();  // every wave has read act2: the next chunk's stage 0b may overwrite the image
+    }
+    flush_group(0);
+    flush_group(1);
+}
+
 // rows s >= n_unique[b] := row 0 (duplicate centroids), columns [c0, c0+ncols)
 __global__ void fill_dup_rows_kernel(float* __restrict__ out, int ldo, int S, int c0, int ncols,
                                      const int32_t* __restrict__ n_unique) {
@@ -445,7 +651,10 @@ int launch_group_t(GroupArgs a, int B, hipStream_t st) {
     dim3 grid((unsigned)((B + 7) / 8 * 8 * a.wgs_per_cloud));
     // the widest stage (128-128-256: 70 KB of LDS and 150 registers at 64 rows = 2 workgroups per CU) runs 32-row chunks,
     // 4 workgroups per CU: 44.5 k -> 46.3 k coalitions/s (tuning key 5 = 64 forces 64-row chunks for A/B runs)
-    if (C3 >= 256 && iq::tuning(iq::kTuneExperiment) != 64)
+    if (C1 == 128 && C2 == 128 && C3 == 256 && a.w2_bf3 && a.w3_bf3 && iq::tuning(iq::kTuneExperiment) != 56 &&
+        iq::tuning(iq::kTuneExperiment) != 64)    // 5 = 56 / 64: the fp32-MFMA kernel with 32- / 64-row chunks (A/B and tests)
+        hipLaunchKernelGGL(pn2_group_bf3_kernel, grid, dim3(kThreads), 0, st, a);
+    else if (C3 >= 256 && iq::tuning(iq::kTuneExperiment) != 64)
         hipLaunchKernelGGL((pn2_group_kernel<C1, C2, C3, 32>), grid, dim3(kThreads), 0, st, a);
     else
         hipLaunchKernelGGL((pn2_group_kernel<C1, C2, C3, 64>), grid, dim3(kThreads), 0, st, a);
@@ -470,8 +679,11 @@ double group_work(const GroupArgs& a, int B, int c1, int c2, int c3, hipStream_t
     return rows * 2.0 * ((double)c1 * c2 + (double)c2 * c3);
 }
 
-int launch_group(const iq_pn2_scale& sc, GroupArgs a, const int32_t* n_unique, int B, hipStream_t st, bool dominant = false) {
+int launch_group(const iq_pn2_scale& sc, GroupArgs a, const int32_t* n_unique, int B, hipStream_t st, bool dominant = false,
+                 const void* l2_bf3 = nullptr, const void* l3_bf3 = nullptr) {
     a.w1x = sc.w1x;
+    a.w2_bf3 = reinterpret_cast<const unsigned short*>(l2_bf3);
+    a.w3_bf3 = reinterpret_cast<const unsigned short*>(l3_bf3);
     a.w2 = sc.l2.w; a.b2 = sc.l2.b;
     a.w3 = sc.l3.w; a.b3 = sc.l3.b;
     a.K = sc.nsample;
@@ -1038,7 +1250,7 @@ int run_pn2(const iq_pointnet2_weights* w, const float* xyz, float* logits, cons
         a.U = s.U + ucol; a.ldu = F1;
         a.out = s.a3 + 3 + col; a.ldo = LD3; a.N = S1; a.S = S2;
         iq::ProfileSpan span(iq::kSlotFstn, st);
-        if ((rc = launch_group(w->sa2[q], a, s.nu2, B, st, true))) return rc;
+        if ((rc = launch_group(w->sa2[q], a, s.nu2, B, st, true, w->sa2_l2_bf3[q], w->sa2_l3_bf3[q]))) return rc;
         col += w->sa2[q].l3.cout;
         ucol += w->sa2[q].l2.cin;
     }

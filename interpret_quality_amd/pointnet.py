@@ -67,7 +67,7 @@ class PackedWeights:
             bp[:cout] = b
             wt, bt = dev(pack(w)), dev(bp)
             setattr(self.struct, name, _lib.DenseLayer(wt.data_ptr(), bt.data_ptr(), cin, cout))
-            if name in ("fstn_c3", "feat_c3"):   # layer 3 of the coalition chains on the bf16 matrix pipe: the same weights, split
+            if name in ("fstn_c2", "feat_c2", "fstn_c3", "feat_c3"):   # layers 2-3 of the coalition chains on the bf16 matrix pipe: the same weights, split
                 w32 = np.ascontiguousarray(w, dtype=np.float32)
                 w3 = np.empty(lib.iq_packed_bf3_elems(cout, cin), dtype=np.uint16)
                 _lib.check(lib.iq_pack_weight_bf3(w32.ctypes.data, w3.ctypes.data, cout, cin), "iq_pack_weight_bf3")

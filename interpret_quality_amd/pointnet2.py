@@ -53,13 +53,26 @@ class PackedWeights2:
             wt, bt = dev(out), dev(bp)
             return _lib.DenseLayer(wt.data_ptr(), bt.data_ptr(), cin, cout)
 
+        def bf3(w):
+            """the same folded weights as three bf16 terms (iq_pack_weight_bf3) on the device"""
+            cout, cin = w.shape
+            w32 = np.ascontiguousarray(w, dtype=np.float32)
+            out = np.empty(lib.iq_packed_bf3_elems(cout, cin), dtype=np.uint16)
+            _lib.check(lib.iq_pack_weight_bf3(w32.ctypes.data, out.ctypes.data, cout, cin), "iq_pack_weight_bf3")
+            t = torch.from_numpy(out.view(np.int16)).to(device)
+            self._keep.append(t)
+            return t.data_ptr()
+
         def scale(dst, sa, i, cfg, feat_in):
             w0, b0 = fold_conv_bn(sd, "%s.conv_blocks.%d.0" % (sa, i), "%s.bn_blocks.%d.0" % (sa, i))
             wx = w0[:, feat_in:feat_in + 3]                       # relative xyz comes LAST (models/pointnet2.py:226)
             bias = b0 if feat_in == 0 else np.zeros_like(b0)      # with features the bias travels in U
             dst.w1x = dev(np.concatenate([wx, bias[:, None]], axis=1)).data_ptr()
-            dst.l2 = dense(*fold_conv_bn(sd, "%s.conv_blocks.%d.1" % (sa, i), "%s.bn_blocks.%d.1" % (sa, i)))
-            dst.l3 = dense(*fold_conv_bn(sd, "%s.conv_blocks.%d.2" % (sa, i), "%s.bn_blocks.%d.2" % (sa, i)))
+            w2, b2 = fold_conv_bn(sd, "%s.conv_blocks.%d.1" % (sa, i), "%s.bn_blocks.%d.1" % (sa, i))
+            w3, b3 = fold_conv_bn(sd, "%s.conv_blocks.%d.2" % (sa, i), "%s.bn_blocks.%d.2" % (sa, i))
+            dst.l2, dst.l3 = dense(w2, b2), dense(w3, b3)
+            if sa == "sa2" and w2.shape == (128, 128) and w3.shape == (256, 128):   # the widest scales: bf16 matrix pipe
+                self.struct.sa2_l2_bf3[i], self.struct.sa2_l3_bf3[i] = bf3(w2), bf3(w3)
             dst.radius = cfg["radius"][i]
             dst.nsample = cfg["nsample"][i]
             return w0[:, :feat_in], b0

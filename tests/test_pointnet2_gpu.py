@@ -162,3 +162,33 @@ def test_region_reduced_tables_equal_the_member_walk(model):
     finally:
         lib.iq_set_tuning(5, 0)
     assert torch.equal(got, walk)
+
+
+def test_sa2_on_the_bf16_matrix_pipe_equals_the_fp32_mfma_kernel_to_rounding(model):
+    """The 128-128-256 scales of sa2 run their grouped MLP as six bf16 products per float32 product, float32 accumulation
+    (pn2_group_bf3_kernel, 64-row chunks); tuning key 5 = 56 / 64 selects the fp32-MFMA kernel (32- / 64-row chunks), which
+    gives the same bits for either chunk size.  Same logits to float32 rounding (the two sum k in different orders), on dense
+    clouds and on coalitions with few and many kept points."""
+    from interpret_quality_amd import _lib
+    d = dev()
+    rng = np.random.default_rng(17)
+    clouds = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in (1, 5)]).to(d)
+    rid = torch.stack([hip_ops.region_assign(clouds[c].contiguous(), hip_ops.fps(clouds[c:c + 1], 32)[0].contiguous()) for c in range(2)])
+    centers = clouds.mean(dim=1)
+    keep = [(1 << 32) - 1, 1 << 9, 0x00ff00ff] + [int(x) for x in rng.integers(0, 1 << 32, size=61, dtype=np.uint64)]
+    keep_t = hip_ops.masks_to_tensor(keep, d)
+    co_t = torch.tensor([i % 2 for i in range(len(keep))], dtype=torch.int32, device=d)
+    got = model.coalition_logits(clouds, centers, rid, keep_t, co_t, num_regions=32)
+    dense = model.forward_points(clouds)
+    lib = _lib.load()
+    ref = {}
+    try:
+        for knob in (56, 64):
+            lib.iq_set_tuning(5, knob)
+            ref[knob] = (model.coalition_logits(clouds, centers, rid, keep_t, co_t, num_regions=32), model.forward_points(clouds))
+    finally:
+        lib.iq_set_tuning(5, 0)
+    assert torch.equal(ref[56][0], ref[64][0]) and torch.equal(ref[56][1], ref[64][1])
+    assert not torch.equal(got, ref[56][0])                               # a different kernel did run
+    for a, b in ((got, ref[56][0]), (dense, ref[56][1])):
+        assert (a - b).abs().max().item() < 3e-6 * b.abs().max().item()
