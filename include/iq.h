@@ -388,6 +388,10 @@ typedef struct iq_pointconv_sa {
 typedef struct iq_pointconv_weights {
     iq_pointconv_sa sa[3];
     iq_dense_layer fc1, fc2, fc3;
+    /* optional (NULL: fp32 MFMA): layers 2 and 3 of sa[1] (128 -> 128 -> 256) as three bf16 terms (iq_pack_weight_bf3): its
+     * grouped MLP then runs on the bf16 matrix pipe, float32-exact (pc_group_bf3_kernel) */
+    const void* sa2_l2_bf3;
+    const void* sa2_l3_bf3;
 } iq_pointconv_weights;
 
 size_t iq_pointconv_workspace_bytes(int B, int N);

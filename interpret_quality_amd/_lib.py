@@ -56,7 +56,8 @@ class PointConvSa(ctypes.Structure):
 
 
 class PointConvWeights(ctypes.Structure):
-    _fields_ = [("sa", PointConvSa * 3), ("fc1", DenseLayer), ("fc2", DenseLayer), ("fc3", DenseLayer)]
+    _fields_ = [("sa", PointConvSa * 3), ("fc1", DenseLayer), ("fc2", DenseLayer), ("fc3", DenseLayer),
+                ("sa2_l2_bf3", ctypes.c_void_p), ("sa2_l3_bf3", ctypes.c_void_p)]
 
 
 class DgcnnWeights(ctypes.Structure):

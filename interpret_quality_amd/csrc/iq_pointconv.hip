@@ -10,6 +10,7 @@
 // on the accumulator tiles in registers (16 rows x 16 weights per lane and tile), so the (C3 x K) member
 // features never leave the CU.
 #include "iq_common.h"
+#include "iq_bf3.h"
 #include "iq_mfma.h"
 #include "iq_profile.h"
 #include "iq_srclist.h"
@@ -224,6 +225,8 @@ struct PcGroupArgs {
     const float* w1x;          // [C1][4] = (wx0, wx1, wx2, bias)
     const float* w2; const float* b2;
     const float* w3; const float* b3;
+    const unsigned short* w2_bf3;  // the same two layers as three bf16 terms (iq_pack_weight_bf3) or null:
+    const unsigned short* w3_bf3;  // the 128-128-256 stage then runs pc_group_bf3_kernel
     float* out;                // (B,S,C3*16): [c][w]
     int N, S, K;    int B, wgs_per_cloud, chunks_per_wg;
     const int32_t* n_unique;   // (B) or null: groups s >= n_unique[b] are copies of group 0 and are not computed
@@ -401,6 +404,181 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_kernel(PcGroupArgs a) {
                 }
             }
         }
+    }
+}
+
+// ---- the 128-128-256 stage (sa2) on the bf16 matrix pipe: bf16x3, float32-exact (iq_bf3.h) ----------------------
+// pc_group_kernel with layers 2 and 3 as six bf16 products per float32 product.  As in pn2_group_bf3_kernel (iq_pointnet2.hip):
+// activations as three bf16 planes of 272-byte rows, act1 and act2 in ONE 52 KB image (layer 2's tiles wait in registers for
+// the barrier), layer 3 as 2 x 2 tiles per wave, weights through small register rings.  The contraction over the members stays
+// on v_mfma_f32_16x16x4_f32 (float32 operands straight out of the accumulators).
+template <int MTS>
+__device__ __forceinline__ void pcb_layer2(const unsigned char* abase, const __amdgpu_buffer_rsrc_t& rs, int voff, int nt,
+                                           B3 (&ring)[4], f32x16 (&acc)[MTS][1]) {
+    constexpr int ROWB = 272, PLANEB = 64 * ROWB, TS = 4 * 8 * 1024;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        bf16x8 af[MTS][3];
+#pragma unroll
+        for (int i = 0; i < MTS; ++i) a3_load<PLANEB>(af[i], abase + i * 32 * ROWB, ks);
+        const B3 b[1] = {ring[ks & 3]};
+        if (ks + 4 < 8) ring[ks & 3] = b3_load_at(rs, voff, (nt * 8 + ks + 4) * 1024, TS);
+        mfma_bf3_block<MTS, 1>(af, b, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+struct PcB3x2 { B3 b[2]; };
+__device__ __forceinline__ void pcb_layer3(const unsigned char* abase, const __amdgpu_buffer_rsrc_t& rs, int voff, int nt0,
+                                           PcB3x2 (&ring)[2], f32x16 (&acc)[2][2]) {
+    constexpr int ROWB = 272, PLANEB = 64 * ROWB, TS = 8 * 8 * 1024;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        bf16x8 af[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a3_load<PLANEB>(af[i], abase + i * 32 * ROWB, ks);
+        const B3 b[2] = {ring[ks & 1].b[0], ring[ks & 1].b[1]};
+        if (ks + 2 < 8) {
+            ring[ks & 1].b[0] = b3_load_at(rs, voff, (nt0 * 8 + ks + 2) * 1024, TS);
+            ring[ks & 1].b[1] = b3_load_at(rs, voff, ((nt0 + 4) * 8 + ks + 2) * 1024, TS);
+        }
+        mfma_bf3_block<2, 2>(af, b, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void pc_group_bf3_kernel(PcGroupArgs a) {
+    constexpr int C1 = 128, C3 = 256, ROWB = 272, PLANEB = kMC * ROWB, LDS_SW = kMC + 2;
+    constexpr int Q1 = C1 / 4, NR = kMC * Q1 / kThreads;
+    __shared__ __attribute__((aligned(16))) unsigned char planes[3 * PLANEB];   // act1, then act2: three bf16 planes [64][136]
+    __shared__ __attribute__((aligned(16))) float rel[2 * kMC * 4];
+    __shared__ __attribute__((aligned(16))) float swT[2 * 16 * LDS_SW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = blockIdx.x >> 3;
+    const int b = iq::xcd_cloud(blockIdx.x, a.wgs_per_cloud, a.B);
+    if (b >= a.B) return;
+    const int K = a.K;
+    const int live_groups = a.n_unique ? min(a.S, a.n_unique[b]) : a.S;
+    const int chunks_total = (live_groups * K + kMC - 1) / kMC;
+    const int ch0 = (slot % a.wgs_per_cloud) * a.chunks_per_wg;
+    if (ch0 >= chunks_total) return;
+    const int nchunks = min(a.chunks_per_wg, chunks_total - ch0);
+    const int fl = lane & 31, fh = lane >> 5;
+    const unsigned char* abase = planes + fl * ROWB + 16 * fh;
+    const int wave_s = uniform(wave), voff = lane * 16;
+    const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w2_bf3), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w3_bf3), 0, 0x7fffffff, 0x00020000);
+    const size_t member0 = (size_t)b * a.S * K;
+    const float* swlane = swT + (lane & 15) * LDS_SW + ((lane >> 4) & 1) + 4 * (lane >> 5);
+
+    const int c4 = tid % Q1, rsub = tid / Q1;
+    f32x4 w1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w1[e] = *reinterpret_cast<const f32x4*>(a.w1x + (c4 * 4 + e) * 4);
+    const __amdgpu_buffer_rsrc_t ursrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.U ? a.U + (size_t)b * a.N * a.ldu : a.w1x), 0, 0x7fffffff, 0x00020000);
+    f32x4 ureg[NR];
+    auto stage0a = [&](int ch, int buf) {   // as pc_group_kernel
+        const size_t m = member0 + (size_t)(ch0 + ch) * kMC;
+        if (tid < kMC) *reinterpret_cast<f32x4*>(rel + (buf * kMC + tid) * 4) = *reinterpret_cast<const f32x4*>(a.mrel + (m + tid) * 4);
+        const int mem = tid >> 2, q4 = tid & 3;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.msw + (m + mem) * 16 + q4 * 4);
+        float* dst = swT + buf * 16 * LDS_SW + (q4 * 4) * LDS_SW + mem;
+        dst[0] = v[0]; dst[LDS_SW] = v[1]; dst[2 * LDS_SW] = v[2]; dst[3 * LDS_SW] = v[3];
+    };
+    auto gather_u = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = rsub + i * (kThreads / Q1);
+            const int p = __float_as_int(rel[(buf * kMC + r) * 4 + 3]);
+            if (a.U) ureg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (p * a.ldu + c4 * 4) * 4, 0, 0));
+            else ureg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    stage0a(0, 0);
+    __syncthreads();
+    gather_u(0);
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cur = ch & 1, nxt = cur ^ 1;
+        B3 ring2[4];                                 // layer 2's weights (n-tile = wave), in flight across stage 0b
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ring2[i] = b3_load_at(w2rs, voff, (wave_s * 8 + i) * 1024, 4 * 8 * 1024);
+        // ---- stage 0b: layer 1 -> act1 (three planes) ------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = rsub + i * (kThreads / Q1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rel + (cur * kMC + r) * 4);
+            f32x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = fmaf(w1[e][2], v[2], fmaf(w1[e][1], v[1], w1[e][0] * v[0])) + w1[e][3];
+                if (a.U) t += ureg[i][e];
+                h[e] = fmaxf(t, 0.f);
+            }
+            row4_to_planes<PLANEB>(planes + r * ROWB + c4 * 8, h);
+        }
+        __syncthreads();  // act1 complete
+        // ---- layer 2: tiles (m-tile 0..1, n-tile = wave) kept in registers ---------------------------------------------------
+        f32x16 acc2[2][1] = {{{0}}, {{0}}};
+        pcb_layer2<2>(abase, w2rs, voff, wave_s, ring2, acc2);
+        PcB3x2 ring3[2];                             // layer 3's weights (n-tiles wave, wave + 4), in flight across the epilogue
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ring3[i].b[0] = b3_load_at(w3rs, voff, (wave_s * 8 + i) * 1024, 8 * 8 * 1024);
+            ring3[i].b[1] = b3_load_at(w3rs, voff, ((wave_s + 4) * 8 + i) * 1024, 8 * 8 * 1024);
+        }
+        if (ch + 1 < nchunks) stage0a(ch + 1, nxt);
+        __syncthreads();  // every wave has read act1: the image is free
+        {
+            const float bias = a.b2[wave * 32 + fl];
+            c_tile_to_planes<ROWB, PLANEB>(planes + wave * 64, lane, [&](int i) { return fmaxf(acc2[0][0][i] + bias, 0.f); });
+            c_tile_to_planes<ROWB, PLANEB>(planes + 32 * ROWB + wave * 64, lane, [&](int i) { return fmaxf(acc2[1][0][i] + bias, 0.f); });
+        }
+        __syncthreads();  // act2 complete; rel[nxt] / swT[nxt] visible
+        if (ch + 1 < nchunks) gather_u(nxt);                                // consumed after layer 3
+        // ---- layer 3 (2 x 2 tiles per wave) + contraction over the members (fp32 MFMA, as pc_group_kernel) -------------------
+        f32x16 acc3[2][2] = {{{0}, {0}}, {{0}, {0}}};
+        pcb_layer3(abase, w3rs, voff, wave_s, ring3, acc3);
+        const float* swc = swlane + cur * 16 * LDS_SW;
+        const int g_first = (ch0 + ch) * (kMC / K);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int nt = q * 4 + wave;
+            const float bias = a.b3[nt * 32 + fl];
+            f32x4 d00 = {0, 0, 0, 0}, d01 = d00, d10 = d00, d11 = d00;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int m = c_row_i(2 * p);
+                const float s0 = swc[m], s1 = swc[32 + m];
+                const auto a0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(fmaxf(acc3[0][q][2 * p] + bias, 0.f)),
+                                                                 __float_as_uint(fmaxf(acc3[0][q][2 * p + 1] + bias, 0.f)), false, false);
+                const auto a1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(fmaxf(acc3[1][q][2 * p] + bias, 0.f)),
+                                                                 __float_as_uint(fmaxf(acc3[1][q][2 * p + 1] + bias, 0.f)), false, false);
+                d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a0[0]), s0, d00, 0, 0, 0);
+                d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a0[1]), s0, d01, 0, 0, 0);
+                d10 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a1[0]), s1, d10, 0, 0, 0);
+                d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a1[1]), s1, d11, 0, 0, 0);
+            }
+            const int w = lane & 15, cq = 4 * (lane >> 4);
+            float* dst = a.out + ((size_t)b * a.S + g_first) * (C3 * 16) + (size_t)(nt * 32 + cq) * 16 + w;
+            if (K == 64) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dst[j * 16] = d00[j] + d10[j];
+                    dst[(16 + j) * 16] = d01[j] + d11[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dst[j * 16] = d00[j];
+                    dst[(16 + j) * 16] = d01[j];
+                    dst[C3 * 16 + j * 16] = d10[j];
+                    dst[C3 * 16 + (16 + j) * 16] = d11[j];
+                }
+            }
+        }
+        __syncthreads();  // every wave has read act2 and swT[cur]: the next chunk's stage 0b may overwrite the image
     }
 }
 
@@ -892,7 +1070,7 @@ int launch_pc_knn(const float* keys, int nkeys, const float* queries, int S, WsC
 // idx (B,S,K), inv_density (B,N), U (B,N,ldu) or null.
 int launch_pc_group(const iq_pointconv_sa& sa, const float* xyz, const float* new_xyz, const int16_t* idx, const float* inv_density,
                     const float* U, int ldu, float* out, WsC& s, int N, int S, int K, int B, hipStream_t st,
-                    const int32_t* n_unique = nullptr) {
+                    const int32_t* n_unique = nullptr, const void* l2_bf3 = nullptr, const void* l3_bf3 = nullptr) {
     IQ_REQUIRE((size_t)S * K <= 16384 && (S * K) % kMC == 0 && (K == 32 || K == 64), "pointconv group: S=%d K=%d", S, K);
     const size_t total = (size_t)B * S * K;
     const TinyNets nets{sa.densitynet, sa.weightnet};
@@ -905,6 +1083,7 @@ int launch_pc_group(const iq_pointconv_sa& sa, const float* xyz, const float* ne
     a.mrel = s.mrel; a.msw = s.msw; a.U = U; a.ldu = ldu;
     a.w1x = sa.w1x;
     a.w2 = sa.l2.w; a.b2 = sa.l2.b; a.w3 = sa.l3.w; a.b3 = sa.l3.b;
+    a.w2_bf3 = reinterpret_cast<const unsigned short*>(l2_bf3); a.w3_bf3 = reinterpret_cast<const unsigned short*>(l3_bf3);
     a.out = out; a.N = N; a.S = S; a.K = K; a.B = B; a.n_unique = n_unique;
     a.chunks_per_wg = 4;                                   // 256 members per workgroup: the prologue is amortised, the tail stays even
     const int chunks = S * K / kMC;
@@ -916,7 +1095,10 @@ int launch_pc_group(const iq_pointconv_sa& sa, const float* xyz, const float* ne
         // every group runs all its K members (sums, not maxima: nothing is skipped); MFMA work = the two dense layers + the
         // contraction's 16x16x4 tiles
         iq::ProfileSpan dom(iq::kSlotDominant, st, 2.0 * (double)B * S * K * ((double)c1 * c2 + (double)c2 * c3 + 16.0 * c3));
-        hipLaunchKernelGGL((pc_group_kernel<128, 128, 256>), grid, dim3(kThreads), 0, st, a);
+        if (a.w2_bf3 && a.w3_bf3 && iq::tuning(iq::kTuneExperiment) != 56)   // 5 = 56: the fp32-MFMA kernel (A/B and tests)
+            hipLaunchKernelGGL(pc_group_bf3_kernel, grid, dim3(kThreads), 0, st, a);
+        else
+            hipLaunchKernelGGL((pc_group_kernel<128, 128, 256>), grid, dim3(kThreads), 0, st, a);
     }
     else return iq::fail(IQ_EUNSUPPORTED, "pointconv stage %d-%d-%d has no kernel instantiation", c1, c2, c3);
     return iq::check_launch("pc_group_kernel");
@@ -1009,7 +1191,7 @@ int run_pointconv(const iq_pointconv_weights* w, const float* xyz, float* logits
             return rc;
         }
         if ((rc = iq::launch_linear(s.l1, 128, w->sa[1].u, s.u2, 128, B * S1, 0, st))) return rc;
-        if ((rc = launch_pc_group(w->sa[1], s.nx1, s.nx2, s.idx2, s.inv2, s.u2, 128, s.g2, s, S1, S2, 64, B, st))) return rc;
+        if ((rc = launch_pc_group(w->sa[1], s.nx1, s.nx2, s.idx2, s.inv2, s.u2, 128, s.g2, s, S1, S2, 64, B, st, nullptr, w->sa2_l2_bf3, w->sa2_l3_bf3))) return rc;
         if ((rc = iq::launch_linear(s.g2, 4096, w->sa[1].linear, s.l2, 256, B * S2, 1, st))) return rc;
     }
     // ---- sa3: group all 128 points, 259 -> 256 -> 512 -> 1024 ------------------------------------------------------

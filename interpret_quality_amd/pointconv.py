@@ -40,6 +40,16 @@ class PackedWeightsC:
             wt, bt = dev(out), dev(bp)
             return _lib.DenseLayer(wt.data_ptr(), bt.data_ptr(), cin, cout)
 
+        def bf3(w):
+            """the same folded weights as three bf16 terms (iq_pack_weight_bf3) on the device"""
+            cout, cin = w.shape
+            w32 = np.ascontiguousarray(w, dtype=np.float32)
+            out = np.empty(lib.iq_packed_bf3_elems(cout, cin), dtype=np.uint16)
+            _lib.check(lib.iq_pack_weight_bf3(w32.ctypes.data, out.ctypes.data, cout, cin), "iq_pack_weight_bf3")
+            t = torch.from_numpy(out.view(np.int16)).to(device)
+            self._keep.append(t)
+            return t.data_ptr()
+
         def tiny(prefix):
             rows = []
             for j in range(3):
@@ -56,8 +66,11 @@ class PackedWeightsC:
             dst.w1x = dev(np.concatenate([w0[:, :3], bias[:, None]], axis=1)).data_ptr()
             if feat:
                 dst.u = dense(w0[:, 3:], b0)
-            dst.l2 = dense(*fold_conv_bn(sd, p + ".mlp_convs.1", p + ".mlp_bns.1"))
-            dst.l3 = dense(*fold_conv_bn(sd, p + ".mlp_convs.2", p + ".mlp_bns.2"))
+            w2, b2 = fold_conv_bn(sd, p + ".mlp_convs.1", p + ".mlp_bns.1")
+            w3, b3 = fold_conv_bn(sd, p + ".mlp_convs.2", p + ".mlp_bns.2")
+            dst.l2, dst.l3 = dense(w2, b2), dense(w3, b3)
+            if k == 1 and w2.shape == (128, 128) and w3.shape == (256, 128):   # sa2's grouped MLP on the bf16 matrix pipe
+                self.struct.sa2_l2_bf3, self.struct.sa2_l3_bf3 = bf3(w2), bf3(w3)
             dst.densitynet = tiny(p + ".densitynet")
             dst.weightnet = tiny(p + ".weightnet")
             dst.linear = dense(*fold_conv_bn(sd, p + ".linear", p + ".bn_linear"))

@@ -166,3 +166,30 @@ def test_per_cloud_tables_are_kept_across_launches_and_never_go_stale(model):
     cob = torch.tensor([i % 2 for i in range(4000)], dtype=torch.int32, device=d)
     model.coalition_logits(*a2, big, cob, num_regions=32)
     assert torch.equal(model.coalition_logits(*a2, keep, co, num_regions=32), moved)
+
+
+def test_sa2_on_the_bf16_matrix_pipe_equals_the_fp32_mfma_kernel_to_rounding(model):
+    """sa2's grouped MLP (128 -> 128 -> 256) runs as six bf16 products per float32 product with float32 accumulation
+    (pc_group_bf3_kernel); tuning key 5 = 56 selects the fp32-MFMA kernel.  Same logits to float32 rounding, on dense clouds and
+    on coalitions."""
+    from interpret_quality_amd import _lib
+    d = dev()
+    rng = np.random.default_rng(23)
+    clouds = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in (2, 7)]).to(d)
+    rid = torch.stack([hip_ops.region_assign(clouds[c].contiguous(), hip_ops.fps(clouds[c:c + 1], 32)[0].contiguous()) for c in range(2)])
+    centers = clouds.mean(dim=1)
+    keep = [(1 << 32) - 1, 0xffff0000] + [int(x) | 0xff for x in rng.integers(0, 1 << 32, size=30, dtype=np.uint64)]
+    keep_t = hip_ops.masks_to_tensor(keep, d)
+    co_t = torch.tensor([i % 2 for i in range(len(keep))], dtype=torch.int32, device=d)
+    got = model.coalition_logits(clouds, centers, rid, keep_t, co_t, num_regions=32)
+    dense = model.forward_points(clouds)
+    lib = _lib.load()
+    lib.iq_set_tuning(5, 56)
+    try:
+        ref = model.coalition_logits(clouds, centers, rid, keep_t, co_t, num_regions=32)
+        dense_ref = model.forward_points(clouds)
+    finally:
+        lib.iq_set_tuning(5, 0)
+    assert not torch.equal(got, ref)                                      # a different kernel did run
+    for a, b in ((got, ref), (dense, dense_ref)):
+        assert (a - b).abs().max().item() < 3e-6 * b.abs().max().item()
