@@ -156,8 +156,8 @@ def _read_slot(lib, slot):
 # dominates its step here
 OTHER_MODELS = {
     "pointnet2": {"config": "BASELINE configs[2]", "dense_gflop": 7.83, "kernel": "pn2_group_kernel<128,128,256> (sa2, r=0.8)"},
-    "dgcnn": {"config": "BASELINE configs[3]", "dense_gflop": 5.33, "kernel": "pn_gemm_bf3_pool_kernel (conv5 + max/mean pool)", "bf3": True},
-    "gcnn": {"config": "BASELINE configs[3] (gcnn)", "dense_gflop": 4.79, "kernel": "pn_gemm_bf3_pool_kernel (conv5 + max/mean pool)", "bf3": True},
+    "dgcnn": {"config": "BASELINE configs[3]", "dense_gflop": 5.33, "kernel": "pn_gemm_bf3_kernel<pool> (conv5 + max/mean pool)", "bf3": True},
+    "gcnn": {"config": "BASELINE configs[3] (gcnn)", "dense_gflop": 4.79, "kernel": "pn_gemm_bf3_kernel<pool> (conv5 + max/mean pool)", "bf3": True},
     "pointconv": {"config": "Shapley shape of configs[2]", "dense_gflop": None, "kernel": "pc_group_kernel<128,128,256> (sa2)"},
 }
 

@@ -182,6 +182,9 @@ typedef struct iq_dense_layer {
     const float* b;
     int32_t cin;
     int32_t cout;
+    const void* w_bf3;   /* optional (NULL: fp32 MFMA): the same weights as three bf16 terms (iq_pack_weight_bf3); wide layers
+                          * (cout a multiple of 256, cin a multiple of 32) then take their products on the bf16 matrix pipe,
+                          * float32-exact */
 } iq_dense_layer;
 
 typedef struct iq_pointnet_weights {

@@ -19,7 +19,8 @@ class IqError(RuntimeError):
 
 
 class DenseLayer(ctypes.Structure):
-    _fields_ = [("w", ctypes.c_void_p), ("b", ctypes.c_void_p), ("cin", ctypes.c_int32), ("cout", ctypes.c_int32)]
+    _fields_ = [("w", ctypes.c_void_p), ("b", ctypes.c_void_p), ("cin", ctypes.c_int32), ("cout", ctypes.c_int32),
+                ("w_bf3", ctypes.c_void_p)]
 
 
 class PointNetWeights(ctypes.Structure):

@@ -326,26 +326,37 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_lds_kernel(const float* _
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(kThreads, 2) void pn_gemm_bf3_pool_kernel(const float* __restrict__ A, int lda,
-                                                                       const unsigned short* __restrict__ w3,
-                                                                       const float* __restrict__ bias, float* __restrict__ out,
-                                                                       int M, int K, int Nout, int relu,
-                                                                       const int32_t* __restrict__ m_dev,
-                                                                       const float* __restrict__ row_w, int col_blocks) {
+// POOL = false: the plain dense layer out (M, ldo) = act(A W^T + b) on the same tiles (launch_linear, for layers that carry
+// iq_dense_layer.w_bf3); tile_nu / rows_per_cloud as in pn_gemm_lds_kernel.
+template <bool POOL>
+__global__ __launch_bounds__(kThreads, 2) void pn_gemm_bf3_kernel(const float* __restrict__ A, int lda,
+                                                                  const unsigned short* __restrict__ w3,
+                                                                  const float* __restrict__ bias, float* __restrict__ out, int ldo,
+                                                                  int M, int K, int Nout, int relu,
+                                                                  const int32_t* __restrict__ m_dev,
+                                                                  const float* __restrict__ row_w, int col_blocks,
+                                                                  const int32_t* __restrict__ tile_nu, int rows_per_cloud) {
     // wave tile: ALL 128 rows (MT = 4 m-tiles) x 64 columns (NT = 2): a weight fragment feeds four m-tiles - with 64 x 128 wave
     // tiles (two m-tiles per fragment) the weight stream alone asked the L2 for 19 TB/s at full matrix rate
     constexpr int MT = 4, NT = 2, KC = 32, ROWB = 80, PLANE = 128 * ROWB;      // bytes
     __shared__ __attribute__((aligned(16))) unsigned char As[2][3 * PLANE];
-    __shared__ float wrow[128];
+    __shared__ float wrow[POOL ? 128 : 1];
     const int row_tiles = (M + 127) / 128;
     const int per = 8 * col_blocks, grp = blockIdx.x / per, rr = blockIdx.x - grp * per;
     const int bx = grp * 8 + (rr & 7), by = rr >> 3;                   // column blocks of a row tile side by side on one XCD
     if (bx >= row_tiles) return;
     if (m_dev) M = min(M, *m_dev);
-    const int m0 = bx * 128;
+    int m0 = bx * 128;
+    if (!POOL && tile_nu) {   // as pn_gemm_lds_kernel: cloud-fastest walk, tiles beyond a cloud's live rows skipped
+        const int ntc = rows_per_cloud / 128, nc = row_tiles / ntc;
+        if (nc * ntc == row_tiles) m0 = ((bx % nc) * ntc + bx / nc) * 128;
+        if (m0 >= M) return;
+        const int c = m0 / rows_per_cloud;
+        if (m0 - c * rows_per_cloud >= tile_nu[c]) return;
+    }
     if (m0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 128) wrow[tid] = m0 + tid < M ? row_w[m0 + tid] : 0.f;
+    if (POOL && tid < 128) wrow[tid] = m0 + tid < M ? row_w[m0 + tid] : 0.f;
     const int KS = K >> 4, nchunks = K / KC;
     const int NTT = (Nout + 31) >> 5;
     const int nt0 = (by * 4 + wave) * NT;
@@ -446,6 +457,29 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_bf3_pool_kernel(const flo
         if (kc + 1 < nchunks) store_chunk((kc + 1) & 1);
         __syncthreads();
     }
+    if (!POOL) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if (m0 + i * 32 >= M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = (nt0 + j) * 32 + (lane & 31);
+                if (nt0 + j >= NTT || col >= Nout) continue;
+                const float b = breg[j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + i * 32 + c_row(r, lane);
+                    if (row < M) {
+                        float v = acc[i][j][r] + b;
+                        if (relu == 1) v = fmaxf(v, 0.f);
+                        else if (relu == 2) v = v > 0.f ? v : 0.2f * v;
+                        out[(size_t)row * ldo + col] = v;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int trow = m0 + i * 32;
@@ -488,6 +522,16 @@ int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* o
     IQ_REQUIRE(L.w && L.b && L.cin % 8 == 0 && L.cout >= 1, "dense layer: bad descriptor (cin=%d cout=%d)", L.cin, L.cout);
     const int ntiles = (L.cout + 31) / 32;
     if (tile_nu && (rows_per_cloud <= 0 || rows_per_cloud % 128 != 0)) tile_nu = nullptr;   // tiles must not straddle clouds
+    // bf16x3 on the bf16 matrix pipe, float32-exact - for EVERY M, so that a row's result does not depend on the launch it is in
+    // (5 = 57: fp32 MFMA, A/B and tests)
+    // (column blocks of 256: 320 outputs would leave the second block a quarter full, and lose to the NT = 5 fp32 tiling)
+    if (L.w_bf3 && L.cout % 256 == 0 && L.cin % 32 == 0 && iq::tuning(iq::kTuneExperiment) != 57) {
+        const int gx = (M + 127) / 128, gy = (L.cout + 255) / 256;
+        hipLaunchKernelGGL(pn_gemm_bf3_kernel<false>, dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
+                           reinterpret_cast<const unsigned short*>(L.w_bf3), L.b, out, ldo, M, L.cin, L.cout, relu, m_dev, nullptr, gy,
+                           tile_nu, rows_per_cloud);
+        return iq::check_launch("pn_gemm_bf3_kernel");
+    }
     if (M >= 2048 && ntiles >= 4 && L.cin % 32 == 0 && iq::tuning(iq::kTuneNoLdsGemm) == 0) {
         const int shape = iq::tuning(iq::kTuneExperiment);   // 5 = 30: round 3's choice of shapes (A/B runs)
         if (ntiles % 10 == 0 && shape != 30 && (long long)((M + 127) / 128) * (ntiles / 10) >= 2048) {
@@ -572,9 +616,10 @@ int iq::launch_linear_pool(const float* A, int lda, const iq_dense_layer& L, flo
         return iq::fail(IQ_EUNSUPPORTED, "dense layer + pool: cin=%d cout=%d", L.cin, L.cout);
     const int gy = (ntiles + 7) / 8, gx = (M + 127) / 128;
     if (w_bf3 && L.cout % 256 == 0 && iq::tuning(iq::kTuneExperiment) != 53) {   // 5 = 53: the fp32 MFMA (A/B and tests)
-        hipLaunchKernelGGL(pn_gemm_bf3_pool_kernel, dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
-                           reinterpret_cast<const unsigned short*>(w_bf3), L.b, partial, M, L.cin, L.cout, relu, m_dev, row_w, gy);
-        return iq::check_launch("pn_gemm_bf3_pool_kernel");
+        hipLaunchKernelGGL(pn_gemm_bf3_kernel<true>, dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
+                           reinterpret_cast<const unsigned short*>(w_bf3), L.b, partial, 0, M, L.cin, L.cout, relu, m_dev, row_w, gy,
+                           nullptr, 0);
+        return iq::check_launch("pn_gemm_bf3_kernel<pool>");
     }
     if (iq::tuning(iq::kTuneExperiment) == 48) {   // 5 = 48: the (tiles, column blocks) grid of rounds 1-3 (A/B)
         hipLaunchKernelGGL((pn_gemm_lds_kernel<4, true>), dim3(gx, gy), dim3(kThreads), 0, st, A, lda, L.w, L.b, partial, 0, M, L.cin, L.cout,

@@ -120,7 +120,7 @@ int launch_linear_splitk(const float* A, int lda, const iq_dense_layer& L, float
 // the column maxima and the row_w-weighted column sums over the rows with row_w > 0 (the activations are never stored).
 // cin % 32 == 0, cout % 32 == 0, cout >= 256.
 // w_bf3 (optional): the layer's weights split into three bf16 terms (iq_pack_weight_bf3): the products then run on the bf16
-// matrix pipe, float32-exact (pn_gemm_bf3_pool_kernel).
+// matrix pipe, float32-exact (pn_gemm_bf3_kernel<pool>).
 int launch_linear_pool(const float* A, int lda, const iq_dense_layer& L, float* partial, int M, int relu,
                        const float* row_w, hipStream_t st, const int32_t* m_dev = nullptr, const void* w_bf3 = nullptr);
 // Farthest point sampling (iq_geom.hip); n_unique may be null.

@@ -164,7 +164,7 @@ __device__ __forceinline__ void l3_pass_v2(const WBuf& w3, const float* abase, i
 }
 
 // ---- Variant 3: L3 on the bf16 matrix pipe, float32-exact -----------------------------------------------------------------------
-// (csrc/iq_linear.hip, pn_gemm_bf3_pool_kernel, has the arithmetic: a float32 is three bf16 terms, a product the six largest of the
+// (csrc/iq_linear.hip, pn_gemm_bf3_kernel<pool>, has the arithmetic: a float32 is three bf16 terms, a product the six largest of the
 // nine term products, each exact, accumulated in float32; 16 k cost 192 matrix cycles instead of 512.)  act2 lives in LDS as three
 // bf16 planes [64][136] (row stride 272 bytes = 68 dwords: the same conflict-free ds_read_b128 pattern as the float image), written
 // split by layer 2's epilogue; the weights come split and packed from the host (iq_pack_weight_bf3: fragment (term, n-tile, k-step)

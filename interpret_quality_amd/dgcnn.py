@@ -57,7 +57,7 @@ class PackedWeightsD:
         w5 = np.ascontiguousarray(_np(sd["conv5.0.weight"]).reshape(1024, 512) * s[:, None], dtype=np.float32)
         self.struct.conv5 = dense(w5, t)
         # conv5 (half of a DGCNN step, three quarters of GCNN's) runs on the bf16 matrix pipe: the same folded float32 weights as
-        # three bf16 terms (csrc/iq_linear.hip: pn_gemm_bf3_pool_kernel)
+        # three bf16 terms (csrc/iq_linear.hip: pn_gemm_bf3_kernel<pool>)
         w3 = np.empty(lib.iq_packed_bf3_elems(1024, 512), dtype=np.uint16)
         _lib.check(lib.iq_pack_weight_bf3(w5.ctypes.data, w3.ctypes.data, 1024, 512), "iq_pack_weight_bf3")
         w3t = torch.from_numpy(w3.view(np.int16)).to(device)

@@ -66,12 +66,16 @@ class PackedWeights:
             bp = np.zeros(lib.iq_padded_cout(cout), dtype=np.float32)
             bp[:cout] = b
             wt, bt = dev(pack(w)), dev(bp)
-            setattr(self.struct, name, _lib.DenseLayer(wt.data_ptr(), bt.data_ptr(), cin, cout))
-            if name in ("fstn_c2", "feat_c2", "fstn_c3", "feat_c3"):   # layers 2-3 of the coalition chains on the bf16 matrix pipe: the same weights, split
+
+            def bf3():   # the same weights as three bf16 terms (iq_pack_weight_bf3): products on the bf16 matrix pipe, float32-exact
                 w32 = np.ascontiguousarray(w, dtype=np.float32)
                 w3 = np.empty(lib.iq_packed_bf3_elems(cout, cin), dtype=np.uint16)
                 _lib.check(lib.iq_pack_weight_bf3(w32.ctypes.data, w3.ctypes.data, cout, cin), "iq_pack_weight_bf3")
-                setattr(self.struct, name + "_bf3", dev(w3.view(np.int16)).data_ptr())
+                return dev(w3.view(np.int16)).data_ptr()
+            wide = cout % 256 == 0 and cin % 32 == 0       # the 1024 -> 512 -> 256 heads (include/iq.h: iq_dense_layer.w_bf3)
+            setattr(self.struct, name, _lib.DenseLayer(wt.data_ptr(), bt.data_ptr(), cin, cout, bf3() if wide else None))
+            if name in ("fstn_c2", "feat_c2", "fstn_c3", "feat_c3"):   # layers 2-3 of the coalition chains
+                setattr(self.struct, name + "_bf3", bf3())
 
         def in_layer(name, layer, bn):
             w, b = fold_bn(sd, layer, bn)  # (64,3), (64,)

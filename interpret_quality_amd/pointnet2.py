@@ -51,7 +51,8 @@ class PackedWeights2:
             bp = np.zeros(lib.iq_padded_cout(cout), dtype=np.float32)
             bp[:cout] = b
             wt, bt = dev(out), dev(bp)
-            return _lib.DenseLayer(wt.data_ptr(), bt.data_ptr(), cin, cout)
+            wide = cout % 256 == 0 and cin % 32 == 0                     # wide layers: also as three bf16 terms (include/iq.h)
+            return _lib.DenseLayer(wt.data_ptr(), bt.data_ptr(), cin, cout, bf3(w32) if wide else None)
 
         def bf3(w):
             """the same folded weights as three bf16 terms (iq_pack_weight_bf3) on the device"""
