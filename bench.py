@@ -65,6 +65,7 @@ PEAK_BF16_MFMA_TFLOPS = 16 * 157.3   # same table: the bf16 MFMA runs 16 x the f
 BF3_PRODUCTS = 6              # bf16 products per float32 product when both operands are split in three bf16 terms
 CHAIN_MAC_PER_ROW = 143360.0  # 64*64 + 64*128 + 128*1024: the MFMA layers of one chain-kernel row
 CHAIN_MAC_L12, CHAIN_MAC_L3 = 64 * 64 + 64 * 128, 128 * 1024   # layers 1-2 run in 32-row tiles, layer 3 ends on a 16-row tile
+CHAIN_MAC_L1, CHAIN_MAC_L2 = 64 * 64, 64 * 128                  # (fp32 kernel only); with bf16x3 layer 1 alone stays on the fp32 MFMA
 SLOT_DOMINANT = 5
 
 
@@ -634,7 +635,7 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
         rows = np.concatenate([rows_of(k.cpu().numpy().view(np.uint64), sizes, R) for k in keeps])
         rows32 = (rows + 31) // 32 * 32
         # layer 3 (91 % of a row's MACs) runs on the bf16 matrix pipe, float32-exact (six bf16 products per float32 product), in
-        # 32-row tiles; layers 1-2 on the fp32 MFMA.  (IQ_BENCH_FP32_L3=1 / tuning key 5 = 54: layer 3 on the fp32 MFMA too, with
+        # 32-row tiles; layer 1 on the fp32 MFMA, layer 2 as bf16x3 too.  (IQ_BENCH_FP32_L3=1 / tuning key 5 = 54: layer 3 on the fp32 MFMA too, with
         # 16-row tail tiles - round 3's kernel.)
         bf3 = os.environ.get("IQ_BENCH_FP32_L3") != "1"
         rows_l3 = rows32 if bf3 else np.where((rows - 1) % 32 < 16, (rows + 15) // 16 * 16, rows32)
@@ -648,8 +649,11 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
         tf = lambda flop: flop / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0  # noqa: E731
         achieved = tf(executed_flop)
         # the matrix pipe's minimum time for what the kernel issues: fp32 MFMAs at 157.3 TF, bf16 MFMAs at 16 x that, six per product
-        t_min = l12_flop / (PEAK_F32_MFMA_TFLOPS * 1e12) + (BF3_PRODUCTS * l3_flop / (PEAK_BF16_MFMA_TFLOPS * 1e12) if bf3
-                                                              else l3_flop / (PEAK_F32_MFMA_TFLOPS * 1e12))
+        if bf3:   # layer 1 (the 64 x 64 transform) on the fp32 MFMA, layers 2-3 as six bf16 products per float32 product
+            f32_flop = l12_flop * CHAIN_MAC_L1 / CHAIN_MAC_L12
+            t_min = f32_flop / (PEAK_F32_MFMA_TFLOPS * 1e12) + BF3_PRODUCTS * (executed_flop - f32_flop) / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+        else:
+            t_min = executed_flop / (PEAK_F32_MFMA_TFLOPS * 1e12)
         peak_mix = executed_flop / t_min / 1e12
         step_flops = lib.iq_pointnet_flops_per_coalition(NUM_POINTS) * n_coal
         traffic, traffic_detail = (None, "not measured (N > 1 or --traffic 0)")
@@ -674,10 +678,10 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
             "roofline": {"bound": "mfma", "kernel": "pn_chain_kernel<fstn|trunk>", "achieved": achieved,
                          "peak": peak_mix, "unit": "TFLOP/s", "frac": achieved / peak_mix,
                          "frac_basis": "executed",
-                         "peak_basis": ("float32-equivalent TFLOP/s of the matrix pipe for this kernel's instruction mix: layers 1-2 (9 % of the "
-                                        "MACs) on v_mfma_f32_32x32x2_f32 at 157.3 TF, layer 3 as six exact bf16 products per float32 product on "
-                                        "v_mfma_f32_32x32x16_bf16 at 16 x 157.3 / 6 = 419 TF") if bf3 else "dense fp32 MFMA peak",
-                         "layer3_on": "bf16 matrix pipe, three-term split, float32-exact" if bf3 else "fp32 MFMA",
+                         "peak_basis": ("float32-equivalent TFLOP/s of the matrix pipe for this kernel's instruction mix: layer 1 (3 % of the "
+                                        "MACs) on v_mfma_f32_32x32x2_f32 at 157.3 TF, layers 2-3 as six exact bf16 products per float32 product "
+                                        "on v_mfma_f32_32x32x16_bf16 at 16 x 157.3 / 6 = 419 TF") if bf3 else "dense fp32 MFMA peak",
+                         "layers_2_3_on": "bf16 matrix pipe, three-term split, float32-exact" if bf3 else "fp32 MFMA",
                          "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                          "frac_useful": tf(useful_flop) / peak_mix,
                          "frac_algorithmic": tf(algorithmic_flop) / peak_mix,
@@ -691,7 +695,7 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
                          "note": "frac_basis executed: achieved = float32 FLOP of the MFMA tiles the kernel issues (32-row tiles) / HIP-event "
                                  "launch time (separate profiled pass); frac = achieved / peak, i.e. the matrix pipe's minimum time for "
                                  "the issued instructions (see peak_basis) / the launch time.  frac_of_fp32_mfma_peak: achieved / 157.3 - "
-                                 "above 1 because layer 3 no longer runs on the fp32 MFMA.  frac_useful: the coalitions' distinct rows "
+                                 "above 1 because layers 2-3 no longer run on the fp32 MFMA.  frac_useful: the coalitions' distinct rows "
                                  "only (no tile padding).  frac_algorithmic: SURVEY 8d's figure, the dense reference layers this kernel "
                                  "implements (every coalition, all 1024 rows): the kernel evaluates each coalition's distinct "
                                  "points only, an exact skip (DESIGN.md 3).  traffic: HBM bytes per launch from rocprofv3 FETCH_SIZE x2 "

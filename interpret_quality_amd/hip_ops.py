@@ -278,9 +278,11 @@ def smoothness_enum(cloud, region_id, num_regions, mode, objective, step=1e-3, e
 
 
 class PackedLinear:
-    """A (cout,cin) weight + bias in the library's MFMA fragment order (iq_pack_weight) on the device."""
+    """A (cout,cin) weight + bias in the library's MFMA fragment order (iq_pack_weight) on the device.  bf3: also as three bf16
+    terms (iq_pack_weight_bf3) - a layer with cout % 256 == 0 and cin % 32 == 0 then takes its products on the bf16 matrix pipe,
+    float32-exact (include/iq.h: iq_dense_layer.w_bf3)."""
 
-    def __init__(self, weight, bias, device):
+    def __init__(self, weight, bias, device, bf3=False):
         lib = _lib.load()
         w = np.ascontiguousarray(weight, dtype=np.float32)
         self.cout, self.cin = w.shape
@@ -289,7 +291,13 @@ class PackedLinear:
         bp = np.zeros(lib.iq_padded_cout(self.cout), dtype=np.float32)
         bp[:self.cout] = np.asarray(bias, dtype=np.float32)
         self.w, self.b = torch.from_numpy(packed).to(device), torch.from_numpy(bp).to(device)
-        self.struct = _lib.DenseLayer(self.w.data_ptr(), self.b.data_ptr(), self.cin, self.cout)
+        self.w3 = None
+        if bf3:
+            terms = np.empty(lib.iq_packed_bf3_elems(self.cout, self.cin), dtype=np.uint16)
+            _lib.check(lib.iq_pack_weight_bf3(w.ctypes.data, terms.ctypes.data, self.cout, self.cin), "iq_pack_weight_bf3")
+            self.w3 = torch.from_numpy(terms.view(np.int16)).to(device)
+        self.struct = _lib.DenseLayer(self.w.data_ptr(), self.b.data_ptr(), self.cin, self.cout,
+                                      self.w3.data_ptr() if self.w3 is not None else None)
 
 
 def linear(x, layer, act=0):

@@ -332,6 +332,40 @@ def test_linear_variants_agree_and_match_fp32_reference(m, cin, cout, act):
     assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("m,cin,cout,act", [(5000, 512, 1024, 2), (1, 1024, 512, 1), (131, 4096, 256, 1), (40000, 128, 256, 0)])
+def test_dense_layer_on_the_bf16_matrix_pipe_is_float32_exact(m, cin, cout, act):
+    """A layer that carries its weights as three bf16 terms (iq_dense_layer.w_bf3, cout % 256 == 0) takes six exact bf16 products
+    per float32 product, accumulated in float32 (pn_gemm_bf3_kernel<false>), for every row count: at least as close to the
+    float64 result as the fp32-MFMA kernel (tuning key 5 = 57), equal to it within float32 rounding, and a row's result does
+    not depend on the rows around it."""
+    from interpret_quality_amd import _lib
+    rng = np.random.default_rng(m + cin)
+    w = (rng.standard_normal((cout, cin)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    x = rng.standard_normal((m, cin)).astype(np.float32)
+    d = dev()
+    layer = hip_ops.PackedLinear(w, b, d, bf3=True)
+    xt = torch.from_numpy(x).to(d)
+    lib = _lib.load()
+    got = hip_ops.linear(xt, layer, act)
+    lib.iq_set_tuning(5, 57)
+    try:
+        f32 = hip_ops.linear(xt, layer, act)
+    finally:
+        lib.iq_set_tuning(5, 0)
+    ref = torch.from_numpy(x).double() @ torch.from_numpy(w).double().T + torch.from_numpy(b).double()
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.leaky_relu(ref, 0.2)
+    e_bf3, e_f32 = rel_err(got.cpu().numpy(), ref.numpy()), rel_err(f32.cpu().numpy(), ref.numpy())
+    assert e_bf3 < 2e-6 and e_bf3 <= 1.5 * e_f32 + 1e-7, (e_bf3, e_f32)      # (float32 accumulation over cin terms in both)
+    assert not torch.equal(got, f32) or m == 1
+    assert (got - f32).abs().max().item() < 3e-6 * f32.abs().max().item()
+    k = min(m, 77)
+    assert torch.equal(hip_ops.linear(xt[:k].contiguous(), layer, act), got[:k])      # launch-size independent
+
+
 def test_pointnet_without_feature_transform():
     """`feature_transform=False` (models/pointnet.py:62-63,72-78; a constructor option no stage script takes): no feature STN -
     iq_pointnet_coalitions skips that chain and the trunk multiplies by the packed identity (exact).  Dense forward (logits,
