@@ -103,3 +103,34 @@ def test_pack_weight_bf3_terms_add_up_to_the_float32_weight_exactly():
                 got[nt * 32 + (lane & 31), 16 * ks + 8 * (lane >> 5) + j] = terms[:, nt, ks, :, j].astype(np.float64).sum(axis=0)
     assert np.array_equal(got[:cout], w.astype(np.float64)) and not got[cout:].any()
     assert np.abs(terms[1]).max() <= np.abs(terms[0]).max() * 2.0 ** -8 and np.abs(terms[2]).max() <= np.abs(terms[0]).max() * 2.0 ** -16
+
+
+def test_ctypes_structures_have_the_layout_of_the_header(tmp_path):
+    """Every struct of include/iq.h that crosses the boundary, field by field: sizeof and offsetof as gcc sees the header against
+    the ctypes mirror in _lib.py (a field added on one side only would shift every pointer behind it, silently)."""
+    import ctypes
+    import subprocess
+    from interpret_quality_amd import _lib
+    pairs = {"iq_dense_layer": _lib.DenseLayer, "iq_pointnet_weights": _lib.PointNetWeights, "iq_pn2_scale": _lib.Pn2Scale,
+             "iq_pointnet2_weights": _lib.PointNet2Weights, "iq_pointconv_sa": _lib.PointConvSa,
+             "iq_pointconv_weights": _lib.PointConvWeights, "iq_dgcnn_weights": _lib.DgcnnWeights,
+             "iq_smoothness_params": _lib.SmoothnessParams}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "iq.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe)], check=True, capture_output=True)
+    seen = 0
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        cname, what, val = ln.split()
+        cls = pairs[cname]
+        want = ctypes.sizeof(cls) if what == "sizeof" else getattr(cls, what).offset
+        assert int(val) == want, (cname, what, val, want)
+        seen += 1
+    assert seen == sum(1 + len(c._fields_) for c in pairs.values())
