@@ -366,6 +366,24 @@ def test_dense_layer_on_the_bf16_matrix_pipe_is_float32_exact(m, cin, cout, act)
     assert torch.equal(hip_ops.linear(xt[:k].contiguous(), layer, act), got[:k])      # launch-size independent
 
 
+def test_bf16x3_split_loses_no_bit_of_a_float32():
+    """The three-term split itself, through the kernel: with a signed power-of-two diagonal as the weight, a bf16x3 layer must
+    return every input bit for bit (x = h + m + l exactly, each term times 2^k exactly, float32 accumulation of one nonzero
+    product per term) - for ordinary values, for values whose low mantissa bits are all set, and across 60 binades."""
+    rng = np.random.default_rng(9)
+    d = dev()
+    n = 256
+    scale = np.ldexp(1.0, rng.integers(-6, 7, size=n)).astype(np.float32) * rng.choice([-1.0, 1.0], size=n).astype(np.float32)
+    layer = hip_ops.PackedLinear(np.diag(scale).astype(np.float32), np.zeros(n, np.float32), d, bf3=True)
+    x = rng.standard_normal((4096, n)).astype(np.float32)
+    x[1000:2000] = np.ldexp(x[1000:2000], rng.integers(-30, 31, size=(1000, n))).astype(np.float32)      # 2^-30 .. 2^30
+    x[2000:3000] = (x[2000:3000].view(np.uint32) | np.uint32(0xffff)).view(np.float32)                  # low 16 mantissa bits set
+    x[3000:3100] = 0.0
+    got = hip_ops.linear(torch.from_numpy(x).to(d), layer, 0).cpu().numpy()
+    want = x * scale[None, :] + np.float32(0.0)          # the layer adds its (zero) bias: -0 becomes +0
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_pointnet_without_feature_transform():
     """`feature_transform=False` (models/pointnet.py:62-63,72-78; a constructor option no stage script takes): no feature STN -
     iq_pointnet_coalitions skips that chain and the trunk multiplies by the packed identity (exact).  Dense forward (logits,
