@@ -176,6 +176,7 @@ struct GroupArgs {
     int ldo;
     int N, S, K, blocks_per_wg;
     int B, wgs_per_cloud;
+    int probe;               // tuning key 5 (79: per-phase cycle counts of pn2_group_bf3_kernel)
 };
 
 __device__ __forceinline__ void merge_max(float* addr, float v) {
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(kThreads, WPS) void pn2_group_kernel(GroupArgs a) {
 // three bf16 planes of 272-byte rows (conflict-free ds_read_b128), split where they are produced; act1 and act2 SHARE one
 // 52 KB image - layer 2 keeps its two tiles in registers until every wave has read act1 - so that two workgroups fit a CU and
 // fill each other's barriers and stage-0 phases (four barriers per chunk instead of two).
+__device__ unsigned long long g_gb_dbg[12];
 template <int MTS>
 __device__ __forceinline__ void gb_layer2(const unsigned char* abase, const __amdgpu_buffer_rsrc_t& rs, int voff, int nt,
                                           B3 (&ring)[4], f32x16 (&acc)[MTS][1]) {
@@ -461,6 +463,7 @@ __device__ __forceinline__ void gb_layer3(const unsigned char* abase, const __am
     }
 }
 
+template <bool STAMP>   // STAMP: diagnostic build (tuning key 5 = 79)
 __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a) {
     constexpr int C1 = 128, kMC = 64, ROWB = 272, PLANEB = kMC * ROWB, BPC = kMC / kBlk;
     __shared__ __attribute__((aligned(16))) unsigned char planes[3 * PLANEB];   // act1, then act2: three bf16 planes [64][136]
@@ -482,6 +485,21 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
 
     const int fl = lane & 31, fh = lane >> 5;
     const unsigned char* abase = planes + fl * ROWB + 16 * fh;
+    // STAMP: shader cycles per phase of wave 0, summed over workgroups (g_gb_dbg, printed by launch_group_t).  Measured (r4,
+    // cycles per 64-row chunk and wave, two workgroups per CU): stage 0b 4 400, layer 2 5 700, stage 0a 1 850, layer-2
+    // epilogue 4 000, layer 3 + pooling 14 300, barrier waits 1 250, prologue + flush 2 000 per chunk = 33 400, of which the
+    // 288 MFMAs need 9 200: the other wave of the SIMD does the same, and its VALU phases do not hide under this wave's MFMAs
+    // (the two share the SIMD's issue and register ports) - 0.55 MFMA-busy.
+    unsigned long long t_last = 0;
+    unsigned t_sum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int slot) {
+        if (STAMP) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            if (slot >= 0) t_sum[slot] += (unsigned)(t - t_last);
+            t_last = t;
+        }
+    };
 
     constexpr int Q1 = C1 / 4, NR = kMC * Q1 / kThreads;   // stage 0b: a thread owns 4 consecutive channels of NR rows
     const int c4 = tid % Q1, rsub = tid / Q1;
@@ -518,9 +536,11 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
             else ureg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
+    stamp(-1);
     stage0a(0, 0);
     __syncthreads();
     gather_u(0);
+    stamp(0);   // prologue
 
     int run_g[2] = {-1, -1};
     float run_v[2] = {0.f, 0.f};
@@ -564,7 +584,9 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
                 h[e] = fmaxf(fmaf(w1[e][2], v[2], fmaf(w1[e][1], v[1], w1[e][0] * v[0])) + w1[e][3] + ureg[i][e], 0.f);
             row4_to_planes<PLANEB>(planes + r * ROWB + c4 * 8, h);
         }
+        stamp(1);   // ring prime + stage 0b
         __syncthreads();  // act1 complete
+        stamp(2);   // wait
         // ---- layer 2: 128 -> 128, tiles (m-tile 0..1, n-tile = wave) kept in registers -------------------
         f32x16 acc2[2][1] = {{{0}}, {{0}}};
         if (mts == 2) {
@@ -580,15 +602,20 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
             ring3[i].b[0] = b3_load_at(w3rs, voff, (wave_s * 8 + i) * 1024, 8 * 8 * 1024);
             ring3[i].b[1] = b3_load_at(w3rs, voff, ((wave_s + 4) * 8 + i) * 1024, 8 * 8 * 1024);
         }
+        stamp(3);   // layer 2 MFMAs + ring 3 prime
         if (ch + 1 < nchunks) stage0a(ch + 1, nxt);
+        stamp(4);   // stage 0a of the next chunk
         __syncthreads();  // every wave has read act1: the image is free
+        stamp(5);   // wait
         {
             const float bias = a.b2[wave * 32 + fl];
             c_tile_to_planes<ROWB, PLANEB>(planes + wave * 64, lane, [&](int i) { return fmaxf(acc2[0][0][i] + bias, 0.f); });
             if (mts == 2)
                 c_tile_to_planes<ROWB, PLANEB>(planes + 32 * ROWB + wave * 64, lane, [&](int i) { return fmaxf(acc2[1][0][i] + bias, 0.f); });
         }
+        stamp(6);   // layer 2 epilogue
         __syncthreads();  // act2 complete; rel[nxt] visible
+        stamp(7);   // wait
         if (ch + 1 < nchunks) gather_u(nxt);  // consumed after layer 3
         // ---- layer 3: 128 -> 256, 2 x 2 tiles per wave, block maxima merged into the owning groups -------
         if (mts == 2) {
@@ -615,10 +642,17 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
                 for (int i = 0; i < 4; ++i) feed(q, gq[i], m0.v[i]);
             }
         }
+        stamp(8);   // gather + layer 3 + pooling
         __syncthreads();  // every wave has read act2: the next chunk's stage 0b may overwrite the image
+        stamp(9);   // wait
     }
     flush_group(0);
     flush_group(1);
+    stamp(10);
+    if (STAMP && tid == 0) {
+        for (int i = 0; i < 11; ++i) atomicAdd(&g_gb_dbg[i], (unsigned long long)t_sum[i]);
+        atomicAdd(&g_gb_dbg[11], (unsigned long long)nchunks);
+    }
 }
 
 // rows s >= n_unique[b] := row 0 (duplicate centroids), columns [c0, c0+ncols)
@@ -653,7 +687,21 @@ int launch_group_t(GroupArgs a, int B, hipStream_t st) {
     // 4 workgroups per CU: 44.5 k -> 46.3 k coalitions/s (tuning key 5 = 64 forces 64-row chunks for A/B runs)
     if (C1 == 128 && C2 == 128 && C3 == 256 && a.w2_bf3 && a.w3_bf3 && iq::tuning(iq::kTuneExperiment) != 56 &&
         iq::tuning(iq::kTuneExperiment) != 64)    // 5 = 56 / 64: the fp32-MFMA kernel with 32- / 64-row chunks (A/B and tests)
-        hipLaunchKernelGGL(pn2_group_bf3_kernel, grid, dim3(kThreads), 0, st, a);
+    {
+        if (a.probe != 79) hipLaunchKernelGGL(pn2_group_bf3_kernel<false>, grid, dim3(kThreads), 0, st, a);
+        else {   // diagnostic: synchronous
+            hipLaunchKernelGGL(pn2_group_bf3_kernel<true>, grid, dim3(kThreads), 0, st, a);
+            unsigned long long h[12];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gb_dbg), sizeof(h));
+            const double n = (double)h[11];
+            fprintf(stderr, "pn2_group_bf3 (wave 0, cycles per chunk over %.0f chunks): prologue/chunk %.0f | ring2+stage0b %.0f wait %.0f | L2 %.0f stage0a %.0f "
+                            "wait %.0f | epilogue %.0f wait %.0f | gather+L3+pool %.0f wait %.0f | flush/chunk %.0f\n", n, h[0] / n, h[1] / n, h[2] / n,
+                    h[3] / n, h[4] / n, h[5] / n, h[6] / n, h[7] / n, h[8] / n, h[9] / n, h[10] / n);
+            for (auto& v : h) v = 0;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gb_dbg), h, sizeof(h));
+        }
+    }
     else if (C3 >= 256 && iq::tuning(iq::kTuneExperiment) != 64)
         hipLaunchKernelGGL((pn2_group_kernel<C1, C2, C3, 32>), grid, dim3(kThreads), 0, st, a);
     else
@@ -682,6 +730,7 @@ double group_work(const GroupArgs& a, int B, int c1, int c2, int c3, hipStream_t
 int launch_group(const iq_pn2_scale& sc, GroupArgs a, const int32_t* n_unique, int B, hipStream_t st, bool dominant = false,
                  const void* l2_bf3 = nullptr, const void* l3_bf3 = nullptr) {
     a.w1x = sc.w1x;
+    a.probe = iq::tuning(iq::kTuneExperiment);
     a.w2_bf3 = reinterpret_cast<const unsigned short*>(l2_bf3);
     a.w3_bf3 = reinterpret_cast<const unsigned short*>(l3_bf3);
     a.w2 = sc.l2.w; a.b2 = sc.l2.b;
