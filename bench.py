@@ -61,6 +61,9 @@ sys.path.insert(0, REPO)
 
 NUM_POINTS, NUM_REGIONS, NUM_PERMS = 1024, 32, 1000
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak (no xf32/TF32 on gfx950)
+# what a pure register loop of v_mfma_f32_32x32x16_bf16 SUSTAINS under the 1.4 kW cap, as a fraction of the dense peak (the governor
+# drops the clock to 1.86 GHz; tools/micro/mfma_bf16_power.hip, profiles/r04_power_probe.txt) - reported beside `frac`, never instead
+SUSTAINED_BF16_MFMA_FRACTION = 0.776
 PEAK_BF16_MFMA_TFLOPS = 16 * 157.3   # same table: the bf16 MFMA runs 16 x the fp32 one (~2.5 PF dense)
 BF3_PRODUCTS = 6              # bf16 products per float32 product when both operands are split in three bf16 terms
 CHAIN_MAC_PER_ROW = 143360.0  # 64*64 + 64*128 + 128*1024: the MFMA layers of one chain-kernel row
@@ -683,6 +686,7 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
                                         "on v_mfma_f32_32x32x16_bf16 at 16 x 157.3 / 6 = 419 TF") if bf3 else "dense fp32 MFMA peak",
                          "layers_2_3_on": "bf16 matrix pipe, three-term split, float32-exact" if bf3 else "fp32 MFMA",
                          "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "frac_of_sustained_bf16_ceiling": (achieved / (peak_mix * SUSTAINED_BF16_MFMA_FRACTION)) if bf3 else None,
                          "frac_useful": tf(useful_flop) / peak_mix,
                          "frac_algorithmic": tf(algorithmic_flop) / peak_mix,
                          "traffic": traffic, "traffic_detail": traffic_detail,
@@ -695,7 +699,9 @@ def weak_scaling(args, rank, world, dev, collectives, rehearsal, force_dist):
                          "note": "frac_basis executed: achieved = float32 FLOP of the MFMA tiles the kernel issues (32-row tiles) / HIP-event "
                                  "launch time (separate profiled pass); frac = achieved / peak, i.e. the matrix pipe's minimum time for "
                                  "the issued instructions (see peak_basis) / the launch time.  frac_of_fp32_mfma_peak: achieved / 157.3 - "
-                                 "above 1 because layers 2-3 no longer run on the fp32 MFMA.  frac_useful: the coalitions' distinct rows "
+                                 "above 1 because layers 2-3 no longer run on the fp32 MFMA.  frac_of_sustained_bf16_ceiling: against what a pure "
+                                 "register loop of bf16 MFMAs holds under the board's power cap (0.776 of the dense peak at 1.86 GHz, measured: "
+                                 "profiles/r04_power_probe.txt) - the kernel draws 1.3 of 1.4 kW.  frac_useful: the coalitions' distinct rows "
                                  "only (no tile padding).  frac_algorithmic: SURVEY 8d's figure, the dense reference layers this kernel "
                                  "implements (every coalition, all 1024 rows): the kernel evaluates each coalition's distinct "
                                  "points only, an exact skip (DESIGN.md 3).  traffic: HBM bytes per launch from rocprofv3 FETCH_SIZE x2 "
