@@ -61,6 +61,7 @@ struct ChainArgs {
     int32_t* argrow;           // (items,1024) point index of the row that attains each column maximum, or null [ARGMAX trunk only]
     int N, R, items, nclouds, with_centre;
     int tail16;                  // last m-tile of an item on 16x16x4 MFMAs when it holds at most 16 rows (l3_tail16)
+    int l3_single;               // bf16x3 layer 3 one n-tile per pass (tuning key 5 = 58: A/B against two per pass)
     unsigned long long* stamps;  // diagnostic build only
 };
 
@@ -252,6 +253,41 @@ __device__ __forceinline__ void l3_pass_bf3(const __amdgpu_buffer_rsrc_t& rs, in
     }
 }
 
+// The same layer with TWO n-tiles per pass (n-tiles (2 qp) 4 + wave and (2 qp + 1) 4 + wave): the A terms of a k-step are read from
+// LDS once for both, half the LDS traffic of l3_pass_bf3 (the kernel is power-bound: operand bytes cost clock).  Every tile sees
+// the same products in the same order, so the maxima are bit-identical to l3_pass_bf3's.  ring.r[2 i + j] = fragment (k-step
+// parity i, n-tile j of the pair), two k-steps (1 536 matrix cycles) ahead, rolling over pair and chunk boundaries.
+template <int MTS>
+__device__ __forceinline__ void l3_pass_bf3_2x2(const __amdgpu_buffer_rsrc_t& rs, int voff, const unsigned char* abase, int wave_s,
+                                                float (&runmax)[8], B3Ring& ring) {
+#pragma unroll 1
+    for (int qp = 0; qp < 4; ++qp) {
+        f32x16 acc[MTS][2];
+#pragma unroll
+        for (int i = 0; i < MTS; ++i) { acc[i][0] = (f32x16){0}; acc[i][1] = (f32x16){0}; }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            bf16x8 af[MTS][3];
+#pragma unroll
+            for (int i = 0; i < MTS; ++i) a3_load<kPlaneB>(af[i], abase + i * 32 * kLdB, s);
+            const B3 b[2] = {ring.r[2 * (s & 1)], ring.r[2 * (s & 1) + 1]};
+            // k-step s + 2 of this pair, or k-step s - 6 of the next one (b3_load takes the n-tile index mod 8)
+            const int qn = s + 2 < 8 ? 2 * qp : 2 * qp + 2, sn = (s + 2) & 7;
+            ring.r[2 * (s & 1)] = b3_load(rs, voff, qn * 8 + sn, wave_s);
+            ring.r[2 * (s & 1) + 1] = b3_load(rs, voff, (qn + 1) * 8 + sn, wave_s);
+            mfma_bf3_block<MTS, 2>(af, b, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float m = max16(acc[0][j]);
+            if (MTS == 2) m = fmaxf(m, max16(acc[MTS - 1][j]));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) runmax[i] = (i == 2 * qp + j) ? fmaxf(runmax[i], m) : runmax[i];
+        }
+    }
+}
+
 // L3 for a LAST m-tile of at most 16 rows (rows row0 .. row0 + 15 of act2): v_mfma_f32_16x16x4_f32 instead of a 32-row tile
 // of which half would be padding (a coalition's row count is uniform mod 32, so this saves a quarter tile per coalition and
 // chain on average: 1.5 % of the kernel).  BIT-IDENTICAL to the 32x32x2 path: that instruction accumulates its two k values
@@ -396,7 +432,8 @@ __global__ __launch_bounds__(kThreads, L3V == 3 ? 2 : 3) void pn_chain_kernel(Ch
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(L3V == 3 ? a.w2_bf3 : nullptr), 0, 0x7fffffff, 0x00020000);
     if (L3V == 3) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ring3.r[i] = b3_load(w3rs, lane * 16, i, wave_s);
+        for (int i = 0; i < 4; ++i)   // l3_pass_bf3: k-steps 0..3 of n-tile 0; l3_pass_bf3_2x2: k-steps 0..1 of n-tiles 0 and 1
+            ring3.r[i] = b3_load(w3rs, lane * 16, ARGMAX || a.l3_single ? i : (i & 1) * 8 + (i >> 1), wave_s);
     }
     unsigned tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? stamp_now() : 0ull;
@@ -532,8 +569,13 @@ __global__ __launch_bounds__(kThreads, L3V == 3 ? 2 : 3) void pn_chain_kernel(Ch
         // ---- L3: 128 -> 1024, running column max -------------------------------------------
         if (L3V == 3) {
             const unsigned char* ab3 = reinterpret_cast<const unsigned char*>(bufA) + frag_lane * kLdB + frag_h * 16;
-            if (mts == 2) l3_pass_bf3<2, ARGMAX>(w3rs, lane * 16, ab3, wave_s, runmax, ring3, runarg, ch * kMC, frag_h);
-            else          l3_pass_bf3<1, ARGMAX>(w3rs, lane * 16, ab3, wave_s, runmax, ring3, runarg, ch * kMC, frag_h);
+            if (ARGMAX || a.l3_single) {
+                if (mts == 2) l3_pass_bf3<2, ARGMAX>(w3rs, lane * 16, ab3, wave_s, runmax, ring3, runarg, ch * kMC, frag_h);
+                else          l3_pass_bf3<1, ARGMAX>(w3rs, lane * 16, ab3, wave_s, runmax, ring3, runarg, ch * kMC, frag_h);
+            } else {
+                if (mts == 2) l3_pass_bf3_2x2<2>(w3rs, lane * 16, ab3, wave_s, runmax, ring3);
+                else          l3_pass_bf3_2x2<1>(w3rs, lane * 16, ab3, wave_s, runmax, ring3);
+            }
         } else if (L3V == 0) {
             if (mts == 2) l3_pass_v0<2>(w3b, a2base, wave_s, runmax);
             else          l3_pass_v0<1>(w3b, a2base, wave_s, runmax);
@@ -915,6 +957,7 @@ extern "C" int iq_pointnet_coalitions_crt(const iq_pointnet_weights* w, const fl
     a.N = N; a.R = R; a.nclouds = nclouds; a.with_centre = with_centre;
     a.stamps = g_stamps;
     a.tail16 = iq::tuning(iq::kTuneExperiment) != 16 && iq::tuning(iq::kTuneExperiment) != 55;   // 16, 55: 32-row tiles only
+    a.l3_single = iq::tuning(iq::kTuneExperiment) == 58;
 
     // 1. input-STN chain, pre-pooled per (cloud, region) [+ centre]
     a.cloud_of = nullptr; a.trans = nullptr;

@@ -413,8 +413,9 @@ def test_chain_tail_tiles_are_bit_identical_for_every_row_count(model):
     points, 400 random coalitions):
     - the fp32-MFMA kernel (tuning key 5 = 54) with its 16-row tail tiles (l3_tail16: v_mfma_f32_16x16x4_f32 fed in the k order
       of the 32x32x2 fragments) against 32-row tiles only (5 = 55): bit-identical logits and packed feature transforms;
-    - the default kernel (layer 3 as six bf16 products per float32 product, float32 accumulation) against the fp32-MFMA one:
-      the same logits to float32 rounding (measured 3e-7 of the largest logit; the two sum k in different orders);
+    - the default kernel (layers 2-3 as six bf16 products per float32 product, float32 accumulation) against the fp32-MFMA one:
+      the same logits to float32 rounding (measured 3e-7 of the largest logit; the two sum k in different orders); two n-tiles
+      per pass (default) against one (5 = 58): bit-identical;
     - and the dense forward (1024 rows) on the materialised clouds of a few coalitions, bitwise against the coalition path."""
     from interpret_quality_amd import _lib
     d = dev()
@@ -444,9 +445,12 @@ def test_chain_tail_tiles_are_bit_identical_for_every_row_count(model):
         f32, tf_f32 = eng.coalition_logits(data, center, rid_t, keep_t, None, num_regions=64, return_trans_feat=True)
         lib.iq_set_tuning(5, 55)
         ref, tf_ref = eng.coalition_logits(data, center, rid_t, keep_t, None, num_regions=64, return_trans_feat=True)
+        lib.iq_set_tuning(5, 58)     # bf16x3 layer 3 one n-tile per pass instead of two: the same products in the same order
+        one, tf_one = eng.coalition_logits(data, center, rid_t, keep_t, None, num_regions=64, return_trans_feat=True)
     finally:
         lib.iq_set_tuning(5, 0)
     assert torch.equal(f32, ref) and torch.equal(tf_f32, tf_ref)
+    assert torch.equal(got, one) and torch.equal(tf, tf_one)
     assert not torch.equal(got, f32)                                  # two different kernels did run
     assert (got - f32).abs().max().item() < 2e-6 * f32.abs().max().item()
     assert (tf - tf_f32).abs().max().item() < 2e-6 * tf_f32.abs().max().item()
