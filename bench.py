@@ -284,6 +284,8 @@ def other_models(dev, lib, regions=32):
                 out[name] = {"value": n / dt, "unit": "coalitions/s", "steps": steps, "workload": workload, "config": spec["config"],
                              "roofline": {"bound": "mfma", "kernel": spec["kernel"], "achieved": achieved, "peak": peak,
                                           "unit": "TFLOP/s", "frac": achieved / peak, "frac_of_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+                                          "frac_of_sustained_bf16_ceiling": (achieved / (peak * SUSTAINED_BF16_MFMA_FRACTION)
+                                                                             if spec.get("bf3") else None),
                                           "traffic": None,
                                           "avg_launch_ms": ms / max(launches, 1), "launches": launches,
                                           "executed_flop_per_launch": work / max(launches, 1),
