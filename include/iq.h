@@ -42,6 +42,11 @@ enum {
 #define IQ_MAX_POINTS 4096
 #define IQ_NUM_FEAT 1024
 
+/* ABI version: 100 * major + minor.  101 (round 4/5): every weight descriptor (iq_dense_layer, iq_pointnet_weights, ...) gained
+ * optional `*_bf3` fields (weights split into three bf16 terms, iq_pack_weight_bf3).  Descriptors MUST be zero-initialised before
+ * they are filled (`iq_dense_layer l = {0};` / memset): a NULL *_bf3 pointer selects the float32-MFMA kernels, a non-NULL one is
+ * dereferenced on the device.  A client built against an older header must be rebuilt (the structs grew). */
+#define IQ_ABI_VERSION 101
 int iq_version(void);
 const char* iq_last_error(void);
 
@@ -425,43 +430,19 @@ int iq_pointconv_coalitions(const iq_pointconv_weights* w, const float* clouds, 
  * structures (padded rows, sorted neighbour lists, pair tables) occupy the first iq_pointconv_tables_bytes(nclouds, N) bytes of
  * `workspace`, whatever B is.  `tables_state` (HOST int, in / out; NULL = build everything, keep nothing): bit 0 = the lists,
  * bit 1 = the pair tables are already there for exactly these clouds, centers, nclouds and N - the caller's promise (same
- * workspace base, bytes untouched since the call that set the bit).  Missing parts are built and their bits set. */
+ * workspace base, bytes untouched since the call that set the bit).  Missing parts are built and their bits set.
+ * Bits 2-3 (in, returned unchanged) name how the K-nearest groups are formed: 0 = decided from THIS launch (the sorted-list walk
+ * when nclouds <= 8 or nclouds * 8 <= B, else a per-coalition kNN), 1 = always the walk, 2 = never.  The two sum a group's members
+ * in a different order (results equal to rounding, not bitwise): a caller that splits ONE batch over several launches and wants
+ * launch-size-independent bits passes 1 or 2 on every launch (interpret_quality_amd/pointconv.py decides from the whole batch). */
 size_t iq_pointconv_tables_bytes(int nclouds, int N);
 int iq_pointconv_coalitions_cached(const iq_pointconv_weights* w, const float* clouds, const float* centers,
                                    const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of, float* logits,
                                    void* workspace, size_t workspace_bytes, int B, int nclouds, int N, int* tables_state,
                                    iq_stream_t stream);
 
-/* Optional HIP-event profiler (bench.py's roofline leg).  While enabled, iq_pointnet_coalitions
- * brackets its chain-kernel launches with hipEvents recorded on the launch stream.
- * iq_profile_read(slot) synchronises on the recorded events of that slot, returns their summed
- * duration and count, and forgets them.  Slots: 0 = input-STN pre-pool chain, 1 = feature-STN
- * chain, 2 = trunk chain, 3 = whole iq_pointnet_coalitions call. */
-int iq_profile_enable(int on);
-/* As iq_profile_read, plus the summed `work` (executed FLOP of the MFMA tiles issued) the library attached to the spans
- * of that slot.  Slot 5 = the dominant kernel of a model's step: PointNet++ pn2_group_kernel<128,128,256> (sa2, third
- * scale), DGCNN / GCNN conv5 + pooling GEMM, PointConv pc_group_kernel<128,128,256> (sa2).  Profiler state and the
- * iq_set_tuning knobs belong to the calling thread (like iq_last_error). */
-int iq_profile_read_work(int slot, double* total_ms, int* launches, double* total_work);
-/* Experiment knob: selects between co-compiled kernel variants so that they can be timed
- * interleaved in ONE process.  key 0 = L3 weight-streaming variant of the chain kernel; 1 = extra dynamic LDS
- * of the chain kernel (occupancy experiment); 2 = 1: no LPT launch order; 3 = 1: dense layers never use the
- * LDS-staged GEMM (pn_gemm_lds_kernel), only the register-streaming one; 4 = kNN diagnostics (results are NOT valid
- * except for 3): 1 queue appends without insertion rounds, 2 no selection at all (MFMA + load skeleton), 3 normal
- * selection + round / busy-lane counters returned in the first 24 bytes of iq_knn's tmp (tools/knn_probe.py);
- * 6 = 16-row member blocks per workgroup of the PointNet++ grouped kernel (0 = default 12). */
-int iq_set_tuning(int key, int value);
-/* Debug: workgroups per CU the runtime admits for the chain kernel variants (100*v0 + v2). */
-int iq_debug_chain_occupancy(void);
-/* Debug: per-phase shader-clock sums of the feature-STN chain (diagnostic STAMP instantiation, never
- * used unless enabled).  enable != 0 arms and zeroes 8 counters; out_host (8 x u64 or NULL) receives
- * the counters accumulated so far. */
-int iq_debug_stamps(int enable, unsigned long long* out_host);
-/* Debug: counters of the kNN kernels while tuning key 4 = 3 (synchronises the device, reads and clears them): [0] selection rounds,
- * [1] busy lanes summed over rounds, [2] waves, [3] queries flagged as near-ties, [4] queries re-ranked (their 21 candidates each),
- * [6] of those, zero-gap queries whose re-ranking covers ALL rows; [5] and [7] are not written (always 0). */
-int iq_debug_knn_counters(unsigned long long* out_host /*8, host*/);
-int iq_profile_read(int slot, double* total_ms, int* launches);
+/* The diagnostic entry points (HIP-event profiler, experiment knobs, debug counters) are NOT part of the drop-in surface:
+ * they are declared in iq_debug.h. */
 
 #ifdef __cplusplus
 }

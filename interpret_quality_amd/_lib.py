@@ -132,10 +132,12 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 101   # IQ_ABI_VERSION of include/iq.h these struct layouts were written for
 
 
 def lib_path():
-    return _build.LIBPATH
+    """The product library; IQ_LIBPATH names another BUILD of the same sources (A/B runs of tools/, e.g. lib_packed_ab/)."""
+    return os.environ.get("IQ_LIBPATH") or _build.LIBPATH
 
 
 def load():
@@ -155,6 +157,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if lib.iq_version() != ABI_VERSION:
+        raise IqError("%s reports ABI version %d, these bindings are written for %d - rebuild it (python -m interpret_quality_amd.build "
+                      "--force)" % (path, lib.iq_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -14,19 +14,22 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libiq_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "iq.h")
+DEBUG_HEADER = os.path.join(os.path.dirname(HERE), "include", "iq_debug.h")
 ARCH = "gfx950"
 # Index-valued kernels (FPS, ball query, region assignment) need individually rounded operations:
 # hipcc's default -ffp-contract=fast fuses a*b+c into fma even through the __f*_rn intrinsics.
 NO_CONTRACT = ("iq_geom.hip", "iq_pointnet2.hip", "iq_dgcnn.hip", "iq_pointconv.hip", "iq_smooth.hip")
-# The smoothness enumeration is built without the SLP vectoriser, i.e. without packed float32 instructions (v_pk_mul_f32,
-# v_pk_add_f32, v_pk_fma_f32).  Measured on MI355X (tools/dbg_smooth_det.py, profiles/r04_shared_gpu_determinism.txt): while a
-# SECOND process ran the PointNet chain kernel with layer 3 on the bf16 matrix pipe on the same GPU, 40 % of the smoothness
-# launches differed from the launch before (first by a few ulp in a few lanes, then amplified by the iteration up to 2e-3);
-# with scalar float32 instructions none did, and no other neighbour (copies, rocBLAS float32, hipBLASLt bf16, DGCNN with the
-# bf16x3 conv5, the chain kernel with layer 3 on the fp32 MFMA) had any effect.  No wave was preempted or moved (HW_ID, step
-# gaps), the kernel uses no scratch and no global memory inside its loop.  One process per GPU - the product's layout - never
-# meets this; the two-ranks-on-one-GPU tests do.
-NO_PACKED_FP32 = ("iq_smooth.hip",)
+# Packed float32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) are switched OFF for the whole library: the
+# gfx950 subtarget feature `packed-fp32-ops` is removed for the device compile, so instruction selection cannot emit them
+# whatever the SLP vectoriser or an explicit float2 expression asks for (tests/test_isa_cpu.py disassembles the .so that ships
+# and asserts it).  Two reasons, both measured (profiles/r05_packed_fp32_*.txt):
+#   1. beside MFMAs they are an anti-lever (MI355X_MICROARCH.md cycle constants: 2 v_pk_add_f32 per MFMA gap +26 cycles against
+#      two scalar adds) and every bf16x3 hot loop carried 48-66 of them from the split residuals;
+#   2. round 4: the smoothness kernel's results moved by a few ulp beside a second process running the bf16x3 chain kernel ONLY
+#      while it held packed float32 instructions (profiles/r04_shared_gpu_determinism.txt, tools/shared_gpu_determinism.py).
+# The host pass of hipcc does not know the feature and says so once per pass; that one line is filtered from the output.
+NO_PACKED_FP32_FLAGS = ("-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops")
+_HOST_NOISE = "'-packed-fp32-ops' is not a recognized feature for this target"
 
 
 def sources():
@@ -34,7 +37,7 @@ def sources():
 
 
 def _deps():
-    return sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER]
+    return sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER, DEBUG_HEADER]
 
 
 def up_to_date():
@@ -44,34 +47,45 @@ def up_to_date():
     return all(os.path.getmtime(p) <= t for p in _deps())
 
 
-def build(force=False, verbose=True, extra_flags=()):
-    if not force and up_to_date():
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    out = "\n".join(l for l in p.stdout.split("\n") if _HOST_NOISE not in l).strip()
+    if out:
+        print(out, flush=True)
+    if p.returncode != 0:
+        raise subprocess.CalledProcessError(p.returncode, cmd)
+
+
+def build(force=False, verbose=True, extra_flags=(), packed_fp32=False, libdir=None):
+    """Compile csrc/*.hip into <libdir>/libiq_hip.so.  packed_fp32=True / another libdir: A/B builds only (tools/r05_pk_ab.sh)."""
+    libdir = libdir or LIBDIR
+    libpath = os.path.join(libdir, "libiq_hip.so")
+    if not force and libdir == LIBDIR and up_to_date():
         return LIBPATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(libdir, exist_ok=True)
     objs = []
     for src in sources():
-        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(libdir, os.path.basename(src)[:-4] + ".o")
         newer = os.path.exists(obj) and all(os.path.getmtime(p) <= os.path.getmtime(obj)
-                                            for p in [src, HEADER] + [d for d in _deps() if d.endswith(".h")])
+                                            for p in [src, HEADER, DEBUG_HEADER] + [d for d in _deps() if d.endswith(".h")])
         if force or not newer:
             cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
                    "-Wall", "-Wno-unused-function"] + list(extra_flags)
             if os.path.basename(src) in NO_CONTRACT:
                 cmd.append("-ffp-contract=off")
-            if os.path.basename(src) in NO_PACKED_FP32:
-                cmd.append("-fno-slp-vectorize")
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            if not packed_fp32:
+                cmd += NO_PACKED_FP32_FLAGS
+            _run(cmd, verbose)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIBPATH] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return LIBPATH
+    _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", libpath] + objs, verbose)
+    return libpath
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIBPATH)
+    if "--packed-ab" in sys.argv:      # the round-4 code generation (packed float32 allowed), beside the product build, for A/B runs
+        print(build(force=True, packed_fp32=True, libdir=os.path.join(HERE, "lib_packed_ab")))
+    else:
+        print(build(force="--force" in sys.argv))

@@ -1,10 +1,11 @@
 // Version, error reporting and the optional HIP-event profiler of the C ABI (include/iq.h).
 #include <vector>
 
+#include "../../include/iq_debug.h"
 #include "iq_common.h"
 #include "iq_profile.h"
 
-extern "C" int iq_version(void) { return 100; }  // 0.1.0
+extern "C" int iq_version(void) { return IQ_ABI_VERSION; }
 
 extern "C" const char* iq_last_error(void) { return iq::err_buf(); }
 

@@ -230,6 +230,7 @@ struct PcGroupArgs {
     float* out;                // (B,S,C3*16): [c][w]
     int N, S, K;    int B, wgs_per_cloud, chunks_per_wg;
     const int32_t* n_unique;   // (B) or null: groups s >= n_unique[b] are copies of group 0 and are not computed
+    int prio;                  // pc_group_bf3_kernel: issue priority by phase (tuning key 7; see pn2_group_bf3_kernel)
 };
 
 // One workgroup = `chunks_per_wg` consecutive 64-member chunks of one cloud (K = 32: two groups per chunk, K = 64: one).
@@ -471,6 +472,12 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_bf3_kernel(PcGroupArgs a
     const size_t member0 = (size_t)b * a.S * K;
     const float* swlane = swT + (lane & 15) * LDS_SW + ((lane >> 4) & 1) + 4 * (lane >> 5);
 
+    const int pm = a.prio;                   // issue priority by phase, as pn2_group_bf3_kernel (iq_pointnet2.hip)
+    auto prio_mfma = [&](bool enter) {
+        if (pm == 1) { if (enter) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        else if (pm == 2) { if (enter) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+    };
+    if (pm == 2) __builtin_amdgcn_s_setprio(1);
     const int c4 = tid % Q1, rsub = tid / Q1;
     f32x4 w1[4];
 #pragma unroll
@@ -521,7 +528,9 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_bf3_kernel(PcGroupArgs a
         __syncthreads();  // act1 complete
         // ---- layer 2: tiles (m-tile 0..1, n-tile = wave) kept in registers ---------------------------------------------------
         f32x16 acc2[2][1] = {{{0}}, {{0}}};
+        prio_mfma(true);
         pcb_layer2<2>(abase, w2rs, voff, wave_s, ring2, acc2);
+        prio_mfma(false);
         PcB3x2 ring3[2];                             // layer 3's weights (n-tiles wave, wave + 4), in flight across the epilogue
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -539,7 +548,9 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_bf3_kernel(PcGroupArgs a
         if (ch + 1 < nchunks) gather_u(nxt);                                // consumed after layer 3
         // ---- layer 3 (2 x 2 tiles per wave) + contraction over the members (fp32 MFMA, as pc_group_kernel) -------------------
         f32x16 acc3[2][2] = {{{0}, {0}}, {{0}, {0}}};
+        prio_mfma(true);
         pcb_layer3(abase, w3rs, voff, wave_s, ring3, acc3);
+        prio_mfma(false);
         const float* swc = swlane + cur * 16 * LDS_SW;
         const int g_first = (ch0 + ch) * (kMC / K);
 #pragma unroll
@@ -1085,6 +1096,7 @@ int launch_pc_group(const iq_pointconv_sa& sa, const float* xyz, const float* ne
     a.w2 = sa.l2.w; a.b2 = sa.l2.b; a.w3 = sa.l3.w; a.b3 = sa.l3.b;
     a.w2_bf3 = reinterpret_cast<const unsigned short*>(l2_bf3); a.w3_bf3 = reinterpret_cast<const unsigned short*>(l3_bf3);
     a.out = out; a.N = N; a.S = S; a.K = K; a.B = B; a.n_unique = n_unique;
+    a.prio = iq::tuning(iq::kTunePrio);
     a.chunks_per_wg = 4;                                   // 256 members per workgroup: the prologue is amortised, the tail stays even
     const int chunks = S * K / kMC;
     a.wgs_per_cloud = (chunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
@@ -1354,7 +1366,8 @@ extern "C" int iq_pointconv_coalitions_cached(const iq_pointconv_weights* w, con
         return iq::fail(IQ_EWORKSPACE, "iq_pointconv_coalitions: workspace %zu < %zu bytes", workspace_bytes, need);
     WsC s = carve_c(reinterpret_cast<char*>(workspace) + cloud_bytes, B, N);
     carve_w_rest(t, reinterpret_cast<char*>(workspace) + cloud_bytes + base_bytes, B, nclouds, N);
-    int have = tables_state ? *tables_state : 0;          // bit 0: sorted lists, bit 1: pair tables (see above)
+    int have = tables_state ? (*tables_state & 3) : 0;    // bit 0: sorted lists, bit 1: pair tables (see above)
+    const int force = tables_state ? ((*tables_state >> 2) & 3) : 0;
     hipStream_t st = iq::as_stream(stream);
     int rc;
     iq::ProfileSpan call_span(iq::kSlotCall, st);
@@ -1365,7 +1378,9 @@ extern "C" int iq_pointconv_coalitions_cached(const iq_pointconv_weights* w, con
     if ((rc = iq::check_launch("pc_mask_kernel"))) return rc;
     // the lists for up to 8 source clouds whatever B is: the two ways of forming a group differ in the order of the sum over its
     // members, and a coalition's logits must not depend on how many others share its launch (5 = 14: pc_knn_kernel)
-    const bool use_walk = (nclouds <= 8 || (long long)nclouds * 8 <= B) && iq::tuning(iq::kTuneExperiment) != 14;
+    // tables_state bits 2-3 (in): 1 = always the list walk, 2 = never - a caller that splits one batch over several launches names
+    // the path once, so that every launch (a short tail included) forms its groups the same way; 0 = decide from this launch
+    const bool use_walk = (force == 1 || (force == 0 && (nclouds <= 8 || (long long)nclouds * 8 <= B))) && iq::tuning(iq::kTuneExperiment) != 14;
     PcWalk walk{};
     if (use_walk) {
         if (!(have & 1)) {
@@ -1393,6 +1408,6 @@ extern "C" int iq_pointconv_coalitions_cached(const iq_pointconv_weights* w, con
             walk.feat_tab = t.feat;
         }
     }
-    if (tables_state) *tables_state = have;
+    if (tables_state) *tables_state = have | (force << 2);
     return run_pointconv(w, t.X, logits, s, B, N, st, use_walk ? &walk : nullptr);
 }

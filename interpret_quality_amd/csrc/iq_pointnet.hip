@@ -62,6 +62,7 @@ struct ChainArgs {
     int N, R, items, nclouds, with_centre;
     int tail16;                  // last m-tile of an item on 16x16x4 MFMAs when it holds at most 16 rows (l3_tail16)
     int l3_single;               // bf16x3 layer 3 one n-tile per pass (tuning key 5 = 58: A/B against two per pass)
+    int prio;                    // issue priority 1 inside the bf16x3 MFMA loops of layers 2-3 (tuning key 7; iq_pointnet2.hip)
     unsigned long long* stamps;  // diagnostic build only
 };
 
@@ -569,6 +570,7 @@ __global__ __launch_bounds__(kThreads, L3V == 3 ? 2 : 3) void pn_chain_kernel(Ch
         // ---- L3: 128 -> 1024, running column max -------------------------------------------
         if (L3V == 3) {
             const unsigned char* ab3 = reinterpret_cast<const unsigned char*>(bufA) + frag_lane * kLdB + frag_h * 16;
+            if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
             if (ARGMAX || a.l3_single) {
                 if (mts == 2) l3_pass_bf3<2, ARGMAX>(w3rs, lane * 16, ab3, wave_s, runmax, ring3, runarg, ch * kMC, frag_h);
                 else          l3_pass_bf3<1, ARGMAX>(w3rs, lane * 16, ab3, wave_s, runmax, ring3, runarg, ch * kMC, frag_h);
@@ -576,6 +578,7 @@ __global__ __launch_bounds__(kThreads, L3V == 3 ? 2 : 3) void pn_chain_kernel(Ch
                 if (mts == 2) l3_pass_bf3_2x2<2>(w3rs, lane * 16, ab3, wave_s, runmax, ring3);
                 else          l3_pass_bf3_2x2<1>(w3rs, lane * 16, ab3, wave_s, runmax, ring3);
             }
+            if (a.prio == 1) __builtin_amdgcn_s_setprio(0);
         } else if (L3V == 0) {
             if (mts == 2) l3_pass_v0<2>(w3b, a2base, wave_s, runmax);
             else          l3_pass_v0<1>(w3b, a2base, wave_s, runmax);
@@ -958,6 +961,7 @@ extern "C" int iq_pointnet_coalitions_crt(const iq_pointnet_weights* w, const fl
     a.stamps = g_stamps;
     a.tail16 = iq::tuning(iq::kTuneExperiment) != 16 && iq::tuning(iq::kTuneExperiment) != 55;   // 16, 55: 32-row tiles only
     a.l3_single = iq::tuning(iq::kTuneExperiment) == 58;
+    a.prio = iq::tuning(iq::kTunePrio);
 
     // 1. input-STN chain, pre-pooled per (cloud, region) [+ centre]
     a.cloud_of = nullptr; a.trans = nullptr;

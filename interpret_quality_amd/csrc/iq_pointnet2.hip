@@ -177,6 +177,7 @@ struct GroupArgs {
     int N, S, K, blocks_per_wg;
     int B, wgs_per_cloud;
     int probe;               // tuning key 5 (79: per-phase cycle counts of pn2_group_bf3_kernel)
+    int prio;                // issue priority by phase in pn2_group_bf3_kernel (see there); tuning key 7, default 1
 };
 
 __device__ __forceinline__ void merge_max(float* addr, float v) {
@@ -501,6 +502,17 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
         }
     };
 
+    // Issue priority by phase (MI355X_MICROARCH.md, two waves per SIMD, item 2): the two workgroups of a CU put two waves on each
+    // SIMD, arbitrated by priority then AGE - an older wave in a VALU phase (stage 0b, the split epilogue: hundreds of independent
+    // instructions) keeps the issue port and the younger wave's MFMAs wait.  Priority 1 while a wave is in an MFMA loop lets its
+    // one MFMA per 32 cycles through and leaves the other 24 cycles to the partner's VALU work.  a.prio: 0 off, 1 MFMA phases
+    // high, 2 VALU phases high (the opposite, A/B only).
+    const int pm = a.prio;
+    auto prio_mfma = [&](bool enter) {
+        if (pm == 1) { if (enter) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        else if (pm == 2) { if (enter) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+    };
+    if (pm == 2) __builtin_amdgcn_s_setprio(1);
     constexpr int Q1 = C1 / 4, NR = kMC * Q1 / kThreads;   // stage 0b: a thread owns 4 consecutive channels of NR rows
     const int c4 = tid % Q1, rsub = tid / Q1;
     f32x4 w1[4];
@@ -589,6 +601,7 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
         stamp(2);   // wait
         // ---- layer 2: 128 -> 128, tiles (m-tile 0..1, n-tile = wave) kept in registers -------------------
         f32x16 acc2[2][1] = {{{0}}, {{0}}};
+        prio_mfma(true);
         if (mts == 2) {
             gb_layer2<2>(abase, w2rs, voff, wave_s, ring2, acc2);
         } else {
@@ -596,6 +609,7 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
             gb_layer2<1>(abase, w2rs, voff, wave_s, ring2, one);
             acc2[0][0] = one[0][0];
         }
+        prio_mfma(false);
         B3x2 ring3[2];                               // layer 3's weights (n-tiles wave, wave + 4), in flight across the epilogue
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -620,7 +634,9 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
         // ---- layer 3: 128 -> 256, 2 x 2 tiles per wave, block maxima merged into the owning groups -------
         if (mts == 2) {
             f32x16 acc3[2][2] = {{{0}, {0}}, {{0}, {0}}};
+            prio_mfma(true);
             gb_layer3<2>(abase, w3rs, voff, wave_s, ring3, acc3);
+            prio_mfma(false);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const float bias = a.b3[(q * 4 + wave) * 32 + fl];
@@ -633,7 +649,9 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
             }
         } else {
             f32x16 acc3[1][2] = {{{0}, {0}}};
+            prio_mfma(true);
             gb_layer3<1>(abase, w3rs, voff, wave_s, ring3, acc3);
+            prio_mfma(false);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const float bias = a.b3[(q * 4 + wave) * 32 + fl];
@@ -731,6 +749,7 @@ int launch_group(const iq_pn2_scale& sc, GroupArgs a, const int32_t* n_unique, i
                  const void* l2_bf3 = nullptr, const void* l3_bf3 = nullptr) {
     a.w1x = sc.w1x;
     a.probe = iq::tuning(iq::kTuneExperiment);
+    a.prio = iq::tuning(iq::kTunePrio);
     a.w2_bf3 = reinterpret_cast<const unsigned short*>(l2_bf3);
     a.w3_bf3 = reinterpret_cast<const unsigned short*>(l3_bf3);
     a.w2 = sc.l2.w; a.b2 = sc.l2.b;

@@ -38,10 +38,46 @@ def ensure_rendezvous():
         os.environ["MASTER_PORT"] = str(free_port())
 
 
-def visible_gpus():
-    """Devices this process could use, WITHOUT initialising the runtime (device_count() reads sysfs on this image)."""
-    import torch
-    return torch.cuda.device_count()
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
+_VISIBLE_ENV = ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")
+
+
+def kfd_gpus(nodes_dir=KFD_NODES, dri_dir="/dev/dri"):
+    """GPUs the kernel driver shows to THIS process, from the KFD topology in sysfs - no HIP runtime, no torch: the nodes with
+    SIMDs (CPU nodes have simd_count 0) whose render node this process may open (a container is handed its GPUs as
+    /dev/dri/renderD<minor> devices; sysfs itself is not filtered).  None when there is no KFD tree to read."""
+    try:
+        names = sorted(os.listdir(nodes_dir), key=lambda n: (len(n), n))
+    except OSError:
+        return None
+    count = 0
+    for n in names:
+        try:
+            props = dict(l.split(None, 1) for l in open(os.path.join(nodes_dir, n, "properties")).read().splitlines() if " " in l)
+        except OSError:
+            continue                                  # a node of another container: not ours
+        if int(props.get("simd_count", "0")) <= 0:
+            continue
+        minor = int(props.get("drm_render_minor", "-1"))
+        dev = os.path.join(dri_dir, "renderD%d" % minor)
+        if minor < 0 or not os.path.exists(dev) or os.access(dev, os.R_OK | os.W_OK):
+            count += 1                                # no render-node bookkeeping (or no /dev/dri view): count the node itself
+    return count
+
+
+def visible_gpus(nodes_dir=KFD_NODES, dri_dir="/dev/dri"):
+    """Devices a rank of this job could use, WITHOUT initialising any GPU runtime in the parent: the KFD topology (kfd_gpus),
+    cut down by the *_VISIBLE_DEVICES lists the ranks will inherit.  Only where there is no KFD tree at all does it fall back to
+    torch.cuda.device_count() (which does not create a HIP context on this image)."""
+    n = kfd_gpus(nodes_dir, dri_dir)
+    if n is None:
+        import torch
+        return torch.cuda.device_count()
+    for var in _VISIBLE_ENV:
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def self_launch(script, argv, nproc, grace_s=30.0, poll_s=0.2):

@@ -106,9 +106,10 @@ class PointConvEngine:
         _lib.check(rc, "iq_pointconv_forward")
         return logits
 
-    def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None):
+    def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None, walk=None):
         """iq_pointconv_coalitions: clouds (nc,N,3), centers (nc,3), region_id (nc,N) i32, keep (B,) i64 bit masks,
-        cloud_of (B,) i32 or None -> logits (B,C)."""
+        cloud_of (B,) i32 or None -> logits (B,C).  walk: True / False names how groups are formed (sorted-list walk or a kNN per
+        coalition) for a batch that is split over several launches; None lets the library decide from this launch alone."""
         for t, dt, nm in ((clouds, torch.float32, "clouds"), (centers, torch.float32, "centers"), (region_id, torch.int32, "region_id"),
                           (keep, torch.int64, "keep"), (cloud_of, torch.int32, "cloud_of")):
             if t is None and nm == "cloud_of":
@@ -120,12 +121,12 @@ class PointConvEngine:
         workspace.ensure(self, self.lib.iq_pointconv_coalitions_workspace_bytes(b, nc, n))
         logits = torch.empty((b, self.weights.num_classes), dtype=torch.float32, device=self.device)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
-        state = ctypes.c_int(self._tables_state(clouds, centers, nc, n))
+        state = ctypes.c_int(self._tables_state(clouds, centers, nc, n) | (0 if walk is None else (4 if walk else 8)))
         rc = self.lib.iq_pointconv_coalitions_cached(ctypes.byref(self.weights.struct), p(clouds), p(centers), p(region_id), p(keep),
                                                      p(cloud_of), p(logits), p(self._ws), self._ws.numel(), b, nc, n,
                                                      ctypes.byref(state), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "iq_pointconv_coalitions")
-        self._tab["state"] = state.value
+        self._tab["state"] = state.value & 3
         return logits
 
     def _tables_state(self, clouds, centers, nc, n):
@@ -137,7 +138,13 @@ class PointConvEngine:
         (the chunks of an interaction ratio, the batches of a pose) pass the same tensors and re-use the tables; round 3 rebuilt
         ~1 GB per source cloud on every launch.  (Writing into a held tensor behind torch's back - a raw pointer - is not seen.)"""
         t = self._tab
-        key = (self._ws.data_ptr(), nc, n, clouds.data_ptr(), clouds._version, centers.data_ptr(), centers._version)
+        try:
+            versions = (clouds._version, centers._version)
+        except RuntimeError:        # inference tensors carry no version counter: nothing to tell a rewrite by, so rebuild
+            self._tab = {}
+            return 0
+        # the stream is part of the key: tables another stream is still building must not be read from this one
+        key = (self._ws.data_ptr(), nc, n, clouds.data_ptr(), centers.data_ptr(), versions, torch.cuda.current_stream().cuda_stream)
         if t.get("key") == key and t.get("state", 0) and t["clouds"] is clouds and t["centers"] is centers:
             return int(t["state"])
         self._tab = {"key": key, "clouds": clouds, "centers": centers, "state": 0}
@@ -235,14 +242,17 @@ class PointConvDensityClsSsg(nn.Module):
             return out
         own = [cloud_of]
         n = clouds.shape[1]
+        # how groups are formed is decided ONCE, from the whole batch (the library's own rule, iq.h): a memory-tight run that splits
+        # the batch - or its short last launch - must not switch to the other summation order
+        walk = nc <= 8 or nc * 8 <= b
 
         def call(lo, hi):
             if (lo, hi) == (0, b):
-                return eng.coalition_logits(clouds, centers, region_id, keep, cloud_of)
+                return eng.coalition_logits(clouds, centers, region_id, keep, cloud_of, walk)
             if own[0] is None and nc == b:     # one cloud per coalition, split over launches: name each launch's clouds
                 own[0] = torch.arange(b, dtype=torch.int32, device=keep.device)
             return eng.coalition_logits(clouds, centers, region_id, keep[lo:hi].contiguous(),
-                                        own[0][lo:hi].contiguous() if own[0] is not None else None)
+                                        own[0][lo:hi].contiguous() if own[0] is not None else None, walk)
         # the launch size comes from the memory that is free now (workspace.py), at most max_clouds_per_call
         return workspace.run_in_steps(eng, b, self.max_clouds_per_call,
                                       lambda k: eng.lib.iq_pointconv_coalitions_workspace_bytes(k, nc, n), call)

@@ -18,14 +18,22 @@ def lib():
 
 
 def test_header_symbols_exported_and_bound(lib):
-    header = open(os.path.join(REPO, "include", "iq.h")).read()
-    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)  # drop comments
-    declared = set(re.findall(r"\b(iq_[a-z0-9_]+)\s*\(", header))
-    assert declared, "no declarations parsed"
-    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    for name in declared:
+    declared = {}
+    for h in ("iq.h", "iq_debug.h"):      # the drop-in surface | diagnostics (profiler, experiment knobs, debug counters)
+        header = open(os.path.join(REPO, "include", h)).read()
+        header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)  # drop comments
+        declared[h] = set(re.findall(r"\b(iq_[a-z0-9_]+)\s*\(", header))
+        assert declared[h], "no declarations parsed in %s" % h
+    both = declared["iq.h"] | declared["iq_debug.h"]
+    assert not (declared["iq.h"] & declared["iq_debug.h"])
+    assert both == set(_lib.SIGNATURES), (both ^ set(_lib.SIGNATURES))
+    for name in both:
         assert hasattr(lib, name), name
-    assert lib.iq_version() >= 100
+    # nothing diagnostic is left on the drop-in surface
+    assert not [n for n in declared["iq.h"] if n.startswith(("iq_debug_", "iq_profile_", "iq_set_tuning"))]
+    assert declared["iq_debug.h"] == {n for n in _lib.SIGNATURES if n.startswith(("iq_debug_", "iq_profile_", "iq_set_tuning"))}
+    m = re.search(r"#define IQ_ABI_VERSION (\d+)", open(os.path.join(REPO, "include", "iq.h")).read())
+    assert lib.iq_version() == int(m.group(1)) >= 101
 
 
 def test_pack_weight_layout(lib):
