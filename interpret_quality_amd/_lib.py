@@ -129,6 +129,7 @@ SIGNATURES = {
     "iq_debug_knn_counters": (_I, [ctypes.POINTER(ctypes.c_ulonglong)]),
     "iq_profile_read_work": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
     "iq_profile_read": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+    "iq_debug_mfma_sustained": (_I, [ctypes.c_double, _P, _SZ, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _P]),
 }
 
 _lib = None

@@ -25,8 +25,10 @@ NO_CONTRACT = ("iq_geom.hip", "iq_pointnet2.hip", "iq_dgcnn.hip", "iq_pointconv.
 # and asserts it).  Two reasons, both measured (profiles/r05_packed_fp32_*.txt):
 #   1. beside MFMAs they are an anti-lever (MI355X_MICROARCH.md cycle constants: 2 v_pk_add_f32 per MFMA gap +26 cycles against
 #      two scalar adds) and every bf16x3 hot loop carried 48-66 of them from the split residuals;
-#   2. round 4: the smoothness kernel's results moved by a few ulp beside a second process running the bf16x3 chain kernel ONLY
-#      while it held packed float32 instructions (profiles/r04_shared_gpu_determinism.txt, tools/shared_gpu_determinism.py).
+#   2. rounds 4-5: `v_pk_mul_f32` / `v_pk_add_f32` with `op_sel:[0,1]` (the low result taking the high dword of src1 - the form the
+#      vectoriser uses to broadcast one float of a pair) return a wrong low result in lanes 48-63 while ANOTHER process runs a
+#      bf16-MFMA-dense kernel on the same GPU: a register-only loop shows it in every launch (tools/micro/pk_victim.hip variant 3,
+#      profiles/r05_packed_fp32_victim.txt).  Round 4's smoothness kernel held five such instructions, DGCNN's kNN kernel one.
 # The host pass of hipcc does not know the feature and says so once per pass; that one line is filtered from the output.
 NO_PACKED_FP32_FLAGS = ("-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops")
 _HOST_NOISE = "'-packed-fp32-ops' is not a recognized feature for this target"

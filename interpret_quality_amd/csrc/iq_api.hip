@@ -1,4 +1,5 @@
 // Version, error reporting and the optional HIP-event profiler of the C ABI (include/iq.h).
+#include <algorithm>
 #include <vector>
 
 #include "../../include/iq_debug.h"
@@ -80,4 +81,85 @@ extern "C" int iq_profile_read_work(int which, double* total_ms, int* launches, 
 
 extern "C" int iq_profile_read(int which, double* total_ms, int* launches) {
     return iq_profile_read_work(which, total_ms, launches, nullptr);
+}
+
+// ---- diagnostic: what the bf16 matrix pipe SUSTAINS on this board, now ------------------------------------------------------
+// A register-only loop of v_mfma_f32_32x32x16_bf16 (four independent accumulators per wave, operands with random mantissas and
+// signs so that the datapath toggles), two waves per SIMD on every CU, for about `seconds`.  MFMA-dense kernels on MI355X are
+// bounded by the power cap, not by issue slots (MI355X_MICROARCH.md, DVFS give-back): the clock the governor holds differs from
+// board to board, so bench.py measures this ceiling on the board it runs on instead of quoting a constant.
+namespace {
+typedef float dbg_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 dbg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned dbg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ unsigned long long g_sustained_clk;
+
+__device__ inline dbg_bf16x8 dbg_operand(unsigned seed) {   // eight bf16 in [1, 2) with random mantissas, random signs
+    dbg_u32x4 v;
+    for (int i = 0; i < 4; ++i) {
+        seed = seed * 1664525u + 1013904223u;
+        const unsigned lo = 0x3f80u | ((seed >> 9) & 0x7fu) | ((seed >> 3) & 0x8000u);
+        seed = seed * 1664525u + 1013904223u;
+        const unsigned hi = 0x3f80u | ((seed >> 9) & 0x7fu) | ((seed >> 3) & 0x8000u);
+        v[i] = lo | (hi << 16);
+    }
+    return __builtin_bit_cast(dbg_bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void mfma_sustained_kernel(float* out, int iters, int seed0) {
+    const dbg_bf16x8 a0 = dbg_operand(seed0 + threadIdx.x * 7 + blockIdx.x), a1 = dbg_operand(seed0 * 3 + threadIdx.x * 11 + blockIdx.x);
+    const dbg_bf16x8 b0 = dbg_operand(seed0 * 5 + threadIdx.x * 13), b1 = dbg_operand(seed0 * 9 + threadIdx.x * 17);
+    unsigned long long t0 = 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    dbg_f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c3, 0, 0, 0);
+        }
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+        g_sustained_clk = t1 - t0;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[5] + c2[9] + c3[15];
+}
+}  // namespace
+
+extern "C" int iq_debug_mfma_sustained(double seconds, float* scratch, size_t scratch_floats, double* tflops, double* clock_ghz,
+                                       iq_stream_t stream) {
+    IQ_REQUIRE(scratch && tflops && seconds > 0.0 && seconds <= 10.0, "iq_debug_mfma_sustained: seconds in (0, 10], scratch required");
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return iq::fail(IQ_ELAUNCH, "iq_debug_mfma_sustained: device query failed");
+    const int grid = 2 * cus;                                    // 4 waves per workgroup, 2 workgroups per CU: two waves per SIMD
+    IQ_REQUIRE(scratch_floats >= (size_t)grid * 256, "iq_debug_mfma_sustained: scratch holds %zu floats, %zu needed", scratch_floats,
+               (size_t)grid * 256);
+    hipStream_t st = iq::as_stream(stream);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return iq::fail(IQ_ELAUNCH, "hipEventCreate failed");
+    int iters = 20000;
+    float ms = 0.f;
+    int rc = IQ_OK;
+    for (int pass = 0; pass < 2 && rc == IQ_OK; ++pass) {        // pass 0 calibrates the iteration count for ~`seconds`
+        (void)hipEventRecord(e0, st);
+        hipLaunchKernelGGL(mfma_sustained_kernel, dim3(grid), dim3(256), 0, st, scratch, iters, 12345 + pass);
+        (void)hipEventRecord(e1, st);
+        if ((rc = iq::check_launch("mfma_sustained_kernel"))) break;
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = iq::fail(IQ_ELAUNCH, "event timing failed");
+        if (pass == 0) iters = (int)std::min(2.0e9, std::max(1000.0, iters * seconds * 1e3 / std::max(ms, 1e-3f)));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != IQ_OK) return rc;
+    unsigned long long clk = 0;
+    if (hipMemcpyFromSymbol(&clk, HIP_SYMBOL(g_sustained_clk), sizeof(clk)) != hipSuccess) return iq::fail(IQ_ELAUNCH, "hipMemcpyFromSymbol failed");
+    const double mfma = (double)grid * 4.0 * (double)iters * 16.0;
+    *tflops = mfma * (2.0 * 32 * 32 * 16) / (ms * 1e-3) / 1e12;
+    if (clock_ghz) *clock_ghz = (double)clk / (ms * 1e-3) / 1e9;
+    return IQ_OK;
 }

@@ -230,7 +230,6 @@ struct PcGroupArgs {
     float* out;                // (B,S,C3*16): [c][w]
     int N, S, K;    int B, wgs_per_cloud, chunks_per_wg;
     const int32_t* n_unique;   // (B) or null: groups s >= n_unique[b] are copies of group 0 and are not computed
-    int prio;                  // pc_group_bf3_kernel: issue priority by phase (tuning key 7; see pn2_group_bf3_kernel)
 };
 
 // One workgroup = `chunks_per_wg` consecutive 64-member chunks of one cloud (K = 32: two groups per chunk, K = 64: one).
@@ -472,12 +471,6 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_bf3_kernel(PcGroupArgs a
     const size_t member0 = (size_t)b * a.S * K;
     const float* swlane = swT + (lane & 15) * LDS_SW + ((lane >> 4) & 1) + 4 * (lane >> 5);
 
-    const int pm = a.prio;                   // issue priority by phase, as pn2_group_bf3_kernel (iq_pointnet2.hip)
-    auto prio_mfma = [&](bool enter) {
-        if (pm == 1) { if (enter) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-        else if (pm == 2) { if (enter) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
-    };
-    if (pm == 2) __builtin_amdgcn_s_setprio(1);
     const int c4 = tid % Q1, rsub = tid / Q1;
     f32x4 w1[4];
 #pragma unroll
@@ -528,9 +521,7 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_bf3_kernel(PcGroupArgs a
         __syncthreads();  // act1 complete
         // ---- layer 2: tiles (m-tile 0..1, n-tile = wave) kept in registers ---------------------------------------------------
         f32x16 acc2[2][1] = {{{0}}, {{0}}};
-        prio_mfma(true);
         pcb_layer2<2>(abase, w2rs, voff, wave_s, ring2, acc2);
-        prio_mfma(false);
         PcB3x2 ring3[2];                             // layer 3's weights (n-tiles wave, wave + 4), in flight across the epilogue
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -548,9 +539,7 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_bf3_kernel(PcGroupArgs a
         if (ch + 1 < nchunks) gather_u(nxt);                                // consumed after layer 3
         // ---- layer 3 (2 x 2 tiles per wave) + contraction over the members (fp32 MFMA, as pc_group_kernel) -------------------
         f32x16 acc3[2][2] = {{{0}, {0}}, {{0}, {0}}};
-        prio_mfma(true);
         pcb_layer3(abase, w3rs, voff, wave_s, ring3, acc3);
-        prio_mfma(false);
         const float* swc = swlane + cur * 16 * LDS_SW;
         const int g_first = (ch0 + ch) * (kMC / K);
 #pragma unroll
@@ -1096,7 +1085,6 @@ int launch_pc_group(const iq_pointconv_sa& sa, const float* xyz, const float* ne
     a.w2 = sa.l2.w; a.b2 = sa.l2.b; a.w3 = sa.l3.w; a.b3 = sa.l3.b;
     a.w2_bf3 = reinterpret_cast<const unsigned short*>(l2_bf3); a.w3_bf3 = reinterpret_cast<const unsigned short*>(l3_bf3);
     a.out = out; a.N = N; a.S = S; a.K = K; a.B = B; a.n_unique = n_unique;
-    a.prio = iq::tuning(iq::kTunePrio);
     a.chunks_per_wg = 4;                                   // 256 members per workgroup: the prologue is amortised, the tail stays even
     const int chunks = S * K / kMC;
     a.wgs_per_cloud = (chunks + a.chunks_per_wg - 1) / a.chunks_per_wg;

@@ -62,7 +62,6 @@ struct ChainArgs {
     int N, R, items, nclouds, with_centre;
     int tail16;                  // last m-tile of an item on 16x16x4 MFMAs when it holds at most 16 rows (l3_tail16)
     int l3_single;               // bf16x3 layer 3 one n-tile per pass (tuning key 5 = 58: A/B against two per pass)
-    int prio;                    // issue priority 1 inside the bf16x3 MFMA loops of layers 2-3 (tuning key 7; iq_pointnet2.hip)
     unsigned long long* stamps;  // diagnostic build only
 };
 
@@ -258,7 +257,9 @@ __device__ __forceinline__ void l3_pass_bf3(const __amdgpu_buffer_rsrc_t& rs, in
 // LDS once for both, half the LDS traffic of l3_pass_bf3 (the kernel is power-bound: operand bytes cost clock).  Every tile sees
 // the same products in the same order, so the maxima are bit-identical to l3_pass_bf3's.  ring.r[2 i + j] = fragment (k-step
 // parity i, n-tile j of the pair), two k-steps (1 536 matrix cycles) ahead, rolling over pair and chunk boundaries.
-template <int MTS>
+// PROBE (diagnostic instantiations, tuning key 5 = 91 / 92 / 93, results WRONG, timing only): bit 0 = the weight fragments are
+// never refilled (no L2 / L1 traffic in the loop), bit 1 = the A terms are read from LDS for the first k-step of a pass only.
+template <int MTS, int PROBE = 0>
 __device__ __forceinline__ void l3_pass_bf3_2x2(const __amdgpu_buffer_rsrc_t& rs, int voff, const unsigned char* abase, int wave_s,
                                                 float (&runmax)[8], B3Ring& ring) {
 #pragma unroll 1
@@ -266,16 +267,20 @@ __device__ __forceinline__ void l3_pass_bf3_2x2(const __amdgpu_buffer_rsrc_t& rs
         f32x16 acc[MTS][2];
 #pragma unroll
         for (int i = 0; i < MTS; ++i) { acc[i][0] = (f32x16){0}; acc[i][1] = (f32x16){0}; }
+        bf16x8 af[MTS][3];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            bf16x8 af[MTS][3];
+            if (!(PROBE & 2) || s == 0) {
 #pragma unroll
-            for (int i = 0; i < MTS; ++i) a3_load<kPlaneB>(af[i], abase + i * 32 * kLdB, s);
+                for (int i = 0; i < MTS; ++i) a3_load<kPlaneB>(af[i], abase + i * 32 * kLdB, s);
+            }
             const B3 b[2] = {ring.r[2 * (s & 1)], ring.r[2 * (s & 1) + 1]};
             // k-step s + 2 of this pair, or k-step s - 6 of the next one (b3_load takes the n-tile index mod 8)
             const int qn = s + 2 < 8 ? 2 * qp : 2 * qp + 2, sn = (s + 2) & 7;
-            ring.r[2 * (s & 1)] = b3_load(rs, voff, qn * 8 + sn, wave_s);
-            ring.r[2 * (s & 1) + 1] = b3_load(rs, voff, (qn + 1) * 8 + sn, wave_s);
+            if (!(PROBE & 1)) {
+                ring.r[2 * (s & 1)] = b3_load(rs, voff, qn * 8 + sn, wave_s);
+                ring.r[2 * (s & 1) + 1] = b3_load(rs, voff, (qn + 1) * 8 + sn, wave_s);
+            }
             mfma_bf3_block<MTS, 2>(af, b, acc);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -362,7 +367,7 @@ __device__ __forceinline__ unsigned long long stamp_now() {
         }                                                           \
     } while (0)
 
-template <int MODE, int L3V, bool STAMP = false, bool ARGMAX = false>
+template <int MODE, int L3V, bool STAMP = false, bool ARGMAX = false, int PROBE = 0>
 __global__ __launch_bounds__(kThreads, L3V == 3 ? 2 : 3) void pn_chain_kernel(ChainArgs a) {
     // act0 (ld 68) then act2: float image (ld 132), or - L3V = 3 - three bf16 planes of 272-byte rows
     __shared__ __attribute__((aligned(16))) float bufA[L3V == 3 ? 3 * kPlaneB / 4 : kMC * kLd2];
@@ -570,15 +575,13 @@ __global__ __launch_bounds__(kThreads, L3V == 3 ? 2 : 3) void pn_chain_kernel(Ch
         // ---- L3: 128 -> 1024, running column max -------------------------------------------
         if (L3V == 3) {
             const unsigned char* ab3 = reinterpret_cast<const unsigned char*>(bufA) + frag_lane * kLdB + frag_h * 16;
-            if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
             if (ARGMAX || a.l3_single) {
                 if (mts == 2) l3_pass_bf3<2, ARGMAX>(w3rs, lane * 16, ab3, wave_s, runmax, ring3, runarg, ch * kMC, frag_h);
                 else          l3_pass_bf3<1, ARGMAX>(w3rs, lane * 16, ab3, wave_s, runmax, ring3, runarg, ch * kMC, frag_h);
             } else {
-                if (mts == 2) l3_pass_bf3_2x2<2>(w3rs, lane * 16, ab3, wave_s, runmax, ring3);
-                else          l3_pass_bf3_2x2<1>(w3rs, lane * 16, ab3, wave_s, runmax, ring3);
+                if (mts == 2) l3_pass_bf3_2x2<2, PROBE>(w3rs, lane * 16, ab3, wave_s, runmax, ring3);
+                else          l3_pass_bf3_2x2<1, PROBE>(w3rs, lane * 16, ab3, wave_s, runmax, ring3);
             }
-            if (a.prio == 1) __builtin_amdgcn_s_setprio(0);
         } else if (L3V == 0) {
             if (mts == 2) l3_pass_v0<2>(w3b, a2base, wave_s, runmax);
             else          l3_pass_v0<1>(w3b, a2base, wave_s, runmax);
@@ -798,6 +801,11 @@ void launch_chain(const ChainArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((pn_chain_kernel<kTrunk, 3, false, true>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
     else if (MODE == kTrunk && a.argrow)
         hipLaunchKernelGGL((pn_chain_kernel<kTrunk, 2, false, true>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
+    else if (MODE != kPrepool && a.w3_bf3 && a.w2_bf3 && !fp32_l3 && knob >= 91 && knob <= 93) {   // timing probes, results wrong
+        if (knob == 91) hipLaunchKernelGGL((pn_chain_kernel<MODE == kPrepool ? kFstn : MODE, 3, false, false, 1>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
+        else if (knob == 92) hipLaunchKernelGGL((pn_chain_kernel<MODE == kPrepool ? kFstn : MODE, 3, false, false, 2>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
+        else hipLaunchKernelGGL((pn_chain_kernel<MODE == kPrepool ? kFstn : MODE, 3, false, false, 3>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
+    }
     else if (MODE != kPrepool && a.w3_bf3 && a.w2_bf3 && !fp32_l3)
         hipLaunchKernelGGL((pn_chain_kernel<MODE, 3>), dim3(a.items), dim3(kThreads), extra_lds, st, a);
     else
@@ -961,7 +969,7 @@ extern "C" int iq_pointnet_coalitions_crt(const iq_pointnet_weights* w, const fl
     a.stamps = g_stamps;
     a.tail16 = iq::tuning(iq::kTuneExperiment) != 16 && iq::tuning(iq::kTuneExperiment) != 55;   // 16, 55: 32-row tiles only
     a.l3_single = iq::tuning(iq::kTuneExperiment) == 58;
-    a.prio = iq::tuning(iq::kTunePrio);
+
 
     // 1. input-STN chain, pre-pooled per (cloud, region) [+ centre]
     a.cloud_of = nullptr; a.trans = nullptr;

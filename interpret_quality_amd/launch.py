@@ -50,6 +50,10 @@ def kfd_gpus(nodes_dir=KFD_NODES, dri_dir="/dev/dri"):
         names = sorted(os.listdir(nodes_dir), key=lambda n: (len(n), n))
     except OSError:
         return None
+    try:
+        have_dri = any(f.startswith("renderD") for f in os.listdir(dri_dir))
+    except OSError:
+        have_dri = False
     count = 0
     for n in names:
         try:
@@ -60,8 +64,10 @@ def kfd_gpus(nodes_dir=KFD_NODES, dri_dir="/dev/dri"):
             continue
         minor = int(props.get("drm_render_minor", "-1"))
         dev = os.path.join(dri_dir, "renderD%d" % minor)
-        if minor < 0 or not os.path.exists(dev) or os.access(dev, os.R_OK | os.W_OK):
-            count += 1                                # no render-node bookkeeping (or no /dev/dri view): count the node itself
+        if minor < 0 or not have_dri:
+            count += 1                                # no render-node bookkeeping (or no /dev/dri view at all): the node itself
+        elif os.path.exists(dev) and os.access(dev, os.R_OK | os.W_OK):
+            count += 1
     return count
 
 

@@ -297,9 +297,11 @@ def test_two_rank_pipelines_write_the_same_artefacts_as_one_process(tmp_path, mo
               ("final_gen_pair.py", ["--num_pairs_random", "4", "--num_save_context_max", "3"]),
               ("final_point_binary_interaction_logits.py", []), ("final_cal_interactions.py", []))
     results = {}
-    for tag, launcher in (("one", [sys.executable]),
-                          ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                                   "--master-addr", "127.0.0.1", "--master-port", "29573"])):
+    launchers = (("one", [sys.executable]),
+                 ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29573"]))
+
+    def pipeline(tag, launcher):
         work = tmp_path / tag
         work.mkdir()
         for k, (script, extra) in enumerate(stages):
@@ -309,6 +311,13 @@ def test_two_rank_pipelines_write_the_same_artefacts_as_one_process(tmp_path, mo
             r = subprocess.run(cmd + [os.path.join(repo, script)] + common + extra, cwd=str(work), env=env,
                                capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, (script, r.stderr[-3000:])
+
+    import concurrent.futures as cf
+    with cf.ThreadPoolExecutor(max_workers=2) as ex:           # the one-process and the two-rank pipeline side by side
+        for f in [ex.submit(pipeline, t, l) for t, l in launchers]:
+            f.result()
+    for tag, _ in launchers:
+        work = tmp_path / tag
         inter = work / root / "interaction_seed1"
         results[tag] = {
             "sv": np.load(str(work / root / "region_sv_all.npy")),
@@ -335,7 +344,7 @@ def test_bench_n2_rehearsal_prints_one_valid_json_line(tmp_path):
     env = dict(os.environ, IQ_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29591", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1",
-                        "--warmup", "1", "--perms", "100"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+                        "--warmup", "1", "--repeats", "1", "--perms", "100", "--sustained-s", "0.3"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1

@@ -1,11 +1,12 @@
 """CPU: the gfx950 code INSIDE the libiq_hip.so that ships holds no packed float32 VALU instruction.
 
-Round 4 found the smoothness kernel's results moving by a few ulp beside a second process on the same GPU only while its code
-held v_pk_mul_f32 / v_pk_add_f32, and fenced ONE file with -fno-slp-vectorize - a vectoriser heuristic, not a guarantee.
-Round 5 (profiles/r05_packed_fp32_victim.txt) switches the `packed-fp32-ops` subtarget feature off for the whole
-library, which removes the instructions at instruction selection; beside MFMAs they are also a measured anti-lever
-(MI355X_MICROARCH.md, cycle constants).  This test disassembles the shared library itself (tools/isa_audit.py), so a compiler
-bump, a new flag or an explicit float2 expression cannot bring them back silently."""
+Rounds 4-5 (profiles/r05_packed_fp32_victim.txt): v_pk_mul_f32 / v_pk_add_f32 with op_sel:[0,1] - the form hipcc's SLP
+vectoriser uses to broadcast one float of a register pair - return a wrong low result in lanes 48-63 while a second process runs a
+bf16-MFMA-dense kernel on the same GPU (a register-only loop shows it in every launch); round 4 fenced ONE file with
+-fno-slp-vectorize, a vectoriser heuristic.  The library is now built with the `packed-fp32-ops` subtarget feature switched off,
+which removes the instructions at instruction selection; beside MFMAs they are also a measured anti-lever (MI355X_MICROARCH.md,
+cycle constants).  This test disassembles the shared library itself (tools/isa_audit.py), so a compiler bump, a new flag or an
+explicit float2 expression cannot bring them back silently."""
 import os
 import sys
 

@@ -163,11 +163,13 @@ def test_project_to_bound_option_keeps_points_inside():
 
 def test_enumeration_is_reproducible_beside_a_second_process_on_the_gpu():
     """Two ranks on ONE GPU (what the sweep tests do on a one-GPU box): the smoothness kernel must give the same bits while
-    another process runs the PointNet chain kernel beside it.  With packed float32 instructions in the kernel it did not
-    (40 % of the launches differed; interpret_quality_amd/build.py NO_PACKED_FP32)."""
+    another process runs the PointNet chain kernel beside it.  With packed float32 instructions in the kernel it did not (40-98 %
+    of the launches differed, rounds 4 and 5: v_pk_mul_f32 / v_pk_add_f32 with op_sel:[0,1] go wrong in lanes 48-63 beside such a
+    neighbour, profiles/r05_packed_fp32_victim.txt; the library is now built without packed float32 - build.py, asserted on the
+    shipped code by tests/test_isa_cpu.py - so this is a short guard, not the proof)."""
     import subprocess
     import sys
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "shared_gpu_determinism.py")
-    r = subprocess.run([sys.executable, tool, "--load", "pointnet", "--seconds", "8"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, tool, "--load", "pointnet", "--seconds", "4"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches {'fps': 0, 'region_assign': 0, 'smoothness': 0}" in r.stdout, r.stdout[-2000:]

@@ -7,7 +7,7 @@ import sys
 
 import pytest
 
-from test_dist_gpu import REPO, _artefacts, _assert_same, _env, _run, _torchrun
+from test_dist_gpu import REPO, _artefacts, _assert_same, _env, _run, _run_chains, _torchrun
 
 pytestmark = pytest.mark.gpu
 
@@ -17,12 +17,12 @@ PAIRS = ["--num_pairs_random", "5", "--num_save_context_max", "3"]
 
 
 def _per_stage_scripts(work, model, dataset, clouds):
+    """The chain of launches of one model: one process per stage, in the order of the two shell scripts."""
     common = ["--model", model, "--dataset", dataset, "--synthetic", "--num_clouds", str(clouds)]
     plan = [("final_shapley_value.py", SIZES), ("final_rotate_center_enum_all.py", []), ("final_scale_center_enum_all.py", []),
             ("final_smoothness_center_enum_all.py", []), ("final_gen_pair.py", PAIRS),
             ("final_point_binary_interaction_logits.py", PAIRS), ("final_cal_interactions.py", PAIRS + ["--device_id", "0"])]
-    for script, extra in plan:
-        _run([sys.executable, os.path.join(REPO, script)] + common + extra, work, _env())
+    return [([sys.executable, os.path.join(REPO, script)] + common + extra, work, _env()) for script, extra in plan]
 
 
 def _record(stdout):
@@ -36,13 +36,29 @@ def _record(stdout):
 MODELS, DATASET, CLOUDS = ["pointnet", "gcnn"], "modelnet10", 4      # clouds 0 and 3 are interaction samples (final_util.py:26)
 
 
+ALL_SIX_FLAGS = ["--synthetic", "--num_clouds", "1", "--stages", "shapley_value,scale", "--num_samples_save", "100", "--resume"]
+
+
 @pytest.fixture(scope="module")
-def script_artefacts(tmp_path_factory):
-    """The per-stage scripts, one process each, once for both parametrisations below."""
+def background(tmp_path_factory):
+    """Three independent chains of launches, side by side (four GPU processes beside this one): the per-stage scripts of the two
+    models (the reference side of the first test below) and the all-pairs sweep on two ranks (the second test's run).  Most of a
+    launch is process start-up, so this is what keeps the module's wall time down; what each test asserts is unchanged."""
     one = tmp_path_factory.mktemp("scripts")
-    for m in MODELS:
-        _per_stage_scripts(one, m, DATASET, CLOUDS)
-    return _artefacts(one)
+    six = tmp_path_factory.mktemp("all_six")
+    chains = [_per_stage_scripts(one, m, DATASET, CLOUDS) for m in MODELS]
+    # (the two models share only the FPS index file of the dataset: written once, by the first stage that finds it missing, behind
+    # the guard the two-rank race test covers - so one launch first, then everything side by side)
+    _run(*chains[0][0])
+    sweep = os.path.join(REPO, "tools", "sweep.py")
+    res = _run_chains([chains[0][1:], chains[1], [(_torchrun(2, 29735) + [sweep] + ALL_SIX_FLAGS, six, _env(IQ_REHEARSAL="1"))]])
+    return {"scripts": _artefacts(one), "all_six": (res[2][0], six)}
+
+
+@pytest.fixture(scope="module")
+def script_artefacts(background):
+    """The per-stage scripts, one process each, once for the parametrisations below."""
+    return background["scripts"]
 
 
 @pytest.mark.parametrize("ranks", [2])   # (one process: tools/r03_e2e.sh runs the sweep that way; the RCCL test below too)
@@ -76,15 +92,14 @@ def test_sweep_writes_the_same_artefacts_as_the_per_stage_scripts(tmp_path, scri
     assert any(k.endswith("region_sv_all.npy") for k in a) and any("allregion_inc" in k for k in a)
 
 
-def test_sweep_covers_all_six_models_and_both_datasets_on_two_ranks(tmp_path):
+def test_sweep_covers_all_six_models_and_both_datasets_on_two_ranks(background):
     """BASELINE configs[4] plumbing: every (model, dataset) pair through the sweep driver, two ranks (rehearsal: both on cuda:0),
     one cloud each, stage 1 + the scale sweep (the 216-pose sweeps and the interaction stages of every family are covered by the
     tests above and in test_dist_gpu.py; here the point is that all 12 pairs are assigned, run and written exactly once)."""
     import glob
-    sweep = os.path.join(REPO, "tools", "sweep.py")
-    # (--resume on a fresh directory skips nothing; it makes rank 0 broadcast its view of the finished units to the other rank)
-    flags = ["--synthetic", "--num_clouds", "1", "--stages", "shapley_value,scale", "--num_samples_save", "100", "--resume"]
-    r = _run(_torchrun(2, 29735) + [sweep] + flags, tmp_path, _env(IQ_REHEARSAL="1"))
+    # (--resume on a fresh directory skips nothing; it makes rank 0 broadcast its view of the finished units to the other rank;
+    # the run itself was started by the module's `background` fixture, beside the per-stage scripts)
+    r, tmp_path = background["all_six"]
     rec = _record(r.stdout)
     pa = rec["phases"]["A_shapley"]
     assert rec["n_gpus"] == 2 and pa["units"] == 12 and sorted(x["rank"] for x in pa["per_rank"]) == [0, 1]

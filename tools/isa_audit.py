@@ -5,10 +5,11 @@ packed float32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) it
     python tools/isa_audit.py [path/to/libiq_hip.so] [--all]
 
 Why: (1) MI355X_MICROARCH.md prices packed float32 beside MFMAs as an anti-lever (2 v_pk_add_f32 per MFMA gap +26 cycles against
-two scalar ones); (2) round 4 found the smoothness kernel's results changing by a few ulp beside a second process ONLY while it
-held packed float32 instructions (profiles/r04_shared_gpu_determinism.txt, r05_packed_fp32_victim.txt).  The library is built
-with the packed-fp32 subtarget feature switched off (interpret_quality_amd/build.py); tests/test_isa_cpu.py runs this audit on
-the .so that ships and fails on any packed float32 instruction in a kernel that issues MFMAs, and in the smoothness kernel.
+two scalar ones); (2) rounds 4-5 found one operand form of v_pk_mul_f32 / v_pk_add_f32 (op_sel:[0,1]: the low result taking the
+high dword of src1) returning wrong results in lanes 48-63 while another process runs a bf16-MFMA-dense kernel on the same GPU
+(profiles/r05_packed_fp32_victim.txt).  The library is built with the packed-fp32 subtarget feature switched off
+(interpret_quality_amd/build.py); tests/test_isa_cpu.py runs this audit on the .so that ships and fails on any packed float32
+instruction, in a kernel that issues MFMAs or anywhere else.
 
 The device code is taken out of the .so itself (llvm-objdump --offloading, in a scratch directory), so what is audited is what
 the GPU box loads - not a side compile.

@@ -64,12 +64,12 @@ __global__ __launch_bounds__(64) void victim(float* out, int iters) {
     out[gid * 4 + 3] = y1;
 }
 
-// Variant 3 (round 5): does the IGNORED half of a packed operand matter?  hipcc's SLP code for the smoothness loop broadcasts one
-// float to both halves with op_sel / op_sel_hi on a register PAIR whose other register was never written (e.g.
-// `ds_read_b32 v20 ... v_pk_mul_f32 v[28:29], v[14:15], v[20:21] op_sel_hi:[1,0]`, v21 uninitialised): architecturally v21 is not
-// read.  Here the ignored register is set to a chosen bit pattern `garb` (kernel argument) and the packed result is compared
-// with the scalar twin, alone on the GPU: forms 0 = src1 op_sel_hi:[1,0] (high half ignored), 1 = src1 op_sel:[0,1] (low half
-// ignored), 2 = the same two on v_pk_add_f32, 3 = v_pk_fma_f32 src2.
+// Variant 3 (round 5): the OPERAND FORMS of packed float32 - op_sel / op_sel_hi picking the other half of a register pair, as hipcc's
+// SLP code does to broadcast one float to both halves (e.g. `v_pk_mul_f32 v[24:25], v[6:7], v[12:13] op_sel:[0,1] op_sel_hi:[1,0]`).
+// One modifier at a time, on the multiply (forms 0-3), the add (4-7) or the fma's addend (8-9); the half of the pair that the
+// modifier leaves UNREAD holds a chosen bit pattern `garb`; the scalar twin computes the same map.
+//   0 mul hi <- src1.lo (op_sel_hi:[1,0])   1 mul lo <- src1.hi (op_sel:[0,1])   2 mul lo <- src0.hi (op_sel:[1,0])   3 mul hi <- src0.lo (op_sel_hi:[0,1])
+//   4-7 the same four on v_pk_add_f32       8 fma src2 lo <- hi (op_sel:[0,0,1])  9 fma src2 hi <- lo (op_sel_hi:[1,1,0])
 template <int FORM>
 __global__ __launch_bounds__(64) void victim_garbage(float* out, int iters, unsigned garb) {
     const int gid = blockIdx.x * 64 + threadIdx.x;
@@ -78,27 +78,27 @@ __global__ __launch_bounds__(64) void victim_garbage(float* out, int iters, unsi
     f32x2 x = {rnd() * 1.6f - 0.8f, rnd() * 1.6f - 0.8f};
     float y0 = x[0], y1 = x[1];
     const float a = 1.85f + 0.1f * rnd(), na = -a, o = 1.0f;
-    const float g = __builtin_bit_cast(float, garb ^ (FORM == 9 ? gid : 0));
-    const f32x2 c_lo = {na, g}, c_hi = {g, na}, one_lo = {o, g}, one_hi = {g, o};
+    const float g = __builtin_bit_cast(float, garb);
+    const f32x2 c_lo = {na, g}, c_hi = {g, na}, cc = {na, na}, one_lo = {o, g}, one_hi = {g, o}, one = {o, o};
     for (int it = 0; it < iters; ++it) {
         f32x2 t, u;
         asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(t) : "v"(x));
-        if (FORM == 0) {
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(u) : "v"(t), "v"(c_lo));
-            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(x) : "v"(u), "v"(one_lo));
-        } else if (FORM == 1) {
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(u) : "v"(t), "v"(c_hi));
-            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(x) : "v"(u), "v"(one_hi));
-        } else if (FORM == 2) {
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(u) : "v"(t), "v"(c_lo));
-            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(x) : "v"(u), "v"(one_hi));
-        } else {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(x) : "v"(t), "v"(c_lo), "v"(one_lo));
-        }
+        if (FORM == 0) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(u) : "v"(t), "v"(c_lo));
+        else if (FORM == 1) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(u) : "v"(t), "v"(c_hi));
+        else if (FORM == 2) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(u) : "v"(c_hi), "v"(t));
+        else if (FORM == 3) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(u) : "v"(c_lo), "v"(t));
+        else if (FORM < 8) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(u) : "v"(t), "v"(cc));
+        if (FORM < 4) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(x) : "v"(u), "v"(one));
+        else if (FORM == 4) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(x) : "v"(u), "v"(one_lo));
+        else if (FORM == 5) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(x) : "v"(u), "v"(one_hi));
+        else if (FORM == 6) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(x) : "v"(one_hi), "v"(u));
+        else if (FORM == 7) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(x) : "v"(one_lo), "v"(u));
+        else if (FORM == 8) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]" : "=v"(x) : "v"(t), "v"(cc), "v"(one_hi));
+        else asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(x) : "v"(t), "v"(cc), "v"(one_lo));
         float t0, t1, u0, u1;
         asm volatile("v_mul_f32 %0, %1, %1" : "=v"(t0) : "v"(y0));
         asm volatile("v_mul_f32 %0, %1, %1" : "=v"(t1) : "v"(y1));
-        if (FORM == 3) {
+        if (FORM >= 8) {
             asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y0) : "v"(t0), "v"(na), "v"(o));
             asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y1) : "v"(t1), "v"(na), "v"(o));
         } else {
@@ -124,26 +124,44 @@ int main(int argc, char** argv) {
     const size_t n = (size_t)wgs * 64 * 4;
     float* d;
     CK(hipMalloc(&d, n * sizeof(float)));
-    if (variant == 3) {   // ignored-half patterns, alone: one launch per (form, pattern), packed against scalar inside the launch
-        const unsigned pats[] = {0u, 0x3f800000u, 0x7fc00000u, 0x7f800001u, 0xffffffffu, 0x7f800000u, 0xff800000u, 0x00000001u,
-                                 0x007fffffu, 0x80000001u, 0x7f7fffffu, 0x3fc03fc0u, 0x7fc07fc0u, 0xdeadbeefu};
+    if (variant == 3) {   // operand forms x patterns of the unread half: packed against scalar inside each launch, looped for `seconds`
+        const unsigned pats[] = {0u, 0x3f800000u, 0x7fc00000u, 0x7f800001u, 0xffffffffu, 0x00000001u, 0xdeadbeefu};
+        const char* names[10] = {"mul hi<-src1.lo", "mul lo<-src1.hi", "mul lo<-src0.hi", "mul hi<-src0.lo", "add hi<-src1.lo", "add lo<-src1.hi",
+                                 "add lo<-src0.hi", "add hi<-src0.lo", "fma src2 lo<-hi", "fma src2 hi<-lo"};
         std::vector<float> g(n);
-        int any = 0;
-        for (int form = 0; form < 4; ++form)
-            for (unsigned pat : pats) {
-                switch (form) {
-                    case 0: hipLaunchKernelGGL(victim_garbage<0>, dim3(wgs), dim3(64), 0, 0, d, iters, pat); break;
-                    case 1: hipLaunchKernelGGL(victim_garbage<1>, dim3(wgs), dim3(64), 0, 0, d, iters, pat); break;
-                    case 2: hipLaunchKernelGGL(victim_garbage<2>, dim3(wgs), dim3(64), 0, 0, d, iters, pat); break;
-                    default: hipLaunchKernelGGL(victim_garbage<3>, dim3(wgs), dim3(64), 0, 0, d, iters, pat); break;
+        long launches[10] = {0}, bad_launches[10] = {0}, quarter[10][4] = {{0}}, lo_bad[10] = {0}, hi_bad[10] = {0};
+        const auto t0 = std::chrono::steady_clock::now();
+        do
+            for (int form = 0; form < 10; ++form)
+                for (unsigned pat : pats) {
+                    switch (form) {
+                        case 0: hipLaunchKernelGGL(victim_garbage<0>, dim3(wgs), dim3(64), 0, 0, d, iters, pat); break;
+                        case 1: hipLaunchKernelGGL(victim_garbage<1>, dim3(wgs), dim3(64), 0, 0, d, iters, pat); break;
+                        case 2: hipLaunchKernelGGL(victim_garbage<2>, dim3(wgs), dim3(64), 0, 0, d, iters, pat); break;
+                        case 3: hipLaunchKernelGGL(victim_garbage<3>, dim3(wgs), dim3(64), 0, 0, d, iters, pat); break;
+                        case 4: hipLaunchKernelGGL(victim_garbage<4>, dim3(wgs), dim3(64), 0, 0, d, iters, pat); break;
+                        case 5: hipLaunchKernelGGL(victim_garbage<5>, dim3(wgs), dim3(64), 0, 0, d, iters, pat); break;
+                        case 6: hipLaunchKernelGGL(victim_garbage<6>, dim3(wgs), dim3(64), 0, 0, d, iters, pat); break;
+                        case 7: hipLaunchKernelGGL(victim_garbage<7>, dim3(wgs), dim3(64), 0, 0, d, iters, pat); break;
+                        case 8: hipLaunchKernelGGL(victim_garbage<8>, dim3(wgs), dim3(64), 0, 0, d, iters, pat); break;
+                        default: hipLaunchKernelGGL(victim_garbage<9>, dim3(wgs), dim3(64), 0, 0, d, iters, pat); break;
+                    }
+                    CK(hipMemcpy(g.data(), d, n * sizeof(float), hipMemcpyDeviceToHost));
+                    bool b = false;
+                    for (size_t i = 0; i < n; i += 4) {
+                        const bool lo = memcmp(&g[i], &g[i + 2], 4) != 0, hi = memcmp(&g[i + 1], &g[i + 3], 4) != 0;
+                        if (lo || hi) { b = true; ++quarter[form][((i / 4) & 63) >> 4]; lo_bad[form] += lo; hi_bad[form] += hi; }
+                    }
+                    ++launches[form]; bad_launches[form] += b;
                 }
-                CK(hipMemcpy(g.data(), d, n * sizeof(float), hipMemcpyDeviceToHost));
-                long lanes_bad = 0;
-                for (size_t i = 0; i < n; i += 4) lanes_bad += memcmp(&g[i], &g[i + 2], 8) != 0;
-                if (lanes_bad) any = 1;
-                printf("ignored-half form %d pattern 0x%08x: lanes where packed != scalar: %ld of %zu (lane 0: packed %.9g %.9g scalar %.9g %.9g)\n",
-                       form, pat, lanes_bad, n / 4, g[0], g[1], g[2], g[3]);
-            }
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds);
+        int any = 0;
+        for (int f = 0; f < 10; ++f) {
+            printf("form %d %-16s: %4ld launches (x %d waves x %d iterations), %4ld with packed != scalar; lanes 0-15 / 16-31 / 32-47 / 48-63: %ld %ld %ld %ld; "
+                   "low half %ld, high half %ld\n", f, names[f], launches[f], wgs, iters, bad_launches[f], quarter[f][0], quarter[f][1], quarter[f][2],
+                   quarter[f][3], lo_bad[f], hi_bad[f]);
+            any |= bad_launches[f] != 0;
+        }
         return any;
     }
     std::vector<float> first(n), got(n);

@@ -8,9 +8,12 @@ busy with the chosen kind of work.  Prints `rounds N mismatches {...}`; exit cod
 
 Why it exists: in round 4 the two-ranks-on-one-GPU sweep test failed on the smoothness artefacts only.  This loop showed the
 smoothness kernel deterministic alone and beside every neighbour except ONE - the PointNet chain kernel with layer 3 on the
-bf16 matrix pipe - and only while the smoothness kernel used packed float32 instructions (v_pk_mul_f32 / v_pk_add_f32); see
-interpret_quality_amd/build.py (NO_PACKED_FP32) and profiles/r04_shared_gpu_determinism.txt.  tests/test_smoothness_gpu.py runs
-it for a few seconds.  (Product code only: nothing under oracle/ is imported.)
+bf16 matrix pipe - and only while the smoothness kernel used packed float32 instructions.  Round 5 found the ingredient with
+register-only victims (tools/micro/pk_victim.hip, smooth_victim.hip; profiles/r05_packed_fp32_victim.txt): v_pk_mul_f32 /
+v_pk_add_f32 with op_sel:[0,1] return a wrong low result in lanes 48-63 beside such a neighbour; the library is built without
+packed float32 now (interpret_quality_amd/build.py).  IQ_LIBPATH=interpret_quality_amd/lib_packed_ab/libiq_hip.so (python -m
+interpret_quality_amd.build --packed-ab) runs this tool on round 4's code generation.  tests/test_smoothness_gpu.py runs it for a few
+seconds.  (Product code only: nothing under oracle/ is imported.)
 """
 import argparse
 import os
