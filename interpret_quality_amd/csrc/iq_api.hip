@@ -92,7 +92,7 @@ namespace {
 typedef float dbg_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 dbg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned dbg_u32x4 __attribute__((ext_vector_type(4)));
-__device__ unsigned long long g_sustained_clk;
+__device__ unsigned long long g_sustained_clk[2];   // shader-clock ticks (s_memtime) and 100 MHz ticks (s_memrealtime) of block 0's loop
 
 __device__ inline dbg_bf16x8 dbg_operand(unsigned seed) {   // eight bf16 in [1, 2) with random mantissas, random signs
     dbg_u32x4 v;
@@ -109,8 +109,11 @@ __device__ inline dbg_bf16x8 dbg_operand(unsigned seed) {   // eight bf16 in [1,
 __global__ __launch_bounds__(256) void mfma_sustained_kernel(float* out, int iters, int seed0) {
     const dbg_bf16x8 a0 = dbg_operand(seed0 + threadIdx.x * 7 + blockIdx.x), a1 = dbg_operand(seed0 * 3 + threadIdx.x * 11 + blockIdx.x);
     const dbg_bf16x8 b0 = dbg_operand(seed0 * 5 + threadIdx.x * 13), b1 = dbg_operand(seed0 * 9 + threadIdx.x * 17);
-    unsigned long long t0 = 0;
-    if (threadIdx.x == 0 && blockIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    unsigned long long t0 = 0, r0 = 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
     dbg_f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -124,7 +127,8 @@ __global__ __launch_bounds__(256) void mfma_sustained_kernel(float* out, int ite
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         unsigned long long t1;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-        g_sustained_clk = t1 - t0;
+        g_sustained_clk[0] = t1 - t0;
+        g_sustained_clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[5] + c2[9] + c3[15];
 }
@@ -156,10 +160,12 @@ extern "C" int iq_debug_mfma_sustained(double seconds, float* scratch, size_t sc
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc != IQ_OK) return rc;
-    unsigned long long clk = 0;
-    if (hipMemcpyFromSymbol(&clk, HIP_SYMBOL(g_sustained_clk), sizeof(clk)) != hipSuccess) return iq::fail(IQ_ELAUNCH, "hipMemcpyFromSymbol failed");
+    unsigned long long clk[2] = {0, 0};
+    if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_sustained_clk), sizeof(clk)) != hipSuccess) return iq::fail(IQ_ELAUNCH, "hipMemcpyFromSymbol failed");
     const double mfma = (double)grid * 4.0 * (double)iters * 16.0;
     *tflops = mfma * (2.0 * 32 * 32 * 16) / (ms * 1e-3) / 1e12;
-    if (clock_ghz) *clock_ghz = (double)clk / (ms * 1e-3) / 1e9;
+    // in-kernel clock = shader ticks / 100 MHz ticks x 0.1 GHz (MI355X_MICROARCH.md, DVFS give-back item 6): independent of how
+    // long block 0 was resident
+    if (clock_ghz) *clock_ghz = clk[1] ? (double)clk[0] / (double)clk[1] * 0.1 : 0.0;
     return IQ_OK;
 }

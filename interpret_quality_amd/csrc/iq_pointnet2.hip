@@ -177,7 +177,6 @@ struct GroupArgs {
     int N, S, K, blocks_per_wg;
     int B, wgs_per_cloud;
     int probe;               // tuning key 5 (79: per-phase cycle counts of pn2_group_bf3_kernel)
-    int prio;                // issue priority by phase in pn2_group_bf3_kernel (see there); tuning key 7, default 1
 };
 
 __device__ __forceinline__ void merge_max(float* addr, float v) {
@@ -428,6 +427,15 @@ __global__ __launch_bounds__(kThreads, WPS) void pn2_group_kernel(GroupArgs a) {
 // three bf16 planes of 272-byte rows (conflict-free ds_read_b128), split where they are produced; act1 and act2 SHARE one
 // 52 KB image - layer 2 keeps its two tiles in registers until every wave has read act1 - so that two workgroups fit a CU and
 // fill each other's barriers and stage-0 phases (four barriers per chunk instead of two).
+// Round 5, three closed experiments on the 0.55 MFMA-busy of this kernel and its PointConv twin (profiles/r05_grouped_schedule.txt;
+// patches under tools/experiments/): (1) s_setprio 1 inside the MFMA loops, or inside the VALU phases: no change (81.3-82.1 k
+// coalitions/s either way); (2) "ping-pong": one 512-thread workgroup running two block ranges, the second half one phase behind,
+// every barrier shared, so that each SIMD always pairs a VALU phase of one wave with an MFMA loop of the other: bit-identical, 9 %
+// SLOWER (80.3 -> 73.3 k; PointConv 84.5 -> 82.3 k), and still 8 % slower with the A terms of the MFMA loops prefetched one k-step
+// ahead (83.2 -> 76.6 k) - one wave alone does not keep the matrix pipe fed, the two workgroups' waves overlapping in their MFMA
+// loops is what saturates it; (3) the VALU phases (layer 1, the three-term splits) written stage by stage over eight independent
+// values instead of value by value (the compiler's schedule is one dependent chain after the other on two or three temporaries):
+// bit-identical, no change (81.5 / 81.9 k; PointConv 85.0 / 84.9 k; chain kernel 781.2 / 781.7 k).
 __device__ unsigned long long g_gb_dbg[12];
 template <int MTS>
 __device__ __forceinline__ void gb_layer2(const unsigned char* abase, const __amdgpu_buffer_rsrc_t& rs, int voff, int nt,
@@ -502,17 +510,6 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
         }
     };
 
-    // Issue priority by phase (MI355X_MICROARCH.md, two waves per SIMD, item 2): the two workgroups of a CU put two waves on each
-    // SIMD, arbitrated by priority then AGE - an older wave in a VALU phase (stage 0b, the split epilogue: hundreds of independent
-    // instructions) keeps the issue port and the younger wave's MFMAs wait.  Priority 1 while a wave is in an MFMA loop lets its
-    // one MFMA per 32 cycles through and leaves the other 24 cycles to the partner's VALU work.  a.prio: 0 off, 1 MFMA phases
-    // high, 2 VALU phases high (the opposite, A/B only).
-    const int pm = a.prio;
-    auto prio_mfma = [&](bool enter) {
-        if (pm == 1) { if (enter) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-        else if (pm == 2) { if (enter) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
-    };
-    if (pm == 2) __builtin_amdgcn_s_setprio(1);
     constexpr int Q1 = C1 / 4, NR = kMC * Q1 / kThreads;   // stage 0b: a thread owns 4 consecutive channels of NR rows
     const int c4 = tid % Q1, rsub = tid / Q1;
     f32x4 w1[4];
@@ -601,7 +598,6 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
         stamp(2);   // wait
         // ---- layer 2: 128 -> 128, tiles (m-tile 0..1, n-tile = wave) kept in registers -------------------
         f32x16 acc2[2][1] = {{{0}}, {{0}}};
-        prio_mfma(true);
         if (mts == 2) {
             gb_layer2<2>(abase, w2rs, voff, wave_s, ring2, acc2);
         } else {
@@ -609,7 +605,6 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
             gb_layer2<1>(abase, w2rs, voff, wave_s, ring2, one);
             acc2[0][0] = one[0][0];
         }
-        prio_mfma(false);
         B3x2 ring3[2];                               // layer 3's weights (n-tiles wave, wave + 4), in flight across the epilogue
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -634,10 +629,8 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
         // ---- layer 3: 128 -> 256, 2 x 2 tiles per wave, block maxima merged into the owning groups -------
         if (mts == 2) {
             f32x16 acc3[2][2] = {{{0}, {0}}, {{0}, {0}}};
-            prio_mfma(true);
-            gb_layer3<2>(abase, w3rs, voff, wave_s, ring3, acc3);
-            prio_mfma(false);
-#pragma unroll
+                gb_layer3<2>(abase, w3rs, voff, wave_s, ring3, acc3);
+    #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const float bias = a.b3[(q * 4 + wave) * 32 + fl];
                 const TileMax m0 = reduce_tile(acc3[0][q], bias);
@@ -649,10 +642,8 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
             }
         } else {
             f32x16 acc3[1][2] = {{{0}, {0}}};
-            prio_mfma(true);
-            gb_layer3<1>(abase, w3rs, voff, wave_s, ring3, acc3);
-            prio_mfma(false);
-#pragma unroll
+                gb_layer3<1>(abase, w3rs, voff, wave_s, ring3, acc3);
+    #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const float bias = a.b3[(q * 4 + wave) * 32 + fl];
                 const TileMax m0 = reduce_tile(acc3[0][q], bias);
@@ -749,7 +740,6 @@ int launch_group(const iq_pn2_scale& sc, GroupArgs a, const int32_t* n_unique, i
                  const void* l2_bf3 = nullptr, const void* l3_bf3 = nullptr) {
     a.w1x = sc.w1x;
     a.probe = iq::tuning(iq::kTuneExperiment);
-    a.prio = iq::tuning(iq::kTunePrio);
     a.w2_bf3 = reinterpret_cast<const unsigned short*>(l2_bf3);
     a.w3_bf3 = reinterpret_cast<const unsigned short*>(l3_bf3);
     a.w2 = sc.l2.w; a.b2 = sc.l2.b;

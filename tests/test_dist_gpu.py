@@ -90,7 +90,9 @@ def test_bench_runs_its_collectives_on_rccl_with_a_forced_single_rank_group(tmp_
     bench = os.path.join(REPO, "bench.py")
     flags = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--repeats", "1", "--perms", "100", "--other-models", "0", "--cpu-baseline", "0",
              "--eager-baseline", "0", "--traffic", "0", "--strong-steps", "0", "--sustained-s", "0.3"]
-    r = _run(_torchrun(1, 29611) + [bench] + flags, tmp_path, _env(IQ_FORCE_DIST="1"))
+    # under torchrun, and (second chain, side by side) without it - RANK / WORLD_SIZE absent: defaults, a free rendezvous port
+    (r,), (r2,) = _run_chains([[(_torchrun(1, 29611) + [bench] + flags, tmp_path, _env(IQ_FORCE_DIST="1"))],
+                               [([sys.executable, bench] + flags, tmp_path, _env(IQ_FORCE_DIST="1"))]])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
@@ -100,9 +102,7 @@ def test_bench_runs_its_collectives_on_rccl_with_a_forced_single_rank_group(tmp_
     sus = d["roofline"]["sustained_bf16_mfma"]
     assert 0.3 < sus["frac_of_dense_peak"] <= 1.0 and 0.8 < sus["shader_clock_ghz"] < 2.6
     assert abs(d["roofline"]["frac_of_sustained_bf16_ceiling"] - d["roofline"]["frac"] / sus["frac_of_dense_peak"]) < 1e-9
-    # and without torchrun (RANK / WORLD_SIZE absent: defaults), same switch
-    r = _run([sys.executable, bench] + flags, tmp_path, _env(IQ_FORCE_DIST="1"))   # a free rendezvous port is picked
-    assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1
+    assert len([ln for ln in r2.stdout.splitlines() if ln.startswith("{")]) == 1
 
 
 def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):

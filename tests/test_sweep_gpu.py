@@ -47,11 +47,10 @@ def background(tmp_path_factory):
     one = tmp_path_factory.mktemp("scripts")
     six = tmp_path_factory.mktemp("all_six")
     chains = [_per_stage_scripts(one, m, DATASET, CLOUDS) for m in MODELS]
-    # (the two models share only the FPS index file of the dataset: written once, by the first stage that finds it missing, behind
-    # the guard the two-rank race test covers - so one launch first, then everything side by side)
-    _run(*chains[0][0])
+    # (the two models share only the FPS index file of the dataset; whichever first stage finds it missing writes it under a
+    # temporary name and renames it - shapley_stage.save_fps - so two writers of the same bytes cannot hurt each other)
     sweep = os.path.join(REPO, "tools", "sweep.py")
-    res = _run_chains([chains[0][1:], chains[1], [(_torchrun(2, 29735) + [sweep] + ALL_SIX_FLAGS, six, _env(IQ_REHEARSAL="1"))]])
+    res = _run_chains([chains[0], chains[1], [(_torchrun(2, 29735) + [sweep] + ALL_SIX_FLAGS, six, _env(IQ_REHEARSAL="1"))]])
     return {"scripts": _artefacts(one), "all_six": (res[2][0], six)}
 
 

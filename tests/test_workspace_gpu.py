@@ -89,9 +89,8 @@ def test_stage_scripts_share_a_nearly_full_card_with_another_process(tmp_path):
                 common = ["--model", model, "--dataset", "modelnet10", "--synthetic", "--num_clouds", "1"]
                 chains.append([([sys.executable, os.path.join(REPO, "final_shapley_value.py")] + common + ["--num_samples_save", "100"], work, _env()),
                                ([sys.executable, os.path.join(REPO, "final_scale_center_enum_all.py")] + common, work, _env())])
-            if tag == "empty":      # the reference run on an empty card: the two models side by side (start-up dominates)
-                _run(*chains[0][0])                 # (the dataset's FPS index file is written once, by the first launch)
-                _run_chains([chains[0][1:], chains[1]])
+            if tag == "empty":      # the reference run on an empty card: the two models side by side (start-up dominates; the
+                _run_chains(chains)  # dataset's FPS index file is written under a temporary name and renamed: two writers are safe)
             else:                   # the pinned card: one child at a time next to the ballast, as before
                 for chain in chains:
                     for step in chain:

@@ -124,9 +124,9 @@ def main():
         load(a.load, a.seconds)
         return 0
     child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--role", "load", "--load", a.load,
-                              "--seconds", str(a.seconds + 10)])
+                              "--seconds", str(a.seconds + 7)])
     try:
-        time.sleep(6)                                  # the neighbour imports torch and builds its model first
+        time.sleep(5)                                  # the neighbour imports torch and builds its model first
         rounds, bad = check(a.seconds)
     finally:
         rc = child.wait()
