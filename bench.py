@@ -320,7 +320,7 @@ def measure_sustained(lib, dev, seconds):
                    "iq_debug_mfma_sustained")
         SUSTAINED["frac"] = tf.value / PEAK_BF16_MFMA_TFLOPS
         return {"tflops": tf.value, "frac_of_dense_peak": SUSTAINED["frac"], "shader_clock_ghz": clk.value, "seconds": seconds,
-                "what": "register-only loop of v_mfma_f32_32x32x16_bf16 on random operands, two waves per SIMD on every CU, measured on "
+                "what": "register-only loop of v_mfma_f32_32x32x16_bf16 on random operands, one wave per SIMD on every CU, measured on "
                         "this board after the timed regions (outside them)"}
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)[:300]}

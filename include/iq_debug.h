@@ -50,9 +50,9 @@ int iq_debug_knn_counters(unsigned long long* out_host /*8, host*/);
 int iq_profile_read(int slot, double* total_ms, int* launches);
 
 /* Diagnostic: the rate the bf16 matrix pipe SUSTAINS on this board now - a register-only loop of v_mfma_f32_32x32x16_bf16 on
- * random operands, two waves per SIMD on every CU, for about `seconds` (two launches: a calibration, then the measurement; both
+ * random operands, one wave per SIMD on every CU, for about `seconds` (two launches: a calibration, then the measurement; both
  * synchronise the stream).  tflops: dense bf16 TFLOP/s of the measured launch; clock_ghz (optional): shader clock held by its first
- * wave (s_memtime ticks / s_memrealtime ticks x 100 MHz).  scratch: device buffer of at least 512 * compute-unit-count floats.  MFMA-dense kernels
+ * wave (s_memtime ticks / wall time of the launch).  scratch: device buffer of at least 256 * compute-unit-count floats.  MFMA-dense kernels
  * on MI355X are power-bound: bench.py divides by THIS figure for `frac_of_sustained_bf16_ceiling` instead of a constant. */
 int iq_debug_mfma_sustained(double seconds, float* scratch /*device*/, size_t scratch_floats, double* tflops /*host*/,
                             double* clock_ghz /*host or NULL*/, iq_stream_t stream);

@@ -85,7 +85,7 @@ extern "C" int iq_profile_read(int which, double* total_ms, int* launches) {
 
 // ---- diagnostic: what the bf16 matrix pipe SUSTAINS on this board, now ------------------------------------------------------
 // A register-only loop of v_mfma_f32_32x32x16_bf16 (four independent accumulators per wave, operands with random mantissas and
-// signs so that the datapath toggles), two waves per SIMD on every CU, for about `seconds`.  MFMA-dense kernels on MI355X are
+// signs so that the datapath toggles), one wave per SIMD on every CU, for about `seconds`.  MFMA-dense kernels on MI355X are
 // bounded by the power cap, not by issue slots (MI355X_MICROARCH.md, DVFS give-back): the clock the governor holds differs from
 // board to board, so bench.py measures this ceiling on the board it runs on instead of quoting a constant.
 namespace {
@@ -140,7 +140,9 @@ extern "C" int iq_debug_mfma_sustained(double seconds, float* scratch, size_t sc
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return iq::fail(IQ_ELAUNCH, "iq_debug_mfma_sustained: device query failed");
-    const int grid = 2 * cus;                                    // 4 waves per workgroup, 2 workgroups per CU: two waves per SIMD
+    const int grid = cus;                                        // 4 waves per workgroup, one workgroup per CU: one wave per SIMD, every
+                                                                 // workgroup resident from the first cycle to the last (r4: two waves per
+                                                                 // SIMD sustain the same rate, profiles/r04_power_probe.txt)
     IQ_REQUIRE(scratch_floats >= (size_t)grid * 256, "iq_debug_mfma_sustained: scratch holds %zu floats, %zu needed", scratch_floats,
                (size_t)grid * 256);
     hipStream_t st = iq::as_stream(stream);
@@ -164,8 +166,10 @@ extern "C" int iq_debug_mfma_sustained(double seconds, float* scratch, size_t sc
     if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_sustained_clk), sizeof(clk)) != hipSuccess) return iq::fail(IQ_ELAUNCH, "hipMemcpyFromSymbol failed");
     const double mfma = (double)grid * 4.0 * (double)iters * 16.0;
     *tflops = mfma * (2.0 * 32 * 32 * 16) / (ms * 1e-3) / 1e12;
-    // in-kernel clock = shader ticks / 100 MHz ticks x 0.1 GHz (MI355X_MICROARCH.md, DVFS give-back item 6): independent of how
-    // long block 0 was resident
-    if (clock_ghz) *clock_ghz = clk[1] ? (double)clk[0] / (double)clk[1] * 0.1 : 0.0;
+    // in-kernel clock: block 0's s_memtime ticks over the launch's wall time (block 0 is resident for the whole launch; this is the
+    // form round 4 validated against the counters).  The s_memtime / s_memrealtime ratio read 9.7 where the PMC clock was 1.94 GHz
+    // (two waves per SIMD, round 5), so it is NOT used.
+    (void)clk[1];
+    if (clock_ghz) *clock_ghz = (double)clk[0] / (ms * 1e-3) / 1e9;
     return IQ_OK;
 }

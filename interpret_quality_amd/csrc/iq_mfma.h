@@ -54,12 +54,23 @@ __device__ __forceinline__ f32x16 mfma4(f32x4 a, f32x4 b, f32x16 c) {
     return c;
 }
 
+// Maxima of accumulator registers WITHOUT the canonicalising `v_max_f32 x, x, x` hipcc puts in front of every fmaxf whose operand
+// it cannot prove quiet (an MFMA result): 16 of them per tile, a third of the pooling's instructions (round 5: the chain kernel held
+// 144, the grouped kernel 144).  v_max3_f32 / v_max_f32 as plain instructions; for non-NaN data the result is fmaxf's.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max2_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ float max16(f32x16 c) {
-    float m0 = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
-    float m1 = fmaxf(fmaxf(c[4], c[5]), fmaxf(c[6], c[7]));
-    float m2 = fmaxf(fmaxf(c[8], c[9]), fmaxf(c[10], c[11]));
-    float m3 = fmaxf(fmaxf(c[12], c[13]), fmaxf(c[14], c[15]));
-    return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    float m0 = max3_raw(c[0], c[1], c[2]), m1 = max3_raw(c[3], c[4], c[5]), m2 = max3_raw(c[6], c[7], c[8]);
+    float m3 = max3_raw(c[9], c[10], c[11]), m4 = max3_raw(c[12], c[13], c[14]);
+    return max3_raw(max3_raw(m0, m1, m2), max3_raw(m3, m4, c[15]), m0);
 }
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5).

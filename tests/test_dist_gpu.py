@@ -61,8 +61,8 @@ def _run_chains(chains):
     import concurrent.futures as cf
     assert len(chains) <= 3
 
-    def one(chain):
-        return [_run(cmd, cwd, env) for cmd, cwd, env in chain]
+    def one(chain):   # an element is a launch (cmd, cwd, env) or a callable (e.g. an Event's set / wait between chains)
+        return [step() if callable(step) else _run(*step) for step in chain]
     with cf.ThreadPoolExecutor(max_workers=len(chains)) as ex:
         futs = [ex.submit(one, c) for c in chains]
         return [f.result() for f in futs]

@@ -1,3 +1,4 @@
+# (A/B of a CLOSED experiment: apply tools/experiments/r05_grouped_staged_valu.patch first; see tools/experiments/README.md)
 # Round 5: VALU phases written stage by stage over independent values (default) against value by value (round 4's order).
 # Grouped bf16x3 kernels: tuning key 7 = 1 selects the old order inside ONE library; chain kernel: two builds (IQ_LIBPATH).
 R=$GRAFT_REPO_ROOT; cd $R

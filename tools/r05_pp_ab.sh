@@ -1,3 +1,4 @@
+# (A/B of a CLOSED experiment: apply tools/experiments/r05_grouped_pingpong.patch first; see tools/experiments/README.md)
 # Round 5: ping-pong halves (+ A-term prefetch in the MFMA loops) against two independent 256-thread workgroups per CU
 # (tuning key 7 = 1), grouped bf16x3 kernels.  Bitwise check first (coalition logits of 200 random coalitions, both schedules).
 R=$GRAFT_REPO_ROOT; cd $R
