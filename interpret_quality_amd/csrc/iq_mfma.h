@@ -54,23 +54,17 @@ __device__ __forceinline__ f32x16 mfma4(f32x4 a, f32x4 b, f32x16 c) {
     return c;
 }
 
-// Maxima of accumulator registers WITHOUT the canonicalising `v_max_f32 x, x, x` hipcc puts in front of every fmaxf whose operand
-// it cannot prove quiet (an MFMA result): 16 of them per tile, a third of the pooling's instructions (round 5: the chain kernel held
-// 144, the grouped kernel 144).  v_max3_f32 / v_max_f32 as plain instructions; for non-NaN data the result is fmaxf's.
-__device__ __forceinline__ float max3_raw(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float max2_raw(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+// Column maximum of a tile's 16 accumulator registers.  Written as chains of fmaxf(fmaxf(a, b), c) so that the compiler forms
+// v_max3_f32 (8 instructions for 16 values).  iq_pointnet.hip is compiled with -fno-honor-nans (build.py): hipcc otherwise puts a
+// canonicalising `v_max_f32 x, x, x` in front of every fmaxf operand it cannot prove quiet - an MFMA result - and the chain kernel
+// carried 144 of them, a third of layer 3's pooling instructions (round 5: +1 % on the headline).  (Hand-written v_max3 through
+// inline asm is NOT an option: the hazard recogniser does not see an asm's reads of a just-written accumulator - the one-tile and
+// two-tile passes of layer 3 stopped agreeing bit for bit.)
 __device__ __forceinline__ float max16(f32x16 c) {
-    float m0 = max3_raw(c[0], c[1], c[2]), m1 = max3_raw(c[3], c[4], c[5]), m2 = max3_raw(c[6], c[7], c[8]);
-    float m3 = max3_raw(c[9], c[10], c[11]), m4 = max3_raw(c[12], c[13], c[14]);
-    return max3_raw(max3_raw(m0, m1, m2), max3_raw(m3, m4, c[15]), m0);
+    float a = fmaxf(fmaxf(c[0], c[1]), c[2]), b = fmaxf(fmaxf(c[8], c[9]), c[10]);
+    a = fmaxf(fmaxf(a, c[3]), c[4]);  b = fmaxf(fmaxf(b, c[11]), c[12]);
+    a = fmaxf(fmaxf(a, c[5]), c[6]);  b = fmaxf(fmaxf(b, c[13]), c[14]);
+    return fmaxf(fmaxf(a, c[7]), fmaxf(b, c[15]));
 }
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5).

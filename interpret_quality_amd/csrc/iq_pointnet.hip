@@ -85,9 +85,9 @@ __device__ __forceinline__ void l3_pass_v0(const WBuf& w3, const float* abase, i
             b1 = bn;
         }
         float m = max16(acc0);
-        if (MTS == 2) m = max2_raw(m, max16(acc1));
+        if (MTS == 2) m = fmaxf(m, max16(acc1));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? max2_raw(runmax[i], m) : runmax[i];
+        for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? fmaxf(runmax[i], m) : runmax[i];
         wq = wnext;
     }
 }
@@ -156,9 +156,9 @@ __device__ __forceinline__ void l3_pass_v2(const WBuf& w3, const float* abase, i
             }
         } else {
             float m = max16(acc0);
-            if (MTS == 2) m = max2_raw(m, max16(acc1));
+            if (MTS == 2) m = fmaxf(m, max16(acc1));
 #pragma unroll
-            for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? max2_raw(runmax[i], m) : runmax[i];
+            for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? fmaxf(runmax[i], m) : runmax[i];
         }
         wq = wn;
     }
@@ -246,9 +246,9 @@ __device__ __forceinline__ void l3_pass_bf3(const __amdgpu_buffer_rsrc_t& rs, in
             }
         } else {
             float m = max16(acc0);
-            if (MTS == 2) m = max2_raw(m, max16(acc1));
+            if (MTS == 2) m = fmaxf(m, max16(acc1));
 #pragma unroll
-            for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? max2_raw(runmax[i], m) : runmax[i];
+            for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? fmaxf(runmax[i], m) : runmax[i];
         }
     }
 }
@@ -287,9 +287,9 @@ __device__ __forceinline__ void l3_pass_bf3_2x2(const __amdgpu_buffer_rsrc_t& rs
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float m = max16(acc[0][j]);
-            if (MTS == 2) m = max2_raw(m, max16(acc[MTS - 1][j]));
+            if (MTS == 2) m = fmaxf(m, max16(acc[MTS - 1][j]));
 #pragma unroll
-            for (int i = 0; i < 8; ++i) runmax[i] = (i == 2 * qp + j) ? max2_raw(runmax[i], m) : runmax[i];
+            for (int i = 0; i < 8; ++i) runmax[i] = (i == 2 * qp + j) ? fmaxf(runmax[i], m) : runmax[i];
         }
     }
 }
@@ -345,7 +345,7 @@ __device__ __forceinline__ void l3_tail16(const WBuf& w3, const float* act2, int
         m0 = fmaxf(m0, __shfl_xor(m0, 32)); m1 = fmaxf(m1, __shfl_xor(m1, 32));
         const float m = (lane & 16) ? m1 : m0;            // lane l keeps column l & 31 of the n-tile, as the 32x32 path does
 #pragma unroll
-        for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? max2_raw(runmax[i], m) : runmax[i];
+        for (int i = 0; i < 8; ++i) runmax[i] = (i == q) ? fmaxf(runmax[i], m) : runmax[i];
         wq = wn;
     }
 }

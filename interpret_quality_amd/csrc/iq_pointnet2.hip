@@ -190,8 +190,8 @@ __device__ __forceinline__ TileMax reduce_tile(f32x16 acc, float bias) {
     TileMax m;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float x = max2_raw(max3_raw(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2]), acc[4 * q + 3]);   // (no canonicalising v_max: iq_mfma.h)
-        x = max2_raw(x, __shfl_xor(x, 32));
+        float x = fmaxf(fmaxf(acc[4 * q], acc[4 * q + 1]), fmaxf(acc[4 * q + 2], acc[4 * q + 3]));
+        x = fmaxf(x, __shfl_xor(x, 32));
         m.v[q] = fmaxf(x + bias, 0.f);
     }
     return m;
