@@ -21,7 +21,7 @@ ARCH = "gfx950"
 NO_CONTRACT = ("iq_geom.hip", "iq_pointnet2.hip", "iq_dgcnn.hip", "iq_pointconv.hip", "iq_smooth.hip")
 # The PointNet chain kernel pools with fmaxf over MFMA results; without -fno-honor-nans every such operand gets a canonicalising
 # v_max_f32 x, x, x first (iq_mfma.h, max16).  The file holds no index-valued kernel and no NaN test.
-NO_NANS = ("iq_pointnet.hip",)
+NO_NANS = ("iq_pointnet.hip", "iq_linear.hip", "iq_dgcnn.hip")
 # Packed float32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) are switched OFF for the whole library: the
 # gfx950 subtarget feature `packed-fp32-ops` is removed for the device compile, so instruction selection cannot emit them
 # whatever the SLP vectoriser or an explicit float2 expression asks for (tests/test_isa_cpu.py disassembles the .so that ships
