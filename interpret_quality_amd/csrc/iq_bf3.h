@@ -9,6 +9,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct B3 { bf16x8 h, m, l; };
 
@@ -73,11 +74,59 @@ __device__ __forceinline__ void row4_to_planes(unsigned char* dst, f32x4 v) {
     const unsigned h0 = bf16_pair(v[0], v[1]), h1 = bf16_pair(v[2], v[3]);
     const float r0 = v[0] - bf16_lo(h0), r1 = v[1] - bf16_hi(h0), r2 = v[2] - bf16_lo(h1), r3 = v[3] - bf16_hi(h1);
     const unsigned m0 = bf16_pair(r0, r1), m1 = bf16_pair(r2, r3);
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
     *reinterpret_cast<u32x2*>(dst + PLANEB) = u32x2{m0, m1};
     *reinterpret_cast<u32x2*>(dst + 2 * PLANEB) =
         u32x2{bf16_pair(r0 - bf16_lo(m0), r1 - bf16_hi(m0)), bf16_pair(r2 - bf16_lo(m1), r3 - bf16_hi(m1))};
+}
+
+// four float32 values -> their three bf16 terms, packed two per dword (element 2 p in the low half)
+__device__ __forceinline__ void split4(f32x4 v, u32x2& h, u32x2& m, u32x2& l) {
+    const unsigned h0 = bf16_pair(v[0], v[1]), h1 = bf16_pair(v[2], v[3]);
+    const float r0 = v[0] - bf16_lo(h0), r1 = v[1] - bf16_hi(h0), r2 = v[2] - bf16_lo(h1), r3 = v[3] - bf16_hi(h1);
+    const unsigned m0 = bf16_pair(r0, r1), m1 = bf16_pair(r2, r3);
+    h = u32x2{h0, h1};
+    m = u32x2{m0, m1};
+    l = u32x2{bf16_pair(r0 - bf16_lo(m0), r1 - bf16_hi(m0)), bf16_pair(r2 - bf16_lo(m1), r3 - bf16_hi(m1))};
+}
+
+// The TRANSPOSED C tile of a layer whose output goes back to LDS as an activation image (round 5): with the weight fragment as the
+// A operand and the activation fragment as B - the same two fragments, swapped - lane (row = lane & 31 of the m-tile, half) holds its
+// row's channels 8 g + 4 half + 0..3 in registers 4 g .. 4 g + 3: four consecutive channels per register quad, so the three bf16
+// planes take whole 8-byte stores and the two-lane DPP trade of c_tile_to_planes (4 VALU per value pair) is not needed.
+// `tile`: plane 0, first row of the m-tile, first channel of the n-tile; value(r): register r after bias / activation, where
+// register r is channel c_row_i(r) + 4 * (lane >> 5) of the n-tile.
+template <int ROWB, int PLANEB, typename F>
+__device__ __forceinline__ void ct_tile_to_planes(unsigned char* tile, int lane, F value) {
+    unsigned char* d = tile + (lane & 31) * ROWB + 8 * (lane >> 5);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        u32x2 h, m, l;
+        split4(f32x4{value(4 * g), value(4 * g + 1), value(4 * g + 2), value(4 * g + 3)}, h, m, l);
+        unsigned char* o = d + g * 16;
+        *reinterpret_cast<u32x2*>(o) = h;
+        *reinterpret_cast<u32x2*>(o + PLANEB) = m;
+        *reinterpret_cast<u32x2*>(o + 2 * PLANEB) = l;
+    }
+}
+
+// transposed six-product k-step over MT m-tiles and ONE n-tile: the weight fragment as the A operand, the activation terms as B;
+// term-major over the tiles (a dependent MFMA is MT instructions away), small terms first, the same products in the same order
+// as mfma_bf3_block<MT, 1>
+template <int TW, int TX, int MT>
+__device__ __forceinline__ void mfma_term_block_tr(const B3& w, const bf16x8 (&x)[MT][3], f32x16 (&acc)[MT][1]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(TW == 0 ? w.h : (TW == 1 ? w.m : w.l), x[i][TX], acc[i][0], 0, 0, 0);
+}
+template <int MT>
+__device__ __forceinline__ void mfma_bf3_block_tr(const bf16x8 (&x)[MT][3], const B3& w, f32x16 (&acc)[MT][1]) {
+    mfma_term_block_tr<0, 2, MT>(w, x, acc);   // (activation l) x (weight h)
+    mfma_term_block_tr<2, 0, MT>(w, x, acc);   // (activation h) x (weight l)
+    mfma_term_block_tr<1, 1, MT>(w, x, acc);
+    mfma_term_block_tr<0, 1, MT>(w, x, acc);   // (activation m) x (weight h)
+    mfma_term_block_tr<1, 0, MT>(w, x, acc);   // (activation h) x (weight m)
+    mfma_term_block_tr<0, 0, MT>(w, x, acc);
 }
 
 // MT x NT tiles of one k-step: six products per tile, the tiles' accumulation chains interleaved (a dependent MFMA is MT * NT

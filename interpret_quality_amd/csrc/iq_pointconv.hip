@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_kernel(PcGroupArgs a) {
 // activations as three bf16 planes of 272-byte rows, act1 and act2 in ONE 52 KB image (layer 2's tiles wait in registers for
 // the barrier), layer 3 as 2 x 2 tiles per wave, weights through small register rings.  The contraction over the members stays
 // on v_mfma_f32_16x16x4_f32 (float32 operands straight out of the accumulators).
-template <int MTS>
+template <int MTS, bool TR>   // TR: transposed tiles (weights as the A operand), as gb_layer2 in iq_pointnet2.hip
 __device__ __forceinline__ void pcb_layer2(const unsigned char* abase, const __amdgpu_buffer_rsrc_t& rs, int voff, int nt,
                                            B3 (&ring)[4], f32x16 (&acc)[MTS][1]) {
     constexpr int ROWB = 272, PLANEB = 64 * ROWB, TS = 4 * 8 * 1024;
@@ -423,7 +423,8 @@ __device__ __forceinline__ void pcb_layer2(const unsigned char* abase, const __a
         for (int i = 0; i < MTS; ++i) a3_load<PLANEB>(af[i], abase + i * 32 * ROWB, ks);
         const B3 b[1] = {ring[ks & 3]};
         if (ks + 4 < 8) ring[ks & 3] = b3_load_at(rs, voff, (nt * 8 + ks + 4) * 1024, TS);
-        mfma_bf3_block<MTS, 1>(af, b, acc);
+        if (TR) mfma_bf3_block_tr<MTS>(af, b[0], acc);
+        else mfma_bf3_block<MTS, 1>(af, b, acc);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -446,6 +447,9 @@ __device__ __forceinline__ void pcb_layer3(const unsigned char* abase, const __a
     }
 }
 
+// TR (the default): layer 2's tiles transposed - act2 stored with whole 8-byte stores, no two-lane DPP trade (tuning key 7 = 1: the
+// untransposed form; same products in the same order).
+template <bool TR>
 __global__ __launch_bounds__(kThreads, 2) void pc_group_bf3_kernel(PcGroupArgs a) {
     constexpr int C1 = 128, C3 = 256, ROWB = 272, PLANEB = kMC * ROWB, LDS_SW = kMC + 2;
     constexpr int Q1 = C1 / 4, NR = kMC * Q1 / kThreads;
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_bf3_kernel(PcGroupArgs a
         __syncthreads();  // act1 complete
         // ---- layer 2: tiles (m-tile 0..1, n-tile = wave) kept in registers ---------------------------------------------------
         f32x16 acc2[2][1] = {{{0}}, {{0}}};
-        pcb_layer2<2>(abase, w2rs, voff, wave_s, ring2, acc2);
+        pcb_layer2<2, TR>(abase, w2rs, voff, wave_s, ring2, acc2);
         PcB3x2 ring3[2];                             // layer 3's weights (n-tiles wave, wave + 4), in flight across the epilogue
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -531,9 +535,17 @@ __global__ __launch_bounds__(kThreads, 2) void pc_group_bf3_kernel(PcGroupArgs a
         if (ch + 1 < nchunks) stage0a(ch + 1, nxt);
         __syncthreads();  // every wave has read act1: the image is free
         {
-            const float bias = a.b2[wave * 32 + fl];
-            c_tile_to_planes<ROWB, PLANEB>(planes + wave * 64, lane, [&](int i) { return fmaxf(acc2[0][0][i] + bias, 0.f); });
-            c_tile_to_planes<ROWB, PLANEB>(planes + 32 * ROWB + wave * 64, lane, [&](int i) { return fmaxf(acc2[1][0][i] + bias, 0.f); });
+            if (TR) {   // register r = channel c_row_i(r) + 4 fh of this wave's n-tile
+                f32x4 bq[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(a.b2 + wave * 32 + 8 * g + 4 * fh);
+                ct_tile_to_planes<ROWB, PLANEB>(planes + wave * 64, lane, [&](int r) { return fmaxf(acc2[0][0][r] + bq[r >> 2][r & 3], 0.f); });
+                ct_tile_to_planes<ROWB, PLANEB>(planes + 32 * ROWB + wave * 64, lane, [&](int r) { return fmaxf(acc2[1][0][r] + bq[r >> 2][r & 3], 0.f); });
+            } else {
+                const float bias = a.b2[wave * 32 + fl];
+                c_tile_to_planes<ROWB, PLANEB>(planes + wave * 64, lane, [&](int i) { return fmaxf(acc2[0][0][i] + bias, 0.f); });
+                c_tile_to_planes<ROWB, PLANEB>(planes + 32 * ROWB + wave * 64, lane, [&](int i) { return fmaxf(acc2[1][0][i] + bias, 0.f); });
+            }
         }
         __syncthreads();  // act2 complete; rel[nxt] / swT[nxt] visible
         if (ch + 1 < nchunks) gather_u(nxt);                                // consumed after layer 3
@@ -1096,7 +1108,10 @@ int launch_pc_group(const iq_pointconv_sa& sa, const float* xyz, const float* ne
         // contraction's 16x16x4 tiles
         iq::ProfileSpan dom(iq::kSlotDominant, st, 2.0 * (double)B * S * K * ((double)c1 * c2 + (double)c2 * c3 + 16.0 * c3));
         if (a.w2_bf3 && a.w3_bf3 && iq::tuning(iq::kTuneExperiment) != 56)   // 5 = 56: the fp32-MFMA kernel (A/B and tests)
-            hipLaunchKernelGGL(pc_group_bf3_kernel, grid, dim3(kThreads), 0, st, a);
+        {
+            if (!iq::tuning(iq::kTuneNoTranspose)) hipLaunchKernelGGL(pc_group_bf3_kernel<true>, grid, dim3(kThreads), 0, st, a);
+            else hipLaunchKernelGGL(pc_group_bf3_kernel<false>, grid, dim3(kThreads), 0, st, a);
+        }
         else
             hipLaunchKernelGGL((pc_group_kernel<128, 128, 256>), grid, dim3(kThreads), 0, st, a);
     }

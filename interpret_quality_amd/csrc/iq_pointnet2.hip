@@ -437,7 +437,8 @@ __global__ __launch_bounds__(kThreads, WPS) void pn2_group_kernel(GroupArgs a) {
 // values instead of value by value (the compiler's schedule is one dependent chain after the other on two or three temporaries):
 // bit-identical, no change (81.5 / 81.9 k; PointConv 85.0 / 84.9 k; chain kernel 781.2 / 781.7 k).
 __device__ unsigned long long g_gb_dbg[12];
-template <int MTS>
+// TR: the TRANSPOSED tiles (weights as the A operand, iq_bf3.h ct_tile_to_planes): same fragments, same products, swapped operands
+template <int MTS, bool TR>
 __device__ __forceinline__ void gb_layer2(const unsigned char* abase, const __amdgpu_buffer_rsrc_t& rs, int voff, int nt,
                                           B3 (&ring)[4], f32x16 (&acc)[MTS][1]) {
     constexpr int ROWB = 272, PLANEB = 64 * ROWB, TS = 4 * 8 * 1024;
@@ -448,7 +449,8 @@ __device__ __forceinline__ void gb_layer2(const unsigned char* abase, const __am
         for (int i = 0; i < MTS; ++i) a3_load<PLANEB>(af[i], abase + i * 32 * ROWB, ks);
         const B3 b[1] = {ring[ks & 3]};
         if (ks + 4 < 8) ring[ks & 3] = b3_load_at(rs, voff, (nt * 8 + ks + 4) * 1024, TS);
-        mfma_bf3_block<MTS, 1>(af, b, acc);
+        if (TR) mfma_bf3_block_tr<MTS>(af, b[0], acc);
+        else mfma_bf3_block<MTS, 1>(af, b, acc);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -472,7 +474,9 @@ __device__ __forceinline__ void gb_layer3(const unsigned char* abase, const __am
     }
 }
 
-template <bool STAMP>   // STAMP: diagnostic build (tuning key 5 = 79)
+// TR (the default): layer 2's tiles transposed, so that act2 is stored with whole 8-byte stores and without the two-lane DPP trade
+// (tuning key 7 = 1: the untransposed form; same products in the same order).
+template <bool STAMP, bool TR>   // STAMP: diagnostic build (tuning key 5 = 79)
 __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a) {
     constexpr int C1 = 128, kMC = 64, ROWB = 272, PLANEB = kMC * ROWB, BPC = kMC / kBlk;
     __shared__ __attribute__((aligned(16))) unsigned char planes[3 * PLANEB];   // act1, then act2: three bf16 planes [64][136]
@@ -599,10 +603,10 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
         // ---- layer 2: 128 -> 128, tiles (m-tile 0..1, n-tile = wave) kept in registers -------------------
         f32x16 acc2[2][1] = {{{0}}, {{0}}};
         if (mts == 2) {
-            gb_layer2<2>(abase, w2rs, voff, wave_s, ring2, acc2);
+            gb_layer2<2, TR>(abase, w2rs, voff, wave_s, ring2, acc2);
         } else {
             f32x16 one[1][1] = {{{0}}};
-            gb_layer2<1>(abase, w2rs, voff, wave_s, ring2, one);
+            gb_layer2<1, TR>(abase, w2rs, voff, wave_s, ring2, one);
             acc2[0][0] = one[0][0];
         }
         B3x2 ring3[2];                               // layer 3's weights (n-tiles wave, wave + 4), in flight across the epilogue
@@ -617,10 +621,20 @@ __global__ __launch_bounds__(kThreads, 2) void pn2_group_bf3_kernel(GroupArgs a)
         __syncthreads();  // every wave has read act1: the image is free
         stamp(5);   // wait
         {
-            const float bias = a.b2[wave * 32 + fl];
-            c_tile_to_planes<ROWB, PLANEB>(planes + wave * 64, lane, [&](int i) { return fmaxf(acc2[0][0][i] + bias, 0.f); });
-            if (mts == 2)
-                c_tile_to_planes<ROWB, PLANEB>(planes + 32 * ROWB + wave * 64, lane, [&](int i) { return fmaxf(acc2[1][0][i] + bias, 0.f); });
+            if (TR) {   // register r = channel c_row_i(r) + 4 fh of this wave's n-tile: the biases of the lane's 16 channels
+                f32x4 bq[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(a.b2 + wave * 32 + 8 * g + 4 * fh);
+                ct_tile_to_planes<ROWB, PLANEB>(planes + wave * 64, lane, [&](int r) { return fmaxf(acc2[0][0][r] + bq[r >> 2][r & 3], 0.f); });
+                if (mts == 2)
+                    ct_tile_to_planes<ROWB, PLANEB>(planes + 32 * ROWB + wave * 64, lane,
+                                                    [&](int r) { return fmaxf(acc2[1][0][r] + bq[r >> 2][r & 3], 0.f); });
+            } else {
+                const float bias = a.b2[wave * 32 + fl];
+                c_tile_to_planes<ROWB, PLANEB>(planes + wave * 64, lane, [&](int i) { return fmaxf(acc2[0][0][i] + bias, 0.f); });
+                if (mts == 2)
+                    c_tile_to_planes<ROWB, PLANEB>(planes + 32 * ROWB + wave * 64, lane, [&](int i) { return fmaxf(acc2[1][0][i] + bias, 0.f); });
+            }
         }
         stamp(6);   // layer 2 epilogue
         __syncthreads();  // act2 complete; rel[nxt] visible
@@ -697,9 +711,10 @@ int launch_group_t(GroupArgs a, int B, hipStream_t st) {
     if (C1 == 128 && C2 == 128 && C3 == 256 && a.w2_bf3 && a.w3_bf3 && iq::tuning(iq::kTuneExperiment) != 56 &&
         iq::tuning(iq::kTuneExperiment) != 64)    // 5 = 56 / 64: the fp32-MFMA kernel with 32- / 64-row chunks (A/B and tests)
     {
-        if (a.probe != 79) hipLaunchKernelGGL(pn2_group_bf3_kernel<false>, grid, dim3(kThreads), 0, st, a);
+        if (a.probe != 79 && !iq::tuning(iq::kTuneNoTranspose)) hipLaunchKernelGGL((pn2_group_bf3_kernel<false, true>), grid, dim3(kThreads), 0, st, a);
+        else if (a.probe != 79) hipLaunchKernelGGL((pn2_group_bf3_kernel<false, false>), grid, dim3(kThreads), 0, st, a);
         else {   // diagnostic: synchronous
-            hipLaunchKernelGGL(pn2_group_bf3_kernel<true>, grid, dim3(kThreads), 0, st, a);
+            hipLaunchKernelGGL((pn2_group_bf3_kernel<true, true>), grid, dim3(kThreads), 0, st, a);
             unsigned long long h[12];
             (void)hipStreamSynchronize(st);
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gb_dbg), sizeof(h));

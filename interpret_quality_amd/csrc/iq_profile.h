@@ -12,7 +12,7 @@ enum ProfileSlot { kSlotPrepool = 0, kSlotFstn = 1, kSlotTrunk = 2, kSlotCall = 
 bool profile_enabled();
 
 // Experiment knobs (iq_set_tuning): A/B kernel variants inside one process (guide rule 24).
-enum TuneKey { kTuneL3Variant = 0, kTuneExtraLds = 1, kTuneNoLpt = 2, kTuneNoLdsGemm = 3, kTuneKnnDebug = 4, kTuneExperiment = 5, kTuneGroupBlocks = 6, kTuneSpare7 = 7, kTuneCount = 8 };
+enum TuneKey { kTuneL3Variant = 0, kTuneExtraLds = 1, kTuneNoLpt = 2, kTuneNoLdsGemm = 3, kTuneKnnDebug = 4, kTuneExperiment = 5, kTuneGroupBlocks = 6, kTuneNoTranspose = 7, kTuneCount = 8 };
 int tuning(int key);
 
 class ProfileSpan {
