@@ -110,6 +110,17 @@ __device__ __forceinline__ void ct_tile_to_planes(unsigned char* tile, int lane,
     }
 }
 
+// one tile, transposed: the six products of mfma_bf3 with the operands swapped (weights = A operand)
+__device__ __forceinline__ f32x16 mfma_bf3_tr(const B3& w, const bf16x8 (&x)[3], f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, x[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.m, x[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, x[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.m, x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, x[0], acc, 0, 0, 0);
+    return acc;
+}
+
 // transposed six-product k-step over MT m-tiles and ONE n-tile: the weight fragment as the A operand, the activation terms as B;
 // term-major over the tiles (a dependent MFMA is MT instructions away), small terms first, the same products in the same order
 // as mfma_bf3_block<MT, 1>

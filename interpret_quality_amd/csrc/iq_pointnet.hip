@@ -490,13 +490,21 @@ __global__ __launch_bounds__(kThreads, L3V == 3 ? 2 : 3) void pn_chain_kernel(Ch
                 f32x16 acc = {0};
 #pragma unroll
                 for (int kb = 0; kb < 8; ++kb) {
-                    acc = mfma4(lds_frag<kLd1>(a1base_A + mt * 32 * kLd1, 0, kb), bw[kb], acc);
+                    // L3V = 3: TRANSPOSED tile (the weight fragment as the A operand: iq_bf3.h, ct_tile_to_planes) - the same products in
+                    // the same order, the lane then holds its row's channels in register quads and act1 needs no two-lane trade
+                    if (L3V == 3) acc = mfma4(bw[kb], lds_frag<kLd1>(a1base_A + mt * 32 * kLd1, 0, kb), acc);
+                    else acc = mfma4(lds_frag<kLd1>(a1base_A + mt * 32 * kLd1, 0, kb), bw[kb], acc);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                const float bias = (MODE == kFstn) ? a.b1[nt * 32 + frag_lane] : 0.f;
-                if (L3V == 3) {   // act1 as three bf16 planes for layer 2
-                    c_tile_to_planes<kLd1B, kPlane1B>(reinterpret_cast<unsigned char*>(bufB) + mt * 32 * kLd1B + nt * 64, lane, [&](int i) {
-                        const float v = acc[i] + bias;
+                const float bias = (MODE == kFstn && L3V != 3) ? a.b1[nt * 32 + frag_lane] : 0.f;
+                if (L3V == 3) {   // act1 as three bf16 planes for layer 2; register r = channel c_row_i(r) + 4 frag_h of the n-tile
+                    f32x4 bq[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                    if (MODE == kFstn) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(a.b1 + nt * 32 + 8 * g + 4 * frag_h);
+                    }
+                    ct_tile_to_planes<kLd1B, kPlane1B>(reinterpret_cast<unsigned char*>(bufB) + mt * 32 * kLd1B + nt * 64, lane, [&](int r) {
+                        const float v = acc[r] + bq[r >> 2][r & 3];
                         return (MODE == kFstn) ? fmaxf(v, 0.f) : v;
                     });
                 } else {
@@ -534,12 +542,14 @@ __global__ __launch_bounds__(kThreads, L3V == 3 ? 2 : 3) void pn_chain_kernel(Ch
                         const int t = pass * 4 + ks, nx = t + PF;
                         const B3 b = bw[t % PF];
                         if (nx < 8) bw[t % PF] = b3_load_l2(w2rs, lane * 16, nts + 2 * (nx >> 2), nx & 3);
-                        acc = mfma_bf3(af, b, acc);
+                        acc = mfma_bf3_tr(b, af, acc);      // transposed tile, as layer 1
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    const float bias = a.b2[nt0 * 32 + pass * 64 + frag_lane];
-                    c_tile_to_planes<kLdB, kPlaneB>(reinterpret_cast<unsigned char*>(bufA) + mt * 32 * kLdB + (nt0 * 32 + pass * 64) * 2, lane,
-                                                    [&](int i) { return fmaxf(acc[i] + bias, 0.f); });
+                    f32x4 bq[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(a.b2 + nt0 * 32 + pass * 64 + 8 * g + 4 * frag_h);
+                    ct_tile_to_planes<kLdB, kPlaneB>(reinterpret_cast<unsigned char*>(bufA) + mt * 32 * kLdB + (nt0 * 32 + pass * 64) * 2, lane,
+                                                     [&](int r) { return fmaxf(acc[r] + bq[r >> 2][r & 3], 0.f); });
                 }
             }
         } else {

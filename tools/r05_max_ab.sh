@@ -7,7 +7,7 @@ d=json.loads(sys.stdin.read().strip().split('\n')[-1]); r=d['roofline']
 print('headline %.0f coalitions/s, %.2f ms/step, chain launch %.3f ms' % (d['value'], d['ms_per_step'], r.get('avg_launch_ms')))"; }
 for rep in 1 2 3; do
   echo "pointnet previous : $(IQ_LIBPATH=$OLD hl)"
-  echo "pointnet no-nans   : $(hl)"
+  echo "pointnet transposed: $(hl)"
 done
 for rep in 1 2 3; do
   echo "pointnet2 previous: $(IQ_LIBPATH=$OLD python3 tools/bench_models.py --model pointnet2 --mode shapley --steps 8 2>&1 | tail -1 | cut -c1-200)"
