@@ -344,7 +344,7 @@ def measure_traffic():
             d = os.path.join(tmp, counter)
             cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--repeats", "1", "--min-region-s", "0", "--profile-steps", "1",
-                   "--cpu-baseline", "0", "--other-models", "0", "--eager-baseline", "0", "--traffic", "0", "--strong-steps", "0"]
+                   "--cpu-baseline", "0", "--other-models", "0", "--eager-baseline", "0", "--traffic", "0", "--strong-steps", "0", "--sustained-s", "0"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:

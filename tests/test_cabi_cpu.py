@@ -123,7 +123,9 @@ def test_ctypes_structures_have_the_layout_of_the_header(tmp_path):
              "iq_pointnet2_weights": _lib.PointNet2Weights, "iq_pointconv_sa": _lib.PointConvSa,
              "iq_pointconv_weights": _lib.PointConvWeights, "iq_dgcnn_weights": _lib.DgcnnWeights,
              "iq_smoothness_params": _lib.SmoothnessParams}
-    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "iq.h"', 'int main(void) {']
+    # (iq_debug.h - the diagnostics - must be plain C too and pulls iq.h in; IQ_ABI_VERSION is what iq_version() returns)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "iq_debug.h"', '#if IQ_ABI_VERSION < 101', '#error "ABI version"', '#endif',
+             'int main(void) {']
     for cname, cls in pairs.items():
         lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
         for fname, _ in cls._fields_:
