@@ -35,7 +35,9 @@ int iq_profile_read_work(int slot, double* total_ms, int* launches, double* tota
  * LDS-staged GEMM (pn_gemm_lds_kernel), only the register-streaming one; 4 = kNN diagnostics (results are NOT valid
  * except for 3): 1 queue appends without insertion rounds, 2 no selection at all (MFMA + load skeleton), 3 normal
  * selection + round / busy-lane counters returned in the first 24 bytes of iq_knn's tmp (tools/knn_probe.py);
- * 6 = 16-row member blocks per workgroup of the PointNet++ grouped kernel (0 = default 12). */
+ * 6 = 16-row member blocks per workgroup of the PointNet++ grouped kernel (0 = default 12); 7 = 1: layer 2 of the grouped bf16x3
+ * kernels with untransposed tiles (round 4's epilogue; bit-identical results, tools/r05_tr_ab.sh).  Key 5 also selects the fp32-MFMA
+ * twins of the bf16x3 kernels (53 / 54 / 56 / 57) and the timing probes of the chain kernel's layer 3 (91 / 92 / 93: results WRONG). */
 int iq_set_tuning(int key, int value);
 /* Debug: workgroups per CU the runtime admits for the chain kernel variants (100*v0 + v2). */
 int iq_debug_chain_occupancy(void);
