@@ -332,7 +332,9 @@ int iq_pointnet2_coalitions(const iq_pointnet2_weights* w, const float* clouds, 
 
 /* models/dgcnn.py:12-18 (knn): the k = 20 largest of -|x_i|^2 - (-2 x_i.x_j) - |x_j|^2 per row, self
  * included, as an (unordered) index set.  x (B,N,C) row-major with C in {3, 64, 128}; idx (B,N,20)
- * int32; tmp = scratch of at least B*N*84 + 16*B + 8192 bytes.
+ * int32; tmp = scratch of at least B*N*84 + 16*B + 8192 bytes; with B*N*C*6 bytes more (C = 64, 128) the inner products run on
+ * the bf16 matrix pipe as three-term bf16 products, float32-accurate, as they do inside iq_dgcnn_* (csrc/iq_dgcnn.hip: knn_kernel
+ * <.., BF3>; iq_set_tuning(5, 22): the fp32 MFMA kernels).  Both arithmetics stand in front of the same exact re-ranking:
  * Feature-space graphs (C = 64, 128): where the float32 expanded form cannot separate the 20th from the 21st nearest
  * (gap below 1e-5 of the magnitude of the summed terms: rounding noise decides for the reference's float32 path too), the
  * query's 21 best candidates are re-ranked by -sum (x_i - x_j)^2 accumulated in float64, i.e. the order the reference

@@ -19,6 +19,7 @@
 // are unchanged; the mean pool weights the centre by M.  Exact, and the kNN work drops
 // with the square of the kept fraction.  All kernels below run on the ragged layout (row offsets per cloud); the dense
 // forward is the special case D_b = N.
+#include "iq_bf3.h"
 #include "iq_common.h"
 #include "iq_mfma.h"
 #include "iq_profile.h"
@@ -158,13 +159,19 @@ __global__ __launch_bounds__(64) void dg_compact_kernel(const float* __restrict_
 // 64 rows per workgroup; 32-channel slices go through a small LDS tile (coalesced float4 reads, many workgroups per
 // CU) and each row is still summed sequentially over its channels by one lane - the order the golden kNN sets were
 // produced with.  Dead (padding) rows get +inf: as keys they then score -inf and are never selected.
+// `planes` (C = 64 / 128, or null): the same rows as three bf16 terms (iq_bf3.h) in MFMA fragment order, for knn_kernel<.., BF3>:
+// fragment (term, 32-row tile, k-step of 16) = 1 KiB at ((term * term_tiles + tile) * C / 16 + k-step) KiB, lane (row & 31) +
+// 32 * (k-half) at 16 bytes - a key tile's operand is then ONE fully coalesced 1 KiB load per term and k-step, and the query tile's
+// operand is the same image.  Written from the registers the norm's loads already hold (6 bytes per value, no second read).
 __global__ __launch_bounds__(kThreads) void rownorm_kernel(const float* __restrict__ x, int ldx, int C, float* __restrict__ xx,
-                                                           Ragged rg, int B) {
+                                                           Ragged rg, int B, unsigned char* __restrict__ planes, int term_tiles) {
     __shared__ float tile[64 * 33];
     const int rows = rg.roff[B];
     const int r0 = blockIdx.x * 64;
     if (r0 >= rows) return;
     const int tid = threadIdx.x;
+    const int KS = C >> 4;
+    const size_t term_bytes = (size_t)term_tiles * KS * 1024;
     float s = 0.f;
     for (int c0 = 0; c0 < C; c0 += 32) {
         const int cw = min(32, C - c0);
@@ -176,6 +183,15 @@ __global__ __launch_bounds__(kThreads) void rownorm_kernel(const float* __restri
                 if (r0 + row < rows) v = *reinterpret_cast<const f32x4*>(x + (size_t)(r0 + row) * ldx + c0 + c4 * 4);
                 float* t = tile + row * 33 + c4 * 4;
                 t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+                if (planes && r0 + row < rows) {
+                    const int c = c0 + c4 * 4, r = r0 + row;
+                    unsigned char* d = planes + ((size_t)(r >> 5) * KS + (c >> 4)) * 1024 + ((r & 31) + 32 * ((c >> 3) & 1)) * 16 + (c & 7) * 2;
+                    u32x2 h, m, l;
+                    split4(v, h, m, l);
+                    *reinterpret_cast<u32x2*>(d) = h;
+                    *reinterpret_cast<u32x2*>(d + term_bytes) = m;
+                    *reinterpret_cast<u32x2*>(d + 2 * term_bytes) = l;
+                }
             }
         } else {
             for (int e = tid; e < 64 * cw; e += kThreads) {
@@ -294,11 +310,18 @@ __global__ void knn_dbg_fetch_kernel(unsigned long long* dst) {
 // is FLAGGED: near_tie[row] holds its 21st candidate (else -1), its neighbour list the other 20 as raw rows, and
 // knn_refine_kernel re-ranks the 21 in exact arithmetic (bit 20 of the word: the gap is exactly zero - identical rows, as in
 // a dense masked cloud, may hide further candidates - so all rows are ranked).
-template <int C, bool REFINE, int PF = 1, int QCAP = 16>
-__global__ __launch_bounds__(64, C == 128 ? (QCAP < 16 ? 3 : 2) : (QCAP < 16 ? 4 : 3)) void knn_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ xx,
+// BF3 (round 5, C = 64 / 128): the inner products on the bf16 matrix pipe, float32-accurate - keys and queries as three bf16 terms
+// each (the fragment image rownorm_kernel writes), six exact products per k-step of 16 accumulated in float32 (iq_bf3.h): 192 matrix
+// cycles per 16 k instead of 512, a key tile's operand three coalesced 1 KiB loads per k-step.  The scores differ from the fp32
+// MFMA's in the last bits only (both within float32 rounding of the exact inner product, the bf16x3 ones closer), which is what
+// REFINE's margin covers; the selection, the flags and the epilogue are untouched.
+template <int C, bool REFINE, int PF = 1, int QCAP = 16, bool BF3 = false>
+__global__ __launch_bounds__(64, BF3 ? (C == 128 ? 2 : 3) : C == 128 ? (QCAP < 16 ? 3 : 2) : (QCAP < 16 ? 4 : 3)) void knn_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ xx,
                                                  int16_t* __restrict__ idx, int32_t* __restrict__ near_tie, Ragged rg, int B,
-                                                 int tiles_per_cloud, int dbg) {
+                                                 int tiles_per_cloud, int dbg, const unsigned char* __restrict__ planes, int term_tiles) {
+    static_assert(!BF3 || (REFINE && C % 16 == 0 && C >= 32), "bf16x3 distances: feature-space graphs only");
     constexpr int KB = C / 8;
+    constexpr int KS = C / 16;                     // BF3: k-steps of 16
     constexpr int KL = REFINE ? kK + 1 : kK;   // list length
     // REFINE: the integer list with tagged indices (iq_topk.h: TaggedTopK) - its 32-ulp buckets lie far inside the band that
     // knn_refine_kernel re-ranks exactly; the exact-only kernel keeps the packed fp64 list
@@ -321,10 +344,24 @@ __global__ __launch_bounds__(64, C == 128 ? (QCAP < 16 ? 3 : 2) : (QCAP < 16 ? 4
     const int fl = lane & 31, fh = lane >> 5;
 
     // B operand: queries, stationary in registers
-    f32x4 qf[KB];
+    f32x4 qf[BF3 ? 1 : KB];
+    bf16x8 qx[BF3 ? KS : 1][3];
+    __amdgpu_buffer_rsrc_t prs[3];                  // BF3: this cloud's tiles of the fragment image, one resource per term
+    if constexpr (BF3) {
+        const size_t term_bytes = (size_t)term_tiles * KS * 1024;
+        const unsigned char* pb = planes + (size_t)(base >> 5) * KS * 1024;
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
-        qf[kb] = *reinterpret_cast<const f32x4*>(xb + (size_t)(q0 + fl) * ldx + 8 * kb + 4 * fh);
+        for (int e = 0; e < 3; ++e) {
+            prs[e] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(pb + e * term_bytes), 0, (N >> 5) * KS * 1024, 0x00020000);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                qx[ks][e] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(prs[e], lane * 16, ((q0 >> 5) * KS + ks) * 1024, 0));
+        }
+    } else {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+            qf[kb] = *reinterpret_cast<const f32x4*>(xb + (size_t)(q0 + fl) * ldx + 8 * kb + 4 * fh);
+    }
     const float xxq = xxb[q0 + fl];
 
     Sel sel;
@@ -364,8 +401,21 @@ __global__ __launch_bounds__(64, C == 128 ? (QCAP < 16 ? 3 : 2) : (QCAP < 16 ? 4
     // key fragments PF k-blocks ahead of the MFMAs (PF = 1: the next one only, 256 MFMA cycles - less than an L2 round trip)
     static_assert(PF >= 1 && PF <= KB && (PF & (PF - 1)) == 0 && KB % PF == 0, "prefetch depth");
     f32x4 ring[PF];
+    // BF3: the three terms of a key tile's k-step, PF k-steps (192 matrix cycles each) ahead
+    auto key_frag3 = [&](int t, int ks) {
+        const int o = (t * KS + ks) * 1024;
+        return B3{__builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(prs[0], lane * 16, o, 0)),
+                  __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(prs[1], lane * 16, o, 0)),
+                  __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(prs[2], lane * 16, o, 0))};
+    };
+    B3 ring3[BF3 ? PF : 1];
+    if constexpr (BF3) {
 #pragma unroll
-    for (int i = 0; i < PF; ++i) ring[i] = key_frag(2 * p0, i);
+        for (int i = 0; i < PF; ++i) ring3[i] = key_frag3(2 * p0, i);
+    } else {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) ring[i] = key_frag(2 * p0, i);
+    }
     kxs[lane] = kx_pair(p0);                                       // wave-private: no barrier (one wave per workgroup)
     float kx_next = kx_pair(pair_at(1));
     // ONE loop (a small state machine) instead of rounds nested in the tile loop: the 20-entry list is then carried
@@ -392,11 +442,20 @@ __global__ __launch_bounds__(64, C == 128 ? (QCAP < 16 ? 3 : 2) : (QCAP < 16 ? 4
             const int pnext = pair_at(k + 1);
             const int tn = pair_done ? 2 * pnext : t + 1;              // (after the last tile: a valid tile, unused)
             f32x16 acc = {0};
+            if constexpr (BF3) {
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                const f32x4 a = ring[kb & (PF - 1)];
-                ring[kb & (PF - 1)] = kb + PF < KB ? key_frag(t, kb + PF) : key_frag(tn, kb + PF - KB);
-                acc = mfma4(a, qf[kb], acc);
+                for (int ks = 0; ks < KS; ++ks) {
+                    const B3 a = ring3[ks & (PF - 1)];
+                    ring3[ks & (PF - 1)] = ks + PF < KS ? key_frag3(t, ks + PF) : key_frag3(tn, ks + PF - KS);
+                    acc = mfma_bf3_tr(a, qx[ks], acc);     // keys = A operand (accumulator rows), queries = B (lanes)
+                }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    const f32x4 a = ring[kb & (PF - 1)];
+                    ring[kb & (PF - 1)] = kb + PF < KB ? key_frag(t, kb + PF) : key_frag(tn, kb + PF - KB);
+                    acc = mfma4(a, qf[kb], acc);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1027,28 +1086,38 @@ __global__ __launch_bounds__(kThreads) void pool_reduce_kernel(const float* __re
 
 // slice_addr: write the neighbours as LDS addresses for edge_fused_kernel (rows < 1024) instead of row indices.
 // near_tie: one int32 per row (rows = upper bound of the row count), scratch of the exact re-ranking (C = 64 / 128).
+// planes / term_tiles: the rows as bf16x3 fragments (rownorm_kernel) - the distances then run on the bf16 matrix pipe (C = 64 / 128)
 int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, int32_t* near_tie, int B, int N, int rows, const Ragged& rg,
-               hipStream_t st, bool slice_addr = false) {
+               hipStream_t st, bool slice_addr = false, const unsigned char* planes = nullptr, int term_tiles = 0) {
     const int tiles = (N + 31) / 32;
     dim3 grid((unsigned)((B + 7) / 8 * 8 * tiles));
     const int dbg = (iq::tuning(iq::kTuneKnnDebug) & 7) | (slice_addr ? 8 : 0);
     const bool refine = iq::tuning(iq::kTuneExperiment) != 20;   // 20: float32 ranking only (A/B and tests)
     const dim3 rgrid((unsigned)((rows + 63) / 64));
-    if (C == 8) hipLaunchKernelGGL((knn_kernel<8, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
-    else if (C == 64 && !refine) hipLaunchKernelGGL((knn_kernel<64, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
-    else if (C == 128 && !refine) hipLaunchKernelGGL((knn_kernel<128, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
-    else if (C == 64) {
+    if (C == 8) hipLaunchKernelGGL((knn_kernel<8, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg, planes, term_tiles);
+    else if (C == 64 && !refine) hipLaunchKernelGGL((knn_kernel<64, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg, planes, term_tiles);
+    else if (C == 128 && !refine) hipLaunchKernelGGL((knn_kernel<128, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg, planes, term_tiles);
+    else if (planes && (C == 64 || C == 128)) {
+        // two k-steps ahead, one accumulator.  Measured and not adopted (same-box A/B, 12 000-coalition step, kNN slot 20.6 ms): four
+        // k-steps ahead 21.3 (fewer waves), even / odd k-steps on two accumulators 20.6, both 25.7 (spills); 16 queue slots 20.8
+        if (C == 64)
+            hipLaunchKernelGGL((knn_kernel<64, true, 2, 12, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg, planes, term_tiles);
+        else
+            hipLaunchKernelGGL((knn_kernel<128, true, 2, 16, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg, planes, term_tiles);
+        if (C == 64) hipLaunchKernelGGL(knn_refine_kernel<64>, rgrid, dim3(64), 0, st, x, ldx, near_tie, idx, rg, B, slice_addr ? 1 : 0, (dbg & 3) == 3);
+        else hipLaunchKernelGGL(knn_refine_kernel<128>, rgrid, dim3(64), 0, st, x, ldx, near_tie, idx, rg, B, slice_addr ? 1 : 0, (dbg & 3) == 3);
+    } else if (C == 64) {
         // 12 queue slots per lane instead of 16: 10 KB of LDS per wave, FOUR waves per SIMD (116 VGPRs) - the selection's VALU
         // work of one wave overlaps with the MFMAs of more neighbours: 28.0 -> 26.7 ms in a same-call A/B (5 = 44: 16 slots, three
         // waves).  Measured and not adopted: key fragments 2 / 4 k-blocks ahead instead of 1 (27.9 / 27.8 ms), 10 slots (27.0 ms),
         // the C = 128 kernel at three waves per SIMD (no change)
         if (iq::tuning(iq::kTuneExperiment) == 44)
-            hipLaunchKernelGGL((knn_kernel<64, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
+            hipLaunchKernelGGL((knn_kernel<64, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg, planes, term_tiles);
         else
-            hipLaunchKernelGGL((knn_kernel<64, true, 1, 12>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
+            hipLaunchKernelGGL((knn_kernel<64, true, 1, 12>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg, planes, term_tiles);
         hipLaunchKernelGGL(knn_refine_kernel<64>, rgrid, dim3(64), 0, st, x, ldx, near_tie, idx, rg, B, slice_addr ? 1 : 0, (dbg & 3) == 3);
     } else if (C == 128) {
-        hipLaunchKernelGGL((knn_kernel<128, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg);
+        hipLaunchKernelGGL((knn_kernel<128, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg, planes, term_tiles);
         hipLaunchKernelGGL(knn_refine_kernel<128>, rgrid, dim3(64), 0, st, x, ldx, near_tie, idx, rg, B, slice_addr ? 1 : 0, (dbg & 3) == 3);
     } else return iq::fail(IQ_EUNSUPPORTED, "knn: C=%d has no kernel instantiation (8, 64, 128)", C);
     return iq::check_launch("knn_kernel");
@@ -1118,7 +1187,8 @@ extern "C" size_t iq_dgcnn_workspace_bytes(int B, int N) {
     return carve_d(nullptr, B, N).bytes;
 }
 
-// Op-level kNN for tests: x (B,N,C) row-major, C in {3, 64, 128}; idx (B,N,20) int32; tmp >= B*N*84 + 16*B + 8192 bytes.
+// Op-level kNN for tests: x (B,N,C) row-major, C in {3, 64, 128}; idx (B,N,20) int32; tmp >= B*N*84 + 16*B + 8192 bytes
+// (+ B*N*C*6 for the bf16x3 operand image of C = 64 / 128: without that room the fp32-MFMA kernels run).
 extern "C" int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes, int B, int N, int C, int k,
                       iq_stream_t stream) {
     IQ_REQUIRE(x && idx && tmp, "iq_knn: null pointer");
@@ -1148,8 +1218,14 @@ extern "C" int iq_knn(const float* x, int32_t* idx, void* tmp, size_t tmp_bytes,
         hipLaunchKernelGGL(pad_xyz_kernel, dim3((r + 255) / 256), dim3(256), 0, st, x, x0, B, N, N);
         src = x0; ld = 8; cpad = 8;
     }
-    hipLaunchKernelGGL(rownorm_kernel, dim3((r + 63) / 64), dim3(kThreads), 0, st, src, ld, C, xx, rg, B);
-    int rc = launch_knn(src, ld, cpad, xx, i16, near_tie, B, N, (int)r, rg, st);
+    // room for the bf16x3 operand image behind the other scratch: the distances of the feature-space graphs run on the bf16 matrix
+    // pipe, as in the model path (5 = 22 / 20: the fp32 MFMA kernels)
+    const int knob = iq::tuning(iq::kTuneExperiment);
+    unsigned char* planes = nullptr;
+    if ((C == 64 || C == 128) && knob != 22 && knob != 20 && tmp_bytes >= iq::align_up(off, 256) + r * C * 6)
+        planes = reinterpret_cast<unsigned char*>(take(r * C * 6));
+    hipLaunchKernelGGL(rownorm_kernel, dim3((r + 63) / 64), dim3(kThreads), 0, st, src, ld, C, xx, rg, B, planes, (int)(r / 32));
+    int rc = launch_knn(src, ld, cpad, xx, i16, near_tie, B, N, (int)r, rg, st, false, planes, (int)(r / 32));
     if (rc) return rc;
     hipLaunchKernelGGL(widen_idx_kernel, dim3((r * kK + 255) / 256), dim3(256), 0, st, i16, idx, r * kK);
     if (iq::tuning(iq::kTuneKnnDebug) == 3)  // diagnostic: selection statistics into the first 24 bytes of tmp
@@ -1196,6 +1272,7 @@ int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, i
     // edge_fused_kernel for every layer or for none: the kNN kernel writes the neighbour lists in the form the consumer reads
     // (LDS addresses for the fused kernel, row indices otherwise), and GCNN's one list serves all four layers
     const bool fused = fused_path(w, N);
+    const bool refine_off = knob == 20;   // float32 ranking only: the fp32-MFMA kernels
     for (int l = 0; l < 4; ++l) {
         const int co = w->pq[l].cout / 2;
         IQ_REQUIRE(w->pq[l].cin == cin, "iq_dgcnn: layer %d expects %d inputs, got %d", l, cin, w->pq[l].cin);
@@ -1206,8 +1283,12 @@ int run_network(const iq_dgcnn_weights* w, const WsD& s, float* logits, int B, i
             if ((rc = iq::check_launch("dg_walk_kernel"))) return rc;
         } else if (l == 0 || !fixed_graph) {
             iq::ProfileSpan span(iq::kSlotPrepool, st);
-            hipLaunchKernelGGL(rownorm_kernel, dim3((rows + 63) / 64), dim3(kThreads), 0, st, src, ld, creal, s.xx, rg, B);
-            if ((rc = launch_knn(src, ld, cin, s.xx, s.idx, s.near_tie, B, N, rows, rg, st, fused))) return rc;
+            // feature-space graphs of the fused path: distances on the bf16 matrix pipe, the operand image in the upper half of the
+            // P/Q buffer (which the fused path leaves alone; the walk tables keep to the lower half).  5 = 22: the fp32 MFMA (A/B, tests)
+            const bool bf3 = fused && (cin == 64 || cin == 128) && knob != 22 && !(refine_off);
+            unsigned char* planes = bf3 ? reinterpret_cast<unsigned char*>(s.pq) + (size_t)rows * 1024 : nullptr;
+            hipLaunchKernelGGL(rownorm_kernel, dim3((rows + 63) / 64), dim3(kThreads), 0, st, src, ld, creal, s.xx, rg, B, planes, rows / 32);
+            if ((rc = launch_knn(src, ld, cin, s.xx, s.idx, s.near_tie, B, N, rows, rg, st, fused, planes, rows / 32))) return rc;
         }
         {
             iq::ProfileSpan span(iq::kSlotFstn, st);
@@ -1327,7 +1408,7 @@ extern "C" int iq_dgcnn_coalitions(const iq_dgcnn_weights* w, const float* cloud
         int16_t* sorted = (int16_t*)take((size_t)nclouds * (N + 1) * Nsl * 2);
         int16_t* srcrow = (int16_t*)take((size_t)B * Np * 2);
         use_walk = N <= kWalkMaxN && (long long)nclouds * 8 <= B && fused_path(w, N) && iq::tuning(iq::kTuneExperiment) != 12 &&
-                   off <= (size_t)B * Np * 512 * 4;
+                   off <= (size_t)B * Np * 256 * 4;     // the lower half: the upper one holds the kNN operand image (run_network)
         if (use_walk) {
             hipLaunchKernelGGL(sl_rows_kernel, dim3((Nsp + 255) / 256, nclouds), dim3(256), 0, st, clouds, centers, xs, xxs, N, Nsp);
             hipLaunchKernelGGL(sl_dist_kernel<0>, dim3(Nsp / 32, nclouds), dim3(64), 0, st, xs, xxs, dmat, Nsp);

@@ -245,7 +245,7 @@ def knn(x, k=20):
     lib = _lib.load()
     b, n, c = x.shape
     out = torch.empty((b, n, k), dtype=torch.int32, device=x.device)
-    tmp = torch.empty((b * n * 84 + 16 * b + 16384,), dtype=torch.uint8, device=x.device)
+    tmp = torch.empty((b * n * (84 + (6 * c if c in (64, 128) else 0)) + 16 * b + 16384,), dtype=torch.uint8, device=x.device)
     _lib.check(lib.iq_knn(_dev(x, torch.float32, "x"), _p(out), _p(tmp), tmp.numel(), b, n, c, k, _stream()), "iq_knn")
     return out
 

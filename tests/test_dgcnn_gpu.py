@@ -88,8 +88,9 @@ def test_knn_xyz_and_feature_space(clouds, oracle):
     assert knn_set_mismatches(got64[:1], g["knn_feat64"][:1].astype(np.int32), x1[:1]) == 0
 
 
+@pytest.mark.parametrize("arith", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("c", [64, 128])
-def test_knn_near_ties_are_ranked_by_exact_distances(c):
+def test_knn_near_ties_are_ranked_by_exact_distances(c, arith):
     """Feature-space graphs: where the float32 expanded form -|q|^2 + 2 q.k - |k|^2 cannot separate the 20th from the 21st
     nearest, knn_refine_kernel ranks by -sum (q - k)^2 in float64 (what the reference's float64 run sees).  Rows are planted
     with near-ties at the boundary (triplets of keys whose distances to a query differ by a few 1e-5 of the distance, below the float32 noise of the expanded form); the neighbour sets must
@@ -118,16 +119,20 @@ def test_knn_near_ties_are_ranked_by_exact_distances(c):
                     n_bad += 1
         return n_bad
 
-    got = hip_ops.knn(xt, 20).cpu().numpy()
-    assert all(len(set(r.tolist())) == 20 for r in got.reshape(-1, 20))
     lib = _lib.load()
+    lib.iq_set_tuning(5, 22 if arith == "fp32" else 0)    # the inner products: fp32 MFMA | three-term bf16 products (the default)
+    try:
+        got = hip_ops.knn(xt, 20).cpu().numpy()
+    finally:
+        lib.iq_set_tuning(5, 0)
+    assert all(len(set(r.tolist())) == 20 for r in got.reshape(-1, 20))
     lib.iq_set_tuning(5, 20)
     try:
         got32 = hip_ops.knn(xt, 20).cpu().numpy()
     finally:
         lib.iq_set_tuning(5, 0)
     n_dec = int(decidable.sum())
-    print("C=%d: %d of %d queries decidable; wrong neighbour sets: refined %d, float32 ranking only %d" % (c, n_dec, b * n, wrong(got), wrong(got32)))
+    print("C=%d %s: %d of %d queries decidable; wrong neighbour sets: refined %d, float32 ranking only %d" % (c, arith, n_dec, b * n, wrong(got), wrong(got32)))
     assert n_dec > 0.9 * b * n
     assert wrong(got) == 0
     assert wrong(got32) > 0
@@ -287,6 +292,43 @@ def test_fused_edgeconv_is_bitwise_the_gemm_plus_gather(cls):
         finally:
             lib.iq_set_tuning(5, 0)
         assert torch.equal(fused[0], split[0]) and torch.equal(fused[1], split[1]), knob
+
+
+def test_knn_on_the_bf16_pipe_gives_the_graphs_of_the_fp32_mfma():
+    """DGCNN's feature-space graphs with the inner products as three-term bf16 products (knn_kernel<.., BF3>, the default) against
+    the fp32-MFMA kernels (tuning key 5 = 22).  Both score within float32 rounding of the exact inner product and both hand every
+    query whose boundary they cannot decide to the same exact re-ranking, so the neighbour SETS agree and with them the logits, bit
+    for bit - on the op (random features with planted near-ties) and through the model (dense forward and compact coalitions)."""
+    from interpret_quality_amd import _lib
+    lib = _lib.load()
+    d = dev()
+    rng = np.random.default_rng(17)
+
+    def fp32(fn):
+        lib.iq_set_tuning(5, 22)
+        try:
+            return fn()
+        finally:
+            lib.iq_set_tuning(5, 0)
+    for c in (64, 128):
+        x = rng.standard_normal((3, 1024, c)).astype(np.float32) + 1.5
+        x[:, 1::4] = x[:, 0::4] + (rng.standard_normal((3, 256, c)) * 1e-4).astype(np.float32)
+        xt = torch.from_numpy(x).to(d)
+        a = np.sort(hip_ops.knn(xt, 20).cpu().numpy(), axis=-1)
+        b = np.sort(fp32(lambda: hip_ops.knn(xt, 20)).cpu().numpy(), axis=-1)
+        assert np.array_equal(a, b), (c, int((a != b).any(axis=-1).sum()))
+    model = make(DGCNN_cls)
+    clouds = torch.stack([torch.from_numpy(synth.make_cloud(i)[0]) for i in (5, 6)]).to(d)
+    rid = torch.from_numpy(rng.integers(0, 32, size=(2, 1024)).astype(np.int32)).to(d)
+    keep = [int(v) for v in rng.integers(0, 1 << 32, size=62)] + [(1 << 32) - 1, 1]
+    keep_t = hip_ops.masks_to_tensor(keep, d)
+    co_t = torch.tensor([i % 2 for i in range(len(keep))], dtype=torch.int32, device=d)
+
+    def both():
+        return (model.coalition_logits(clouds, clouds.mean(dim=1), rid, keep_t, co_t, num_regions=32).clone(),
+                model.forward_points(clouds).clone())
+    got, ref = both(), fp32(both)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
 
 
 def test_forward_on_clouds_of_more_than_1024_points(oracle):
