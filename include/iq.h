@@ -189,7 +189,7 @@ typedef struct iq_dense_layer {
     int32_t cout;
     const void* w_bf3;   /* optional (NULL: fp32 MFMA): the same weights as three bf16 terms (iq_pack_weight_bf3); wide layers
                           * (cout a multiple of 256, cin a multiple of 32) then take their products on the bf16 matrix pipe,
-                          * float32-exact */
+                          * float32-exact; cout = 256 n + 64: the first 256 n columns do, the last 64 stay on the fp32 MFMA */
 } iq_dense_layer;
 
 typedef struct iq_pointnet_weights {

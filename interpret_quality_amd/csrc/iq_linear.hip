@@ -524,7 +524,24 @@ int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* o
     if (tile_nu && (rows_per_cloud <= 0 || rows_per_cloud % 128 != 0)) tile_nu = nullptr;   // tiles must not straddle clouds
     // bf16x3 on the bf16 matrix pipe, float32-exact - for EVERY M, so that a row's result does not depend on the launch it is in
     // (5 = 57: fp32 MFMA, A/B and tests)
-    // (column blocks of 256: 320 outputs would leave the second block a quarter full, and lose to the NT = 5 fp32 tiling)
+    // (column blocks of 256: 320 outputs would leave the second block a quarter full, and lose to the NT = 5 fp32 tiling - so the
+    // whole blocks of such a layer go to the bf16 pipe and its last 64 columns to the fp32 MFMA as a layer of their own; which
+    // columns take which arithmetic depends on the layer only, never on M)
+    if (L.w_bf3 && L.cout > 256 && L.cout % 256 == 64 && L.cin % 32 == 0 && iq::tuning(iq::kTuneExperiment) != 57 &&
+        iq::tuning(iq::kTuneExperiment) != 59) {       // 5 = 59: these layers alone on the fp32 MFMA (A/B)
+        const int gx = (M + 127) / 128, gy = L.cout / 256;
+        hipLaunchKernelGGL(pn_gemm_bf3_kernel<false>, dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
+                           reinterpret_cast<const unsigned short*>(L.w_bf3), L.b, out, ldo, M, L.cin, L.cout, relu, m_dev, nullptr, gy,
+                           tile_nu, rows_per_cloud);
+        int rc = iq::check_launch("pn_gemm_bf3_kernel");
+        if (rc) return rc;
+        iq_dense_layer rest = L;                       // n-tiles 8 gy, 8 gy + 1 of the fp32 image (n-tile-major, cin / 8 fragments each)
+        rest.w = L.w + (size_t)(8 * gy) * (L.cin / 8) * (kFragBytes / 4);
+        rest.b = L.b + 256 * gy;
+        rest.cout = 64;
+        rest.w_bf3 = nullptr;
+        return launch_linear(A, lda, rest, out + 256 * gy, ldo, M, relu, st, m_dev, tile_nu, rows_per_cloud);
+    }
     if (L.w_bf3 && L.cout % 256 == 0 && L.cin % 32 == 0 && iq::tuning(iq::kTuneExperiment) != 57) {
         const int gx = (M + 127) / 128, gy = (L.cout + 255) / 256;
         hipLaunchKernelGGL(pn_gemm_bf3_kernel<false>, dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
@@ -532,13 +549,18 @@ int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* o
                            tile_nu, rows_per_cloud);
         return iq::check_launch("pn_gemm_bf3_kernel");
     }
-    if (M >= 2048 && ntiles >= 4 && L.cin % 32 == 0 && iq::tuning(iq::kTuneNoLdsGemm) == 0) {
+    if (M >= 2048 && (ntiles >= 4 || (ntiles == 2 && (M + 255) / 256 >= 2048)) && L.cin % 32 == 0 && iq::tuning(iq::kTuneNoLdsGemm) == 0) {
         const int shape = iq::tuning(iq::kTuneExperiment);   // 5 = 30: round 3's choice of shapes (A/B runs)
         if (ntiles % 10 == 0 && shape != 30 && (long long)((M + 127) / 128) * (ntiles / 10) >= 2048) {
             // 320 / 640 ... outputs: column blocks of exactly 10 tiles (NT = 5), nothing padded
             dim3 grid((M + 127) / 128, ntiles / 10);
             hipLaunchKernelGGL((pn_gemm_lds_kernel<5, false>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
                                L.cout, relu, m_dev, nullptr, tile_nu, rows_per_cloud, 0);
+        } else if (ntiles == 2 && (M + 255) / 256 >= 2048) {
+            // 64 outputs (the fp32 rest of a 320-output layer): 256-row tiles, every wave both column tiles
+            dim3 grid((M + 255) / 256, 1);
+            hipLaunchKernelGGL((pn_gemm_lds_kernel<2, false, 1>), grid, dim3(kThreads), 0, st, A, lda, L.w, L.b, out, ldo, M, L.cin,
+                               L.cout, relu, m_dev, nullptr, rows_per_cloud % 256 == 0 ? tile_nu : nullptr, rows_per_cloud, 0);
         } else if (ntiles == 4 && shape != 30 && (M + 255) / 256 >= 2048) {
             // 128 outputs: 256-row workgroup tiles, every wave all four column tiles
             dim3 grid((M + 255) / 256, 1);

@@ -333,9 +333,12 @@ def test_linear_variants_agree_and_match_fp32_reference(m, cin, cout, act):
 
 
 @pytest.mark.parametrize("m,cin,cout,act", [(5000, 512, 1024, 2), (1, 1024, 512, 1), (131, 4096, 256, 1), (40000, 128, 256, 0),
-                                             (129, 32, 768, 1), (1025, 96, 256, 2)])   # one chunk of k; three column blocks
+                                             (129, 32, 768, 1), (1025, 96, 256, 2),    # one chunk of k; three column blocks
+                                             # [r5] 256 n + 64 outputs: whole column blocks on the bf16 pipe, the last 64 columns on
+                                             # the fp32 MFMA (PointNet++ sa2's 320-output projection at its bench size; small; two blocks)
+                                             (262200, 320, 320, 1), (700, 64, 320, 0), (2100, 128, 576, 2)])
 def test_dense_layer_on_the_bf16_matrix_pipe_is_float32_exact(m, cin, cout, act):
-    """A layer that carries its weights as three bf16 terms (iq_dense_layer.w_bf3, cout % 256 == 0) takes six exact bf16 products
+    """A layer that carries its weights as three bf16 terms (iq_dense_layer.w_bf3, cout % 256 == 0 or 64) takes six exact bf16 products
     per float32 product, accumulated in float32 (pn_gemm_bf3_kernel<false>), for every row count: at least as close to the
     float64 result as the fp32-MFMA kernel (tuning key 5 = 57), equal to it within float32 rounding, and a row's result does
     not depend on the rows around it."""
@@ -363,6 +366,8 @@ def test_dense_layer_on_the_bf16_matrix_pipe_is_float32_exact(m, cin, cout, act)
     assert e_bf3 < 2e-6 and e_bf3 <= 1.5 * e_f32 + 1e-7, (e_bf3, e_f32)      # (float32 accumulation over cin terms in both)
     assert not torch.equal(got, f32) or m == 1
     assert (got - f32).abs().max().item() < 3e-6 * f32.abs().max().item()
+    if cout % 256 == 64:                                                      # the fp32 rest of a 256 n + 64 layer
+        assert torch.equal(got[:, -64:], f32[:, -64:]) and not torch.equal(got[:, :-64], f32[:, :-64])
     k = min(m, 77)
     assert torch.equal(hip_ops.linear(xt[:k].contiguous(), layer, act), got[:k])      # launch-size independent
 
