@@ -329,8 +329,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // POOL = false: the plain dense layer out (M, ldo) = act(A W^T + b) on the same tiles (launch_linear, for layers that carry
 // iq_dense_layer.w_bf3); tile_nu / rows_per_cloud as in pn_gemm_lds_kernel.
-template <bool POOL, int PROBE = 0>
-__global__ __launch_bounds__(kThreads, 2) void pn_gemm_bf3_kernel(const float* __restrict__ A, int lda,
+template <bool POOL, int PROBE = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void pn_gemm_bf3_kernel(const float* __restrict__ A, int lda,
                                                                   const unsigned short* __restrict__ w3,
                                                                   const float* __restrict__ bias, float* __restrict__ out, int ldo,
                                                                   int M, int K, int Nout, int relu,
@@ -340,6 +340,7 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_bf3_kernel(const float* _
     // wave tile: ALL 128 rows (MT = 4 m-tiles) x 64 columns (NT = 2): a weight fragment feeds four m-tiles - with 64 x 128 wave
     // tiles (two m-tiles per fragment) the weight stream alone asked the L2 for 19 TB/s at full matrix rate
     constexpr int MT = 4, NT = 2, KC = 32, ROWB = 80, PLANE = 128 * ROWB;      // bytes
+    constexpr int NTH = 64 * NW, NLD = 1024 / NTH;    // threads; (row, 4 k) items per thread and chunk
     __shared__ __attribute__((aligned(16))) unsigned char As[2][3 * PLANE];
     __shared__ float wrow[POOL ? 128 : 1];
     const int row_tiles = (M + 127) / 128;
@@ -360,26 +361,26 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_bf3_kernel(const float* _
     if (POOL && tid < 128) wrow[tid] = m0 + tid < M ? row_w[m0 + tid] : 0.f;
     const int KS = K >> 4, nchunks = K / KC;
     const int NTT = (Nout + 31) >> 5;
-    const int nt0 = (by * 4 + wave) * NT;
+    const int nt0 = (by * NW + wave) * NT;
 
     // activations: thread t owns (row, 4 k) = (e >> 3, (e & 7) * 4) for e = t + 256 i
     const WBuf ab = wbuf_make(A + (size_t)m0 * lda, lane);
-    int aoffb[4], soff[4];
+    int aoffb[NLD], soff[NLD];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = tid + kThreads * i, row = e >> 3, c4 = e & 7;
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + NTH * i, row = e >> 3, c4 = e & 7;
         aoffb[i] = (min(row, M - 1 - m0) * lda + c4 * 4) * 4;
         soff[i] = row * ROWB + c4 * 8;
     }
-    f32x4 stage[4];
+    f32x4 stage[NLD];
     auto load_chunk = [&](int kc) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NLD; ++i)
             stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ab.rsrc, aoffb[i], kc * KC * 4, 0));
     };
     auto store_chunk = [&](int buf) {     // split into the three planes
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             if constexpr (PROBE == 1) {   // timing probe: the planes without the split's arithmetic (results WRONG)
                 unsigned char* d = As[buf] + soff[i];
                 const f32x2 lo = {stage[i][0], stage[i][1]}, hi = {stage[i][2], stage[i][3]};
@@ -489,7 +490,8 @@ __global__ __launch_bounds__(kThreads, 2) void pn_gemm_bf3_kernel(const float* _
         }
         return;
     }
-    // (Round 5, measured: the staging split costs 9 % of conv5 (PROBE 1) and this epilogue 8 % (PROBE 2).  Taking the column maximum
+    // (Round 5, measured: the staging split costs 9 % of conv5 (PROBE 1) and this epilogue 8 % (PROBE 2).  NW = 8 - one workgroup
+    // of eight waves per CU on 128 rows x 512 columns, the split shared by twice as many waves: conv5 29.5 ms against 29.1, no.  Taking the column maximum
     // over the raw sums - bias and activation are increasing maps - with an additive -inf mask for the dead rows, 8 instead of 10
     // VALU instructions per value: conv5 30.0 ms against 30.0, not adopted.)
     if constexpr (PROBE == 2) {   // timing probe: no pooling epilogue (results WRONG)
