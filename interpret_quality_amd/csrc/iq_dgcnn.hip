@@ -1099,7 +1099,9 @@ int launch_knn(const float* x, int ldx, int C, const float* xx, int16_t* idx, in
     else if (C == 128 && !refine) hipLaunchKernelGGL((knn_kernel<128, false>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg, planes, term_tiles);
     else if (planes && (C == 64 || C == 128)) {
         // two k-steps ahead, one accumulator.  Measured and not adopted (same-box A/B, 12 000-coalition step, kNN slot 20.6 ms): four
-        // k-steps ahead 21.3 (fewer waves), even / odd k-steps on two accumulators 20.6, both 25.7 (spills); 16 queue slots 20.8
+        // k-steps ahead 21.3 (fewer waves), even / odd k-steps on two accumulators 20.6, both 25.7 (spills); 16 queue slots 20.8;
+        // four independent waves of one cloud per workgroup (one CU, so that one L2 read might serve several) 23.2 with their
+        // own key orders and 23.2 with a common one - the distance skeleton alone 14.1 against 13.6: not the L2 either
         if (C == 64)
             hipLaunchKernelGGL((knn_kernel<64, true, 2, 12, true>), grid, dim3(64), 0, st, x, ldx, xx, idx, near_tie, rg, B, tiles, dbg, planes, term_tiles);
         else
