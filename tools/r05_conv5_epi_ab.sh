@@ -1,5 +1,5 @@
 # Round 5: conv5's pooling epilogue with the column maximum taken over the raw sums (one add + one max per value) against the build
-# before (lib_prev_ab), one box, A B A B; GCNN (conv5 = 3/4 of its step) and DGCNN.
+# before (closed experiment: needs that build as interpret_quality_amd/lib_prev_ab/), one box, A B A B; GCNN (conv5 = 3/4 of its step), DGCNN.
 R=$GRAFT_REPO_ROOT; cd $R
 OLD=$R/interpret_quality_amd/lib_prev_ab/libiq_hip.so
 for m in gcnn dgcnn; do

@@ -12,8 +12,8 @@ SRC, DST = os.path.join(REPO, "gpurun_out", "r05f"), os.path.join(REPO, "profile
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(SRC, pattern), recursive=True)
-    return f[0] if f else None
+    f = glob.glob(os.path.join(SRC, pattern), recursive=True)       # (gpurun merges every run into the same tree: take the newest)
+    return max(f, key=os.path.getmtime) if f else None
 
 
 for tag, out in (("bench_stats", "r05_bench_kernel_stats.csv"), ("stats_pointnet2", "r05_pointnet2_kernel_stats.csv"),
