@@ -335,8 +335,8 @@ def test_linear_variants_agree_and_match_fp32_reference(m, cin, cout, act):
 @pytest.mark.parametrize("m,cin,cout,act", [(5000, 512, 1024, 2), (1, 1024, 512, 1), (131, 4096, 256, 1), (40000, 128, 256, 0),
                                              (129, 32, 768, 1), (1025, 96, 256, 2),    # one chunk of k; three column blocks
                                              # [r5] 256 n + 64 outputs: whole column blocks on the bf16 pipe, the last 64 columns on
-                                             # the fp32 MFMA (PointNet++ sa2's 320-output projection at its bench size; small; two blocks)
-                                             (262200, 320, 320, 1), (700, 64, 320, 0), (2100, 128, 576, 2)])
+                                             # the fp32 MFMA (enough rows for the 256-row tiling of the 64-column rest; small; two blocks)
+                                             (525000, 64, 320, 1), (700, 64, 320, 0), (2100, 128, 576, 2)])
 def test_dense_layer_on_the_bf16_matrix_pipe_is_float32_exact(m, cin, cout, act):
     """A layer that carries its weights as three bf16 terms (iq_dense_layer.w_bf3, cout % 256 == 0 or 64) takes six exact bf16 products
     per float32 product, accumulated in float32 (pn_gemm_bf3_kernel<false>), for every row count: at least as close to the
