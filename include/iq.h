@@ -188,7 +188,7 @@ typedef struct iq_dense_layer {
     int32_t cin;
     int32_t cout;
     const void* w_bf3;   /* optional (NULL: fp32 MFMA): the same weights as three bf16 terms (iq_pack_weight_bf3); wide layers
-                          * (cout a multiple of 256, cin a multiple of 32) then take their products on the bf16 matrix pipe,
+                          * (cout a multiple of 256, cin >= 32) then take their products on the bf16 matrix pipe,
                           * float32-exact; cout = 256 n + 64: the first 256 n columns do, the last 64 stay on the fp32 MFMA */
 } iq_dense_layer;
 
@@ -223,7 +223,8 @@ int iq_pack_weight(const float* w_host /*cout,cin*/, float* out_host, int cout, 
 /* The same weight as THREE bf16 terms (h = bf16(w), m = bf16(w - h), l = bf16(w - h - m), round to nearest even: 24 mantissa bits)
  * in the fragment order of v_mfma_f32_32x32x16_bf16: [term][n-tile][k-step of 16][lane][8], iq_packed_bf3_elems 16-bit elements.
  * A layer that is given it (iq_dgcnn_weights.conv5_bf3) takes its products on the bf16 matrix pipe - six exact bf16 products
- * per float32 product, float32 accumulation: float32 accuracy at 3/8 of the matrix cycles of the fp32 MFMA.  cin % 16 == 0. */
+ * per float32 product, float32 accumulation: float32 accuracy at 3/8 of the matrix cycles of the fp32 MFMA.  cin % 8 == 0; the image's
+ * k range is cin rounded up to a multiple of 32, zero beyond cin (the dense layer never reads A's columns there). */
 size_t iq_packed_bf3_elems(int cout, int cin);
 int iq_pack_weight_bf3(const float* w_host /*cout,cin*/, unsigned short* out_host, int cout, int cin);
 /* feat.fstn.fc3 (4096 x 256): permutes the output rows so that the layer's output vector IS the

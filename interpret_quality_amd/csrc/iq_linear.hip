@@ -329,14 +329,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // POOL = false: the plain dense layer out (M, ldo) = act(A W^T + b) on the same tiles (launch_linear, for layers that carry
 // iq_dense_layer.w_bf3); tile_nu / rows_per_cloud as in pn_gemm_lds_kernel.
-template <bool POOL, int PROBE = 0, int NW = 4>
+template <bool POOL, int PROBE = 0, int NW = 4, bool RAGGED = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void pn_gemm_bf3_kernel(const float* __restrict__ A, int lda,
                                                                   const unsigned short* __restrict__ w3,
                                                                   const float* __restrict__ bias, float* __restrict__ out, int ldo,
                                                                   int M, int K, int Nout, int relu,
                                                                   const int32_t* __restrict__ m_dev,
                                                                   const float* __restrict__ row_w, int col_blocks,
-                                                                  const int32_t* __restrict__ tile_nu, int rows_per_cloud) {
+                                                                  const int32_t* __restrict__ tile_nu, int rows_per_cloud, int Kreal) {
+    // K = the layer's inputs rounded up to a multiple of 32 (the weight image is zero there, iq_pack_weight_bf3), Kreal = the
+    // columns A really has (a multiple of 8).  RAGGED (Kreal < K; its own instantiation - the few registers it needs would spill
+    // in the others): the last chunk's columns beyond Kreal are taken as zero.
     // wave tile: ALL 128 rows (MT = 4 m-tiles) x 64 columns (NT = 2): a weight fragment feeds four m-tiles - with 64 x 128 wave
     // tiles (two m-tiles per fragment) the weight stream alone asked the L2 for 19 TB/s at full matrix rate
     constexpr int MT = 4, NT = 2, KC = 32, ROWB = 80, PLANE = 128 * ROWB;      // bytes
@@ -364,7 +367,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void pn_gemm_bf3_kernel(c
     const int nt0 = (by * NW + wave) * NT;
 
     // activations: thread t owns (row, 4 k) = (e >> 3, (e & 7) * 4) for e = t + 256 i
-    const WBuf ab = wbuf_make(A + (size_t)m0 * lda, lane);
+    // A's resource ends with the last row's last real column, so that the partial last chunk of a layer whose inputs are no
+    // multiple of 32 reads zeros there, not memory behind the matrix (rows are clamped to M - 1 below)
+    WBuf ab = wbuf_make(A + (size_t)m0 * lda, lane);
+    if constexpr (RAGGED) {
+        const long long left = ((long long)(M - 1 - m0) * lda + Kreal) * 4;
+        ab.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (size_t)m0 * lda), 0, (int)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
+    }
     int aoffb[NLD], soff[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -378,9 +387,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void pn_gemm_bf3_kernel(c
         for (int i = 0; i < NLD; ++i)
             stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ab.rsrc, aoffb[i], kc * KC * 4, 0));
     };
-    auto store_chunk = [&](int buf) {     // split into the three planes
+    auto store_chunk = [&](int buf, int kc) {     // split into the three planes
+        // the layer's partial last chunk (Kreal < K): a lane's four columns lie wholly inside or wholly outside the row - outside,
+        // whatever the load brought (the row's padding, the next row, zeros past the matrix' end: see `ab`) is replaced by zeros
+        const bool outside = RAGGED && kc == nchunks - 1 && kc * KC + (tid & 7) * 4 >= Kreal;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
+            if (RAGGED && outside) stage[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if constexpr (PROBE == 1) {   // timing probe: the planes without the split's arithmetic (results WRONG)
                 unsigned char* d = As[buf] + soff[i];
                 const f32x2 lo = {stage[i][0], stage[i][1]}, hi = {stage[i][2], stage[i][3]};
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void pn_gemm_bf3_kernel(c
     for (int j = 0; j < NT; ++j) breg[j] = bias[min((nt0 + j) * 32 + (lane & 31), Nout - 1)];
 
     load_chunk(0);
-    store_chunk(0);
+    store_chunk(0, 0);
     __syncthreads();
     const int aoff = (lane & 31) * ROWB + (lane >> 5) * 16;          // bytes: row of m-tile 0, this lane's 8 k
     for (int kc = 0; kc < nchunks; ++kc) {
@@ -464,7 +477,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void pn_gemm_bf3_kernel(c
                 for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b.h, acc[i][j], 0, 0, 0);
             }
         }
-        if (kc + 1 < nchunks) store_chunk((kc + 1) & 1);
+        if (kc + 1 < nchunks) store_chunk((kc + 1) & 1, kc + 1);
         __syncthreads();
     }
     if (!POOL) {
@@ -550,12 +563,18 @@ int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* o
     // (column blocks of 256: 320 outputs would leave the second block a quarter full, and lose to the NT = 5 fp32 tiling - so the
     // whole blocks of such a layer go to the bf16 pipe and its last 64 columns to the fp32 MFMA as a layer of their own; which
     // columns take which arithmetic depends on the layer only, never on M)
-    if (L.w_bf3 && L.cout > 256 && L.cout % 256 == 64 && L.cin % 32 == 0 && iq::tuning(iq::kTuneExperiment) != 57 &&
+    const int Kp = (L.cin + 31) & ~31;     // the bf16x3 image's k range (iq_pack_weight_bf3 pads with zero columns)
+    if (L.w_bf3 && L.cout > 256 && L.cout % 256 == 64 && L.cin >= 32 && iq::tuning(iq::kTuneExperiment) != 57 &&
         iq::tuning(iq::kTuneExperiment) != 59) {       // 5 = 59: these layers alone on the fp32 MFMA (A/B)
         const int gx = (M + 127) / 128, gy = L.cout / 256;
-        hipLaunchKernelGGL(pn_gemm_bf3_kernel<false>, dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
-                           reinterpret_cast<const unsigned short*>(L.w_bf3), L.b, out, ldo, M, L.cin, L.cout, relu, m_dev, nullptr, gy,
-                           tile_nu, rows_per_cloud);
+        if (Kp != L.cin)
+            hipLaunchKernelGGL((pn_gemm_bf3_kernel<false, 0, 4, true>), dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
+                               reinterpret_cast<const unsigned short*>(L.w_bf3), L.b, out, ldo, M, Kp, L.cout, relu, m_dev, nullptr, gy,
+                               tile_nu, rows_per_cloud, L.cin);
+        else
+            hipLaunchKernelGGL(pn_gemm_bf3_kernel<false>, dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
+                               reinterpret_cast<const unsigned short*>(L.w_bf3), L.b, out, ldo, M, Kp, L.cout, relu, m_dev, nullptr, gy,
+                               tile_nu, rows_per_cloud, L.cin);
         int rc = iq::check_launch("pn_gemm_bf3_kernel");
         if (rc) return rc;
         iq_dense_layer rest = L;                       // n-tiles 8 gy, 8 gy + 1 of the fp32 image (n-tile-major, cin / 8 fragments each)
@@ -565,11 +584,17 @@ int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* o
         rest.w_bf3 = nullptr;
         return launch_linear(A, lda, rest, out + 256 * gy, ldo, M, relu, st, m_dev, tile_nu, rows_per_cloud);
     }
-    if (L.w_bf3 && L.cout % 256 == 0 && L.cin % 32 == 0 && iq::tuning(iq::kTuneExperiment) != 57) {
+    if (L.w_bf3 && L.cout % 256 == 0 && L.cin >= 32 && iq::tuning(iq::kTuneExperiment) != 57 &&
+        !(Kp != L.cin && iq::tuning(iq::kTuneExperiment) == 59)) {      // (59 also: the layers whose inputs are no multiple of 32)
         const int gx = (M + 127) / 128, gy = (L.cout + 255) / 256;
-        hipLaunchKernelGGL(pn_gemm_bf3_kernel<false>, dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
-                           reinterpret_cast<const unsigned short*>(L.w_bf3), L.b, out, ldo, M, L.cin, L.cout, relu, m_dev, nullptr, gy,
-                           tile_nu, rows_per_cloud);
+        if (Kp != L.cin)
+            hipLaunchKernelGGL((pn_gemm_bf3_kernel<false, 0, 4, true>), dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
+                               reinterpret_cast<const unsigned short*>(L.w_bf3), L.b, out, ldo, M, Kp, L.cout, relu, m_dev, nullptr, gy,
+                               tile_nu, rows_per_cloud, L.cin);
+        else
+            hipLaunchKernelGGL(pn_gemm_bf3_kernel<false>, dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
+                               reinterpret_cast<const unsigned short*>(L.w_bf3), L.b, out, ldo, M, Kp, L.cout, relu, m_dev, nullptr, gy,
+                               tile_nu, rows_per_cloud, L.cin);
         return iq::check_launch("pn_gemm_bf3_kernel");
     }
     if (M >= 2048 && (ntiles >= 4 || (ntiles == 2 && (M + 255) / 256 >= 2048)) && L.cin % 32 == 0 && iq::tuning(iq::kTuneNoLdsGemm) == 0) {
@@ -665,15 +690,15 @@ int iq::launch_linear_pool(const float* A, int lda, const iq_dense_layer& L, flo
         if (probe == 94 || probe == 95) {
             if (probe == 94)
                 hipLaunchKernelGGL((pn_gemm_bf3_kernel<true, 1>), dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
-                                   reinterpret_cast<const unsigned short*>(w_bf3), L.b, partial, 0, M, L.cin, L.cout, relu, m_dev, row_w, gy, nullptr, 0);
+                                   reinterpret_cast<const unsigned short*>(w_bf3), L.b, partial, 0, M, L.cin, L.cout, relu, m_dev, row_w, gy, nullptr, 0, L.cin);
             else
                 hipLaunchKernelGGL((pn_gemm_bf3_kernel<true, 2>), dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
-                                   reinterpret_cast<const unsigned short*>(w_bf3), L.b, partial, 0, M, L.cin, L.cout, relu, m_dev, row_w, gy, nullptr, 0);
+                                   reinterpret_cast<const unsigned short*>(w_bf3), L.b, partial, 0, M, L.cin, L.cout, relu, m_dev, row_w, gy, nullptr, 0, L.cin);
             return iq::check_launch("pn_gemm_bf3_kernel<pool, probe>");
         }
         hipLaunchKernelGGL(pn_gemm_bf3_kernel<true>, dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
                            reinterpret_cast<const unsigned short*>(w_bf3), L.b, partial, 0, M, L.cin, L.cout, relu, m_dev, row_w, gy,
-                           nullptr, 0);
+                           nullptr, 0, L.cin);
         return iq::check_launch("pn_gemm_bf3_kernel<pool>");
     }
     if (iq::tuning(iq::kTuneExperiment) == 48) {   // 5 = 48: the (tiles, column blocks) grid of rounds 1-3 (A/B)
@@ -712,19 +737,19 @@ static inline float iq_float_of_bf16(unsigned short h) {
     return f;
 }
 
-extern "C" size_t iq_packed_bf3_elems(int cout, int cin) { return (size_t)3 * iq_padded_cout(cout) * cin; }
+extern "C" size_t iq_packed_bf3_elems(int cout, int cin) { return (size_t)3 * iq_padded_cout(cout) * ((cin + 31) & ~31); }
 
 // [term][n-tile][k-step of 16][lane][8]: lane (n & 31) + 32 ((k >> 3) & 1) holds k-aligned-8 elements of column n
 extern "C" int iq_pack_weight_bf3(const float* w, unsigned short* out, int cout, int cin) {
-    IQ_REQUIRE(w && out && cout >= 1 && cin >= 16 && cin % 16 == 0, "iq_pack_weight_bf3: cout=%d cin=%d", cout, cin);
-    const int KS = cin / 16, ntiles = iq_padded_cout(cout) / 32;
+    IQ_REQUIRE(w && out && cout >= 1 && cin >= 8 && cin % 8 == 0, "iq_pack_weight_bf3: cout=%d cin=%d", cout, cin);
+    const int KS = ((cin + 31) & ~31) / 16, ntiles = iq_padded_cout(cout) / 32;   // k padded to a multiple of 32 with zero columns
     const size_t term = (size_t)ntiles * KS * 512;
     for (int nt = 0; nt < ntiles; ++nt)
         for (int ks = 0; ks < KS; ++ks)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
                     const int n = nt * 32 + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
-                    const float v = n < cout ? w[(size_t)n * cin + k] : 0.f;
+                    const float v = n < cout && k < cin ? w[(size_t)n * cin + k] : 0.f;
                     const unsigned short h = iq_bf16_of(v);
                     const float r1 = v - iq_float_of_bf16(h);
                     const unsigned short m = iq_bf16_of(r1);

@@ -279,7 +279,7 @@ def smoothness_enum(cloud, region_id, num_regions, mode, objective, step=1e-3, e
 
 class PackedLinear:
     """A (cout,cin) weight + bias in the library's MFMA fragment order (iq_pack_weight) on the device.  bf3: also as three bf16
-    terms (iq_pack_weight_bf3) - a layer with cout % 256 == 0 (or 64: all but the last 64 columns) and cin % 32 == 0 then takes its products on the bf16 matrix pipe,
+    terms (iq_pack_weight_bf3) - a layer with cout % 256 == 0 (or 64: all but the last 64 columns) and cin >= 32 then takes its products on the bf16 matrix pipe,
     float32-exact (include/iq.h: iq_dense_layer.w_bf3)."""
 
     def __init__(self, weight, bias, device, bf3=False):

@@ -38,7 +38,7 @@ class PackedWeightsC:
             bp = np.zeros(lib.iq_padded_cout(cout), dtype=np.float32)
             bp[:cout] = b
             wt, bt = dev(out), dev(bp)
-            wide = cout % 256 == 0 and cin % 32 == 0                     # wide layers: also as three bf16 terms (include/iq.h)
+            wide = cout % 256 == 0 and cin >= 32                          # wide layers: also as three bf16 terms (include/iq.h)
             return _lib.DenseLayer(wt.data_ptr(), bt.data_ptr(), cin, cout, bf3(w32) if wide else None)
 
         def bf3(w):

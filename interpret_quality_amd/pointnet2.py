@@ -52,7 +52,7 @@ class PackedWeights2:
             bp[:cout] = b
             wt, bt = dev(out), dev(bp)
             # wide layers: also as three bf16 terms (include/iq.h); 320 outputs: the first 256 columns take them
-            wide = (cout % 256 == 0 or (cout > 256 and cout % 256 == 64)) and cin % 32 == 0
+            wide = (cout % 256 == 0 or (cout > 256 and cout % 256 == 64)) and cin >= 32
             return _lib.DenseLayer(wt.data_ptr(), bt.data_ptr(), cin, cout, bf3(w32) if wide else None)
 
         def bf3(w):

@@ -336,7 +336,10 @@ def test_linear_variants_agree_and_match_fp32_reference(m, cin, cout, act):
                                              (129, 32, 768, 1), (1025, 96, 256, 2),    # one chunk of k; three column blocks
                                              # [r5] 256 n + 64 outputs: whole column blocks on the bf16 pipe, the last 64 columns on
                                              # the fp32 MFMA (enough rows for the 256-row tiling of the 64-column rest; small; two blocks)
-                                             (525000, 64, 320, 1), (700, 64, 320, 0), (2100, 128, 576, 2)])
+                                             (525000, 64, 320, 1), (700, 64, 320, 0), (2100, 128, 576, 2),
+                                             # [r5] inputs that are no multiple of 32 (PointNet++ / PointConv sa3: 643 -> 648, 259 -> 264 columns):
+                                             # the image's k range is padded with zeros, A's columns beyond cin are never read
+                                             (3001, 648, 256, 1), (1500, 264, 256, 1), (130, 40, 256, 0)])
 def test_dense_layer_on_the_bf16_matrix_pipe_is_float32_exact(m, cin, cout, act):
     """A layer that carries its weights as three bf16 terms (iq_dense_layer.w_bf3, cout % 256 == 0 or 64) takes six exact bf16 products
     per float32 product, accumulated in float32 (pn_gemm_bf3_kernel<false>), for every row count: at least as close to the
@@ -370,6 +373,10 @@ def test_dense_layer_on_the_bf16_matrix_pipe_is_float32_exact(m, cin, cout, act)
         assert torch.equal(got[:, -64:], f32[:, -64:]) and not torch.equal(got[:, :-64], f32[:, :-64])
     k = min(m, 77)
     assert torch.equal(hip_ops.linear(xt[:k].contiguous(), layer, act), got[:k])      # launch-size independent
+    if cin % 32:                                    # nothing beyond a row's cin columns is read: NaNs behind the last row change nothing
+        buf = torch.full((m * cin + 64,), float("nan"), dtype=torch.float32, device=d)
+        buf[:m * cin] = xt.reshape(-1)
+        assert torch.equal(hip_ops.linear(buf[:m * cin].view(m, cin), layer, act), got)
 
 
 def test_bf16x3_split_loses_no_bit_of_a_float32():
