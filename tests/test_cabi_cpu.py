@@ -88,28 +88,29 @@ def test_hip_path_refuses_cpu_tensors():
         hip_ops.reward(torch.zeros(4, 10), 0)
 
 
-def test_pack_weight_bf3_terms_add_up_to_the_float32_weight_exactly():
+@pytest.mark.parametrize("cin", [48, 40, 64])
+def test_pack_weight_bf3_terms_add_up_to_the_float32_weight_exactly(cin):
     """iq_pack_weight_bf3 (host): three bf16 terms in the fragment order of v_mfma_f32_32x32x16_bf16.  h + m + l reproduces every
-    float32 weight exactly (24 mantissa bits in three terms), padded columns are zero, and the layout is the documented one."""
-    import ctypes
+    float32 weight exactly (24 mantissa bits in three terms), the image's k range is cin rounded up to a multiple of 32, padded rows
+    and padded k columns are zero, and the layout is the documented one."""
     import numpy as np
     from interpret_quality_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(0)
-    cout, cin = 40, 48
+    cout, kp = 40, (cin + 31) // 32 * 32
     w = (rng.standard_normal((cout, cin)) * np.exp(rng.uniform(-8, 8, size=(cout, cin)))).astype(np.float32)
     n = lib.iq_packed_bf3_elems(cout, cin)
-    assert n == 3 * 64 * cin
+    assert n == 3 * 64 * kp
     out = np.empty(n, dtype=np.uint16)
     assert lib.iq_pack_weight_bf3(w.ctypes.data, out.ctypes.data, cout, cin) == 0
-    terms = (out.astype(np.uint32) << 16).view(np.float32).reshape(3, 2, cin // 16, 64, 8)     # [term][n-tile][k-step][lane][j]
+    terms = (out.astype(np.uint32) << 16).view(np.float32).reshape(3, 2, kp // 16, 64, 8)     # [term][n-tile][k-step][lane][j]
     lane = np.arange(64)
-    got = np.zeros((64, cin), dtype=np.float64)
+    got = np.zeros((64, kp), dtype=np.float64)
     for nt in range(2):
-        for ks in range(cin // 16):
+        for ks in range(kp // 16):
             for j in range(8):
                 got[nt * 32 + (lane & 31), 16 * ks + 8 * (lane >> 5) + j] = terms[:, nt, ks, :, j].astype(np.float64).sum(axis=0)
-    assert np.array_equal(got[:cout], w.astype(np.float64)) and not got[cout:].any()
+    assert np.array_equal(got[:cout, :cin], w.astype(np.float64)) and not got[cout:].any() and not got[:, cin:].any()
     assert np.abs(terms[1]).max() <= np.abs(terms[0]).max() * 2.0 ** -8 and np.abs(terms[2]).max() <= np.abs(terms[0]).max() * 2.0 ** -16
 
 
