@@ -423,7 +423,8 @@ int iq_pointconv_forward(const iq_pointconv_weights* w /*host struct of device p
  * sets as the kNN kernel up to ties; masked points are interchangeable).  With at most eight source clouds sa1's MLP rows
  * - functions of (member point, centroid point) only, sa1 having no input features - come from a table of all (N+1)^2
  * pairs (0.54 GB of workspace per source cloud) and a group is 32 table rows contracted with the members' density x
- * WeightNet weights, in one kernel with the 2048 -> 128 layer behind it.  512 <= N <= 1024.  Asynchronous on `stream`. */
+ * WeightNet weights, in one kernel with the 2048 -> 128 layer behind it.  64 <= N <= 1024 (fewer than 512 points: sa1's
+ * farthest point sampling returns index 0 once the points are used up, models/pointconv.py:54-77, and so does this).  Asynchronous on `stream`. */
 size_t iq_pointconv_coalitions_workspace_bytes(int B, int nclouds, int N);
 int iq_pointconv_coalitions(const iq_pointconv_weights* w, const float* clouds, const float* centers,
                             const int32_t* region_id, const uint64_t* keep, const int32_t* cloud_of, float* logits,

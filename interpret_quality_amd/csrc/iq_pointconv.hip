@@ -1054,7 +1054,8 @@ WsC carve_c(void* base, int B, int N) {
     s.inv1 = (float*)take(b * N * 4); s.inv2 = (float*)take(b * 512 * 4); s.inv3 = (float*)take(b * 128 * 4);
     s.fps1 = (int32_t*)take(b * 512 * 4); s.fps2 = (int32_t*)take(b * 128 * 4); s.nu1 = (int32_t*)take(b * 4);
     s.nx1 = (float*)take(b * 512 * 3 * 4); s.nx2 = (float*)take(b * 128 * 3 * 4);
-    s.k8 = (float*)take(b * ((N + 31) / 32 * 32) * 8 * 4); s.q8 = (float*)take(b * 512 * 8 * 4);
+    // k8 holds the keys of both kNN launches: the N points (sa1) and the 512 sa1 centroids (sa2) - the larger of the two
+    s.k8 = (float*)take(b * (size_t)std::max((N + 31) / 32 * 32, 512) * 8 * 4); s.q8 = (float*)take(b * 512 * 8 * 4);
     s.idx1 = (int16_t*)take(b * 512 * 32 * 2); s.idx2 = (int16_t*)take(b * 128 * 64 * 2);
     s.g1 = (float*)take(b * 512 * 2048 * 4); s.l1 = (float*)take(b * 512 * 128 * 4);
     s.u2 = (float*)take(b * 512 * 128 * 4); s.g2 = (float*)take(b * 128 * 4096 * 4); s.l2 = (float*)take(b * 128 * 256 * 4);
@@ -1307,7 +1308,7 @@ size_t carve_w_rest(WsW& s, void* base, int B, int nc, int N) {
 extern "C" int iq_pointconv_forward(const iq_pointconv_weights* w, const float* xyz, float* logits, void* workspace,
                                     size_t workspace_bytes, int B, int N, iq_stream_t stream) {
     IQ_REQUIRE(w && xyz && logits, "iq_pointconv_forward: null pointer");
-    IQ_REQUIRE(B >= 0 && N >= 512 && N <= 4096, "iq_pointconv_forward: N=%d not in [512, 4096]", N);
+    IQ_REQUIRE(B >= 0 && N >= 64 && N <= 4096, "iq_pointconv_forward: N=%d not in [64, 4096]", N);
     IQ_REQUIRE(w->sa[0].nsample == 32 && w->sa[1].nsample == 64, "iq_pointconv_forward: nsample must be 32 / 64");
     if (B == 0) return IQ_OK;
     const size_t need = carve_c(nullptr, B, N).bytes;
@@ -1357,7 +1358,7 @@ extern "C" int iq_pointconv_coalitions_cached(const iq_pointconv_weights* w, con
                                               iq_stream_t stream) {
     IQ_REQUIRE(B >= 0 && nclouds >= 1, "iq_pointconv_coalitions: B=%d nclouds=%d", B, nclouds);
     IQ_REQUIRE(w && clouds && centers && region_id && (B == 0 || (keep && logits)), "iq_pointconv_coalitions: null pointer");
-    IQ_REQUIRE(N >= 512 && N <= kWalkMaxN, "iq_pointconv_coalitions: N=%d not in [512, %d]", N, kWalkMaxN);
+    IQ_REQUIRE(N >= 64 && N <= kWalkMaxN, "iq_pointconv_coalitions: N=%d not in [64, %d]", N, kWalkMaxN);
     IQ_REQUIRE(cloud_of || nclouds == 1 || nclouds == B, "iq_pointconv_coalitions: cloud_of required when 1 < nclouds != B");
     IQ_REQUIRE(w->sa[0].nsample == 32 && w->sa[1].nsample == 64, "iq_pointconv_coalitions: nsample must be 32 / 64");
     if (B == 0) return IQ_OK;

@@ -219,16 +219,17 @@ class PointConvDensityClsSsg(nn.Module):
     def coalition_logits(self, clouds, centers, region_id, keep, cloud_of=None, num_regions=None, validate=True):
         """Same call as PointNetCls.coalition_logits: logits of B coalitions given as region bit masks (the masked clouds are
         written inside the library; sa1 / sa2 groups from the source clouds' sorted neighbour lists, csrc/iq_pointconv.hip).
-        Clouds of more than 1024 points go through mask kernel + forward_points, source cloud by source cloud; fewer than 512
-        points are rejected here as in the dense forward (the architecture samples 512 centroids, models/pointconv.py:403)."""
+        Clouds of more than 1024 points go through mask kernel + forward_points, source cloud by source cloud; fewer than 64
+        points are rejected here as in the dense forward (sa2 groups 64 neighbours; below 512 points sa1's sampling repeats
+        index 0, as models/pointconv.py:54-77 does)."""
         if validate:
             hip_ops.check_index_range(region_id, 0, int(num_regions) if num_regions else 64, "region_id")
         eng = self.engine()
         nc, b = clouds.shape[0], keep.shape[0]
         if cloud_of is None and nc not in (1, b):
             raise _lib.IqError("cloud_of is required when 1 < number of clouds != number of coalitions")
-        if clouds.shape[1] < 512:
-            raise _lib.IqError("PointConv needs at least 512 points per cloud (sa1 samples 512 centroids), got %d" % clouds.shape[1])
+        if clouds.shape[1] < 64:
+            raise _lib.IqError("PointConv needs at least 64 points per cloud (sa2 groups 64 neighbours), got %d" % clouds.shape[1])
         if clouds.shape[1] > 1024:   # beyond the library's coalition entry: mask kernel + forward, source cloud by source cloud
             which = cloud_of if cloud_of is not None else (torch.zeros(b, dtype=torch.int32, device=keep.device) if nc == 1
                                                           else torch.arange(b, dtype=torch.int32, device=keep.device))

@@ -193,3 +193,37 @@ def test_sa2_on_the_bf16_matrix_pipe_equals_the_fp32_mfma_kernel_to_rounding(mod
     assert not torch.equal(got, ref)                                      # a different kernel did run
     for a, b in ((got, ref), (dense, dense_ref)):
         assert (a - b).abs().max().item() < 3e-6 * b.abs().max().item()
+
+
+@pytest.mark.parametrize("n", [300, 64])
+def test_clouds_of_fewer_than_512_points(model, n):
+    """sa1 samples 512 centroids: on a smaller cloud the reference's farthest point sampling returns index 0 once every point is
+    taken (models/pointconv.py:54-77) and the 512 - N duplicate centroids take part in sa2 like any other point.  Dense forward
+    against the CPU oracle; the coalition path (groups from the source cloud's lists) against the oracle on the masked clouds and
+    against the dense forward on them."""
+    from oracle import ref_cpu as O
+    d = dev()
+    sd = synth.to_torch(synth.pointconv_state_dict(0))
+    orc = O.PointConvOracle(sd)
+
+    def oracle_logits(x):                                        # x (B,N,3) on the CPU
+        out = orc(x.permute(0, 2, 1).contiguous())
+        return (out[0] if isinstance(out, tuple) else out).numpy()
+    pts = torch.from_numpy(np.stack([synth.make_cloud(20 + i, num_points=n)[0] for i in range(3)]))
+    want = oracle_logits(pts)
+    got = model.forward_points(pts.to(d)).cpu().numpy()
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-4
+    rng = np.random.default_rng(n)
+    clouds = pts[:2].to(d)
+    rid = torch.from_numpy(rng.integers(0, 8, size=(2, n)).astype(np.int32)).to(d)
+    centers = clouds.mean(dim=1)
+    keep = [255, 0, 1, 3, 0x0f, 0xf0, 0x55, 0xaa, 254, 127]
+    cloud_of = [i % 2 for i in range(len(keep))]
+    got = model.coalition_logits(clouds, centers, rid, hip_ops.masks_to_tensor(keep, d),
+                                 torch.tensor(cloud_of, dtype=torch.int32, device=d), num_regions=8).cpu().numpy()
+    masked = torch.cat([hip_ops.mask_coalitions(clouds[c].contiguous(), rid[c].contiguous(), hip_ops.masks_to_tensor([k], d),
+                                                centers[c].contiguous()) for k, c in zip(keep, cloud_of)])
+    dense = model.forward_points(masked).cpu().numpy()
+    assert np.abs(got - dense).max() / np.abs(dense).max() < 2e-5
+    want = oracle_logits(masked.cpu())
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-4
