@@ -503,9 +503,17 @@ __global__ __launch_bounds__(64, BF3 ? (C == 128 ? 2 : 3) : C == 128 ? (QCAP < 1
         double v21 = top.v[0];
 #pragma unroll
         for (int q = 1; q <= kK; ++q) v21 = fmin(v21, top.v[q]);
+        // (ONE slot trades places with the last: with fewer than 21 live rows several slots hold -inf, and replacing them all
+        // copied the last slot's row into each of them - the ranks behind it, which decide the cut when fewer than 20 points are
+        // masked, were then counted against the copies.  Found on 21- to 32-point clouds in round 5.)
         const double last = top.v[kK];
+        bool moved = false;
 #pragma unroll
-        for (int q = 0; q < kK; ++q) top.v[q] = top.v[q] == v21 ? last : top.v[q];
+        for (int q = 0; q < kK; ++q) {
+            const bool hit = !moved && top.v[q] == v21;
+            top.v[q] = hit ? last : top.v[q];
+            moved = moved || hit;
+        }
         top.v[kK] = v21;
         double t20 = top.v[0];
 #pragma unroll

@@ -54,8 +54,20 @@ __global__ __launch_bounds__(kThreads) void mask_rows_kernel(MaskArgs a) {
         keep_s[threadIdx.x] = g < a.rows ? row_keep(a, g) : 0ull;
     }
     __syncthreads();
-    const int nvec = a.N * 3 / 4;
     const size_t cloud_floats = (size_t)a.N * 3;
+    if (a.N & 3) {   // a cloud size that is no multiple of 4: the output clouds are not 16-byte aligned - element by element
+        for (int e = threadIdx.x; e < a.N * 3; e += kThreads) {
+            int p, ch;
+            if (a.channel_first) { ch = e / a.N; p = e - ch * a.N; }
+            else                 { p = e / 3;    ch = e - p * 3; }
+            const float x = a.cloud[p * 3 + ch], c = a.center[ch];
+            const int rid = a.region_id[p];
+            for (int r = 0; r < kRowsPerWg && g0 + r < a.rows; ++r)
+                a.out[(size_t)(g0 + r) * cloud_floats + e] = iq::keep_bit(keep_s[r], rid) ? x : c;
+        }
+        return;
+    }
+    const int nvec = a.N * 3 / 4;
     for (int e4 = threadIdx.x; e4 < nvec; e4 += kThreads) {
         float x[4], c[4];
         int rid[4];
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(256) void index_range_kernel(const int32_t* __restr
 int launch(MaskArgs a, iq_stream_t stream) {
     if (a.rows == 0) return IQ_OK;
     IQ_REQUIRE(a.cloud && a.region_id && a.center && a.out, "mask: null pointer");
-    IQ_REQUIRE(a.N > 0 && a.N % 4 == 0 && a.N <= IQ_MAX_POINTS, "mask: N=%d must be a multiple of 4 in (0,%d]", a.N, IQ_MAX_POINTS);
+    IQ_REQUIRE(a.N > 0 && a.N <= IQ_MAX_POINTS, "mask: N=%d not in (0,%d]", a.N, IQ_MAX_POINTS);
     IQ_REQUIRE(a.R >= 0 && a.R <= IQ_MAX_REGIONS, "mask: R=%d out of range", a.R);
     const int grid = (a.rows + kRowsPerWg - 1) / kRowsPerWg;
     hipLaunchKernelGGL(mask_rows_kernel, dim3(grid), dim3(kThreads), 0, iq::as_stream(stream), a);

@@ -400,3 +400,32 @@ def test_layer1_graph_from_source_lists_is_bitwise_the_knn_kernel(cls):
     finally:
         lib.iq_set_tuning(5, 0)
     assert torch.equal(walk, knn)
+
+
+@pytest.mark.parametrize("n", [21, 24, 32])
+def test_coalitions_on_clouds_of_barely_more_than_k_points(n, oracle):
+    """Tiny clouds: a coalition then has fewer than 21 distinct rows AND fewer than 20 masked points, i.e. the top-21 list of the
+    feature-space kNN holds empty slots while the cut behind the weighted centre row is decided by ranks.  (Round 5 found the
+    exchange of the 21st slot copying a row into every empty slot there.)  Coalition path against the dense forward on the
+    masked clouds and against the CPU oracle, DGCNN and GCNN."""
+    d = dev()
+    rng = np.random.default_rng(n)
+    pts = torch.from_numpy(np.stack([synth.make_cloud(40 + i, num_points=n)[0] for i in range(2)]))
+    clouds = pts.to(d)
+    rid = torch.from_numpy(rng.integers(0, 8, size=(2, n)).astype(np.int32)).to(d)
+    centers = clouds.mean(dim=1)
+    keep = [255, 0, 1, 3, 0x0f, 0xf0, 0x55, 0xaa, 254, 127]
+    cloud_of = [i % 2 for i in range(len(keep))]
+    masked = torch.cat([hip_ops.mask_coalitions(clouds[c].contiguous(), rid[c].contiguous(), hip_ops.masks_to_tensor([k], d),
+                                                centers[c].contiguous()) for k, c in zip(keep, cloud_of)])
+    sd = synth.to_torch(synth.dgcnn_state_dict(0))
+    for cls, fixed in ((DGCNN_cls, False), (GCNN_cls, True)):
+        model = make(cls)
+        got = model.coalition_logits(clouds, centers, rid, hip_ops.masks_to_tensor(keep, d),
+                                     torch.tensor(cloud_of, dtype=torch.int32, device=d), num_regions=8).cpu().numpy()
+        dense = model.forward_points(masked).cpu().numpy()
+        with torch.no_grad():
+            want = oracle.dgcnn_forward(sd, masked.cpu().permute(0, 2, 1).contiguous(), 20, fixed).numpy()
+        scale = np.abs(want).max()
+        assert np.abs(got - dense).max() / scale < 2e-5, (cls.__name__, np.abs(got - dense).max(axis=1) / scale)
+        assert np.abs(got - want).max() / scale < 1e-4 and np.abs(dense - want).max() / scale < 1e-4

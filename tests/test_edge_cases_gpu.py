@@ -90,9 +90,9 @@ def test_abi_error_reporting(model):
     lib = _lib.load()
     d = dev()
     # unsupported sizes -> negative code + message, nothing is launched
-    cloud = torch.zeros((1022, 3), device=d)
-    with pytest.raises(_lib.IqError, match="multiple of 4"):
-        hip_ops.mask_shapley(cloud, torch.zeros(1022, dtype=torch.int32, device=d), torch.zeros((1, 8), dtype=torch.int32, device=d),
+    cloud = torch.zeros((4100, 3), device=d)
+    with pytest.raises(_lib.IqError, match="not in"):
+        hip_ops.mask_shapley(cloud, torch.zeros(4100, dtype=torch.int32, device=d), torch.zeros((1, 8), dtype=torch.int32, device=d),
                              torch.zeros(3, device=d))
     with pytest.raises(_lib.IqError, match="label"):
         hip_ops.reward(torch.zeros((4, 10), device=d), 10)

@@ -66,6 +66,31 @@ def test_mask_shapley_bitwise(oracle, num_regions, bs, channel_first):
     assert torch.equal(got.cpu(), want)
 
 
+@pytest.mark.parametrize("n", [1022, 130, 21])
+@pytest.mark.parametrize("channel_first", [False, True])
+def test_masks_on_cloud_sizes_that_are_no_multiple_of_four(oracle, n, channel_first):
+    """mask_data_batch (tools/final_common.py:37-60) takes any cloud; so do the mask kernels (their float4 stores need N % 4 == 0,
+    other sizes go element by element): Shapley prefixes and explicit coalitions, both layouts, bit for bit."""
+    rng = np.random.default_rng(n)
+    pts, _ = synth.make_cloud(3, num_points=n)
+    data = torch.from_numpy(pts).unsqueeze(0)
+    region_id = torch.from_numpy(rng.integers(0, 8, size=n).astype(np.int64))
+    orders = synth.make_orders(3, 8, seed=n)
+    center = torch.mean(data, dim=1).squeeze()
+    want = oracle.shapley_masked_batch(data, center, orders, region_id)                 # (3 * 9, n, 3)
+    d = dev()
+    got = hip_ops.mask_shapley(data[0].to(d), hip_ops.as_i32(region_id, d), hip_ops.as_i32(orders, d), center.to(d),
+                               channel_first=channel_first)
+    assert torch.equal(got.cpu(), want.permute(0, 2, 1).contiguous() if channel_first else want)
+    keep = [0, 255, 1, 0x5a, 0x81]
+    got = hip_ops.mask_coalitions(data[0].to(d), hip_ops.as_i32(region_id, d), hip_ops.masks_to_tensor(keep, d), center.to(d),
+                                  channel_first=channel_first).cpu()
+    for row, k in zip(got, keep):
+        kept = torch.tensor([(k >> int(r)) & 1 for r in region_id], dtype=torch.bool)
+        ref = torch.where(kept[:, None], data[0], center[None, :])
+        assert torch.equal(row, ref.t().contiguous() if channel_first else ref)
+
+
 def test_mask_shapley_golden_checksum(oracle):
     import hashlib
     g = load_golden("pointnet_shapley_R32.npz")
