@@ -3,12 +3,12 @@
 range), region counts 1-64, 1-3 source clouds and 1-11 random coalitions (plus the full and the empty one) - the coalition path
 against the dense forward on the masked clouds (both HIP) and, for small or sampled cases, against the CPU oracle.
 
-    python tools/fuzz_sizes.py [seed] [seconds]
+    python tests/fuzz_sizes.py [seed] [seconds]
 
 Prints every case that raises or disagrees (> 1e-4 of the logit range; DGCNN against the float32 oracle: 1e-2, its feature-space kNN
 cannot be held tighter than the reference holds itself) and a final count.  Round 5: 600 cases found two bugs that
 only small clouds reach (PointConv below 512 points, DGCNN coalitions on 21- to 38-point clouds); 269 cases clean afterwards.
-Test infrastructure: imports oracle/ (never used by the product path)."""
+Test infrastructure (lives under tests/ because it imports oracle/); not collected by pytest."""
 import sys, os, argparse, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
