@@ -66,10 +66,30 @@ while time.time() - t0 < budget:
         o_phi, o_logits = O.shap_sampling_all_regions_batch(om, data_c, torch.tensor([label]), want_rid, orders, s, bs, r, sm)
         e_l = np.abs(logits.cpu().numpy() - o_logits.numpy()).max() / np.abs(o_logits.numpy()).max()
         e_p = np.abs(phi - o_phi).max() / max(np.abs(o_phi).max(), 1e-6)
+        # loop C on the same cloud: random pairs, contexts of a random order m (final_point_binary_interaction_logits.py:15-70)
+        e_i = 0.0
+        if r >= 2:
+            from interpret_quality_amd import interaction
+            npair, nctx = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+            m_order = int(rng.integers(0, r - 1))
+            pairs = np.stack([rng.choice(r, size=2, replace=False) for _ in range(npair)]).astype(np.int64)
+            ctxs = np.stack([np.stack([rng.choice([x for x in range(r) if x not in pr], size=m_order, replace=False) for _ in range(nctx)])
+                             for pr in pairs]).astype(np.int64).reshape(npair, nctx, m_order)
+            args.interaction_batch_size = int(rng.integers(1, 4))
+            got_i = interaction.compute_order_interaction_logits(model, data, want_rid, pairs, ctxs, args).cpu()
+            want_i = O.compute_order_interaction_logits(om, data_c, want_rid, pairs, ctxs, args.interaction_batch_size)
+            e_i = float(np.abs(got_i.numpy() - want_i.numpy()).max() / np.abs(want_i.numpy()).max())
+            # the reduction ((v0 + v3) - v1) - v2 (final_cal_interactions.py:28-36) on the SAME logits: a difference of nearly equal
+            # rewards, each within 2e-6 of the reference's (exp / log differ in the last bits; the reduction itself is bit-exact given v:
+            # tests/test_hip_parity.py) - so an absolute bar, which still catches a wrong row order
+            iv = interaction.compute_order_interaction(want_i.to(d), lbl, args)
+            ow = O.compute_order_interaction(want_i, torch.tensor([label]), sm)
+            if np.abs(np.asarray(iv) - ow).max() > 2e-4:
+                e_i = max(e_i, 1.0)
         ncase += 1
-        if bad_geom or e_l > 1e-4 or e_p > 2e-3 or not np.isfinite(phi).all():
+        if bad_geom or e_l > 1e-4 or e_p > 2e-3 or e_i > 1e-4 or not np.isfinite(phi).all():
             nbad += 1
-            print("MISMATCH %s: geometry %s, logits %.2g, phi %.2g (max |phi| %.3g)" % (desc, "BAD" if bad_geom else "ok", e_l, e_p, np.abs(o_phi).max()), flush=True)
+            print("MISMATCH %s: geometry %s, logits %.2g, phi %.2g (max |phi| %.3g), interaction logits %.2g" % (desc, "BAD" if bad_geom else "ok", e_l, e_p, np.abs(o_phi).max(), e_i), flush=True)
     except Exception as e:   # noqa: BLE001 - a probe: report and go on
         ncase += 1
         print("%s: %s: %s" % (desc, type(e).__name__, str(e)[:160]), flush=True)
