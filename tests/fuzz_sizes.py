@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Randomised size probe (GPU): for every model family, random cloud sizes (a cluster just above each family's minimum and the whole
-range), region counts 1-64, 1-3 source clouds and 1-11 random coalitions (plus the full and the empty one) - the coalition path
+range), region counts 1-64, 1-9 source clouds and 1-89 random coalitions (plus the full and the empty one) - the coalition path
 against the dense forward on the masked clouds (both HIP) and, for small or sampled cases, against the CPU oracle.
 
     python tests/fuzz_sizes.py [seed] [seconds]
 
 Prints every case that raises or disagrees (> 1e-4 of the logit range; DGCNN against the float32 oracle: 1e-2, its feature-space kNN
 cannot be held tighter than the reference holds itself) and a final count.  Round 5: 600 cases found two bugs that
-only small clouds reach (PointConv below 512 points, DGCNN coalitions on 21- to 38-point clouds); 269 cases clean afterwards.
+only small clouds reach (PointConv below 512 points, DGCNN coalitions on 21- to 38-point clouds); 575 cases clean afterwards.
 Test infrastructure (lives under tests/ because it imports oracle/); not collected by pytest."""
 import sys, os, argparse, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -46,8 +46,8 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 60:
     lo, hi = lims[name]
     n = int(rng.choice([rng.integers(lo, min(hi, lo + 40)), rng.integers(lo, hi)]))
     R = int(rng.choice([1, 2, 8, 32, 64]))
-    nc = int(rng.choice([1, 2, 3]))
-    b = int(rng.integers(1, 12))
+    nc = int(rng.choice([1, 2, 3, 9]))                    # (more than 8 source clouds: no pair tables)
+    b = int(rng.choice([rng.integers(1, 12), rng.integers(12, 90)]))   # (8 coalitions per source cloud and more: groups from the source lists)
     m, sd = get(name)
     try:
         pts = torch.from_numpy(np.stack([synth.make_cloud(int(rng.integers(0, 1000)), num_points=n)[0] for _ in range(nc)]))
