@@ -27,7 +27,7 @@ namespace {
 
 constexpr int kFeat = IQ_NUM_FEAT;
 constexpr int kMC = 64;        // rows per chunk
-constexpr int kMaxN = 1024;    // points per cloud supported by the chain kernel
+constexpr int kMaxN = 4096;    // points per cloud supported by the chain kernel (= IQ_MAX_POINTS; row lists are uint16)
 constexpr int kThreads = 256;
 constexpr int kRowCap = kMaxN + kMC;  // row-list stride per item (uint16)
 

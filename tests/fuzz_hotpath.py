@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised probe of the hot path's boundary (GPU): shap_sampling_all_regions_batch, compute_order_interaction_logits and the
-region assignment behind them on random cloud sizes (8-1024), region counts (1-64), permutation counts / batch sizes, both softmax
+region assignment behind them on random cloud sizes (8-4096), region counts (1-64), permutation counts / batch sizes, both softmax
 types - the HIP path (interpret_quality_amd.final_common / interaction) against the CPU oracle's restatement of the reference loop.
 
     python tests/fuzz_hotpath.py [seed] [seconds]
@@ -42,7 +42,7 @@ def get(name):
 t0, ncase, nbad = time.time(), 0, 0
 while time.time() - t0 < budget:
     name = "pointnet"       # (the oracle's loop unpacks PointNet's output tuple: tools/final_common.py:36)
-    n = int(rng.integers(8 if name == "pointnet" else 128, 1025 if name == "pointnet" else 400))
+    n = int(rng.integers(8 if name == "pointnet" else 128, 4097 if name == "pointnet" else 400))
     r = int(rng.choice([1, 2, 3, 8, 17, 32, 64]))
     bs = int(rng.choice([1, 2, 3]))
     s = bs * int(rng.integers(1, 4))

@@ -109,8 +109,8 @@ def test_abi_error_reporting(model):
     assert rc == -3 and b"workspace" in lib.iq_last_error()
     # N beyond the fused kernel's row-list capacity
     rc = lib.iq_pointnet_coalitions(ctypes.byref(eng.weights.struct), p(clouds), None, p(rid), None, None, p(logits), None,
-                                    p(tiny), tiny.numel(), 1, 1, 2048, 1, 0, None)
-    assert rc == -1 and b"N=2048" in lib.iq_last_error()
+                                    p(tiny), tiny.numel(), 1, 1, 4097, 1, 0, None)
+    assert rc == -1 and b"N=4097" in lib.iq_last_error()
     # wrong dtype / device at the Python boundary
     with pytest.raises(_lib.IqError):
         hip_ops.fps(torch.zeros((1, 64, 3), dtype=torch.float64, device=d), 8)
@@ -301,7 +301,7 @@ def test_a_coalitions_logits_do_not_depend_on_the_batch_it_travels_in(name):
     assert torch.equal(logits(keep[39:]), full[39:])
 
 
-@pytest.mark.parametrize("n", [100, 1000])
+@pytest.mark.parametrize("n", [100, 1000, 2500, 4096])      # (beyond 1024 points since round 5: the row lists hold up to IQ_MAX_POINTS)
 def test_pointnet_coalitions_on_odd_cloud_sizes(model, oracle_model, n):
     """N that is not a multiple of the 64-row chunk / 32-row MFMA tile (the reference accepts any N)."""
     pts, _ = synth.make_cloud(12, num_points=n)
