@@ -40,7 +40,7 @@ def oracle_logits(name, sd, x_bn3):
         return O.dgcnn_forward(sd, x, 20, name == "gcnn").numpy()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t0 = time.time(); ncase = nbad = 0
-lims = {"pointnet": (8, 4096), "pointnet2": (128, 1100), "pointconv": (64, 1100), "dgcnn": (21, 1100), "gcnn": (21, 1100)}
+lims = {"pointnet": (8, 4096), "pointnet2": (128, 2100), "pointconv": (64, 2100), "dgcnn": (21, 2100), "gcnn": (21, 2100)}
 while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 60:
     name = list(lims)[ncase % 5]
     lo, hi = lims[name]
