@@ -38,7 +38,7 @@ int iq_profile_read_work(int slot, double* total_ms, int* launches, double* tota
  * 6 = 16-row member blocks per workgroup of the PointNet++ grouped kernel (0 = default 12); 7 = 1: layer 2 of the grouped bf16x3
  * kernels with untransposed tiles (round 4's epilogue; bit-identical results, tools/r05_tr_ab.sh).  Key 5 also selects the fp32-MFMA
  * twins of the bf16x3 kernels (53 / 54 / 56 / 57; 22: DGCNN's feature-space kNN distances; 59: only round 5's additions, the
- * dense layers with 256 n + 64 outputs or with inputs that are no multiple of 32)
+ * dense layers with 256 n + 64 outputs, with inputs that are no multiple of 32, and the split-K layer)
  * and timing probes whose results are WRONG: 91 / 92 / 93 in the chain kernel's layer 3, 94 / 95 in conv5's pooled GEMM (no split
  * arithmetic when the activations are staged / no pooling epilogue; tools/r05_conv5_probe.sh). */
 int iq_set_tuning(int key, int value);

@@ -329,14 +329,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // POOL = false: the plain dense layer out (M, ldo) = act(A W^T + b) on the same tiles (launch_linear, for layers that carry
 // iq_dense_layer.w_bf3); tile_nu / rows_per_cloud as in pn_gemm_lds_kernel.
-template <bool POOL, int PROBE = 0, int NW = 4, bool RAGGED = false>
+template <bool POOL, int PROBE = 0, int NW = 4, bool RAGGED = false, bool SPLITK = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void pn_gemm_bf3_kernel(const float* __restrict__ A, int lda,
                                                                   const unsigned short* __restrict__ w3,
                                                                   const float* __restrict__ bias, float* __restrict__ out, int ldo,
                                                                   int M, int K, int Nout, int relu,
                                                                   const int32_t* __restrict__ m_dev,
                                                                   const float* __restrict__ row_w, int col_blocks,
-                                                                  const int32_t* __restrict__ tile_nu, int rows_per_cloud, int Kreal) {
+                                                                  const int32_t* __restrict__ tile_nu, int rows_per_cloud, int Kreal,
+                                                                  int chunks_per_split) {
+    // SPLITK (few rows, very long K: launch_linear_splitk): workgroup row blockIdx.y takes chunks_per_split 32-k chunks and writes
+    // its RAW partial sums to out + blockIdx.y * M * ldo; bias and activation belong to splitk_reduce_kernel.
     // K = the layer's inputs rounded up to a multiple of 32 (the weight image is zero there, iq_pack_weight_bf3), Kreal = the
     // columns A really has (a multiple of 8).  RAGGED (Kreal < K; its own instantiation - the few registers it needs would spill
     // in the others): the last chunk's columns beyond Kreal are taken as zero.
@@ -363,6 +366,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void pn_gemm_bf3_kernel(c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (POOL && tid < 128) wrow[tid] = m0 + tid < M ? row_w[m0 + tid] : 0.f;
     const int KS = K >> 4, nchunks = K / KC;
+    int kc0 = 0, kc1 = nchunks;
+    if constexpr (SPLITK) {
+        kc0 = blockIdx.y * chunks_per_split;
+        kc1 = min(nchunks, kc0 + chunks_per_split);
+        if (kc0 >= kc1) return;
+        out += (size_t)blockIdx.y * M * ldo;
+    }
     const int NTT = (Nout + 31) >> 5;
     const int nt0 = (by * NW + wave) * NT;
 
@@ -433,7 +443,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void pn_gemm_bf3_kernel(c
     };
     B3 ring[2][NT];                        // two k-steps (3 072 matrix cycles) ahead
 #pragma unroll
-    for (int j = 0; j < NT; ++j) { ring[0][j] = wfrag(j, 0); ring[1][j] = wfrag(j, 1); }
+    for (int j = 0; j < NT; ++j) { ring[0][j] = wfrag(j, 2 * kc0); ring[1][j] = wfrag(j, 2 * kc0 + 1); }
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -443,11 +453,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void pn_gemm_bf3_kernel(c
 #pragma unroll
     for (int j = 0; j < NT; ++j) breg[j] = bias[min((nt0 + j) * 32 + (lane & 31), Nout - 1)];
 
-    load_chunk(0);
-    store_chunk(0, 0);
+    load_chunk(kc0);
+    store_chunk(kc0 & 1, kc0);
     __syncthreads();
     const int aoff = (lane & 31) * ROWB + (lane >> 5) * 16;          // bytes: row of m-tile 0, this lane's 8 k
-    for (int kc = 0; kc < nchunks; ++kc) {
+    for (int kc = kc0; kc < kc1; ++kc) {
         const unsigned char* as = As[kc & 1] + aoff;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void pn_gemm_bf3_kernel(c
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int e = 0; e < 3; ++e) a[i][e] = *reinterpret_cast<const bf16x8*>(as + e * PLANE + i * 32 * ROWB + s * 32);
-            if (s == 0 && kc + 1 < nchunks) load_chunk(kc + 1);     // the next chunk's rows, behind this chunk's first operands
+            if (s == 0 && kc + 1 < kc1) load_chunk(kc + 1);         // the next chunk's rows, behind this chunk's first operands
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const B3 b = ring[s][j];                            // (k-step parity = s: two steps per chunk)
@@ -477,7 +487,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void pn_gemm_bf3_kernel(c
                 for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b.h, acc[i][j], 0, 0, 0);
             }
         }
-        if (kc + 1 < nchunks) store_chunk((kc + 1) & 1, kc + 1);
+        if (kc + 1 < kc1) store_chunk((kc + 1) & 1, kc + 1);
         __syncthreads();
     }
     if (!POOL) {
@@ -493,9 +503,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void pn_gemm_bf3_kernel(c
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + i * 32 + c_row(r, lane);
                     if (row < M) {
-                        float v = acc[i][j][r] + b;
-                        if (relu == 1) v = fmaxf(v, 0.f);
-                        else if (relu == 2) v = v > 0.f ? v : 0.2f * v;
+                        float v = acc[i][j][r];
+                        if constexpr (!SPLITK) {
+                            v += b;
+                            if (relu == 1) v = fmaxf(v, 0.f);
+                            else if (relu == 2) v = v > 0.f ? v : 0.2f * v;
+                        }
                         out[(size_t)row * ldo + col] = v;
                     }
                 }
@@ -570,11 +583,11 @@ int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* o
         if (Kp != L.cin)
             hipLaunchKernelGGL((pn_gemm_bf3_kernel<false, 0, 4, true>), dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
                                reinterpret_cast<const unsigned short*>(L.w_bf3), L.b, out, ldo, M, Kp, L.cout, relu, m_dev, nullptr, gy,
-                               tile_nu, rows_per_cloud, L.cin);
+                               tile_nu, rows_per_cloud, L.cin, 0);
         else
             hipLaunchKernelGGL(pn_gemm_bf3_kernel<false>, dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
                                reinterpret_cast<const unsigned short*>(L.w_bf3), L.b, out, ldo, M, Kp, L.cout, relu, m_dev, nullptr, gy,
-                               tile_nu, rows_per_cloud, L.cin);
+                               tile_nu, rows_per_cloud, L.cin, 0);
         int rc = iq::check_launch("pn_gemm_bf3_kernel");
         if (rc) return rc;
         iq_dense_layer rest = L;                       // n-tiles 8 gy, 8 gy + 1 of the fp32 image (n-tile-major, cin / 8 fragments each)
@@ -590,11 +603,11 @@ int iq::launch_linear(const float* A, int lda, const iq_dense_layer& L, float* o
         if (Kp != L.cin)
             hipLaunchKernelGGL((pn_gemm_bf3_kernel<false, 0, 4, true>), dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
                                reinterpret_cast<const unsigned short*>(L.w_bf3), L.b, out, ldo, M, Kp, L.cout, relu, m_dev, nullptr, gy,
-                               tile_nu, rows_per_cloud, L.cin);
+                               tile_nu, rows_per_cloud, L.cin, 0);
         else
             hipLaunchKernelGGL(pn_gemm_bf3_kernel<false>, dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
                                reinterpret_cast<const unsigned short*>(L.w_bf3), L.b, out, ldo, M, Kp, L.cout, relu, m_dev, nullptr, gy,
-                               tile_nu, rows_per_cloud, L.cin);
+                               tile_nu, rows_per_cloud, L.cin, 0);
         return iq::check_launch("pn_gemm_bf3_kernel");
     }
     if (M >= 2048 && (ntiles >= 4 || (ntiles == 2 && (M + 255) / 256 >= 2048)) && L.cin % 32 == 0 && iq::tuning(iq::kTuneNoLdsGemm) == 0) {
@@ -667,6 +680,18 @@ int iq::launch_linear_splitk(const float* A, int lda, const iq_dense_layer& L, f
     const int kbs = 64;
     const int splits = (KB + kbs - 1) / kbs;
     if (splits <= 1 || ntiles < 4) return launch_linear(A, lda, L, out, ldo, M, relu, st);
+    if (L.w_bf3 && L.cout % 256 == 0 && L.cin % 32 == 0 && iq::tuning(iq::kTuneExperiment) != 57 && iq::tuning(iq::kTuneExperiment) != 59) {
+        // the same 512-k splits on the bf16 matrix pipe (three-term products): 16 chunks of 32 k per workgroup row
+        IQ_REQUIRE(scratch && (size_t)splits * M * L.cout <= scratch_floats, "split-K dense layer: scratch %zu floats < %zu",
+                   scratch_floats, (size_t)splits * M * L.cout);
+        const int gx = (M + 127) / 128, gy = L.cout / 256;
+        hipLaunchKernelGGL((pn_gemm_bf3_kernel<false, 0, 4, false, true>), dim3((unsigned)((gx + 7) / 8 * 8 * gy), (unsigned)splits), dim3(kThreads), 0,
+                           st, A, lda, reinterpret_cast<const unsigned short*>(L.w_bf3), L.b, scratch, L.cout, M, L.cin, L.cout, 0, nullptr, nullptr,
+                           gy, nullptr, 0, L.cin, kbs * 8 / 32);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * L.cout + 255) / 256)), dim3(256), 0, st, scratch, L.b,
+                           out, ldo, M, L.cout, splits, relu);
+        return iq::check_launch("pn_gemm_bf3_kernel<split-K>");
+    }
     IQ_REQUIRE(scratch && (size_t)splits * M * L.cout <= scratch_floats, "split-K dense layer: scratch %zu floats < %zu",
                scratch_floats, (size_t)splits * M * L.cout);
     dim3 grid((M + 127) / 128, (ntiles + 3) / 4, splits);
@@ -690,15 +715,15 @@ int iq::launch_linear_pool(const float* A, int lda, const iq_dense_layer& L, flo
         if (probe == 94 || probe == 95) {
             if (probe == 94)
                 hipLaunchKernelGGL((pn_gemm_bf3_kernel<true, 1>), dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
-                                   reinterpret_cast<const unsigned short*>(w_bf3), L.b, partial, 0, M, L.cin, L.cout, relu, m_dev, row_w, gy, nullptr, 0, L.cin);
+                                   reinterpret_cast<const unsigned short*>(w_bf3), L.b, partial, 0, M, L.cin, L.cout, relu, m_dev, row_w, gy, nullptr, 0, L.cin, 0);
             else
                 hipLaunchKernelGGL((pn_gemm_bf3_kernel<true, 2>), dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
-                                   reinterpret_cast<const unsigned short*>(w_bf3), L.b, partial, 0, M, L.cin, L.cout, relu, m_dev, row_w, gy, nullptr, 0, L.cin);
+                                   reinterpret_cast<const unsigned short*>(w_bf3), L.b, partial, 0, M, L.cin, L.cout, relu, m_dev, row_w, gy, nullptr, 0, L.cin, 0);
             return iq::check_launch("pn_gemm_bf3_kernel<pool, probe>");
         }
         hipLaunchKernelGGL(pn_gemm_bf3_kernel<true>, dim3((unsigned)((gx + 7) / 8 * 8 * gy)), dim3(kThreads), 0, st, A, lda,
                            reinterpret_cast<const unsigned short*>(w_bf3), L.b, partial, 0, M, L.cin, L.cout, relu, m_dev, row_w, gy,
-                           nullptr, 0, L.cin);
+                           nullptr, 0, L.cin, 0);
         return iq::check_launch("pn_gemm_bf3_kernel<pool>");
     }
     if (iq::tuning(iq::kTuneExperiment) == 48) {   // 5 = 48: the (tiles, column blocks) grid of rounds 1-3 (A/B)
