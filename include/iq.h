@@ -42,11 +42,14 @@ enum {
 #define IQ_MAX_POINTS 4096
 #define IQ_NUM_FEAT 1024
 
-/* ABI version: 100 * major + minor.  101 (round 4/5): every weight descriptor (iq_dense_layer, iq_pointnet_weights, ...) gained
+/* ABI version: 100 * major + minor.  101 (round 4): every weight descriptor (iq_dense_layer, iq_pointnet_weights, ...) gained
  * optional `*_bf3` fields (weights split into three bf16 terms, iq_pack_weight_bf3).  Descriptors MUST be zero-initialised before
  * they are filled (`iq_dense_layer l = {0};` / memset): a NULL *_bf3 pointer selects the float32-MFMA kernels, a non-NULL one is
- * dereferenced on the device.  A client built against an older header must be rebuilt (the structs grew). */
-#define IQ_ABI_VERSION 101
+ * dereferenced on the device.  A client built against an older header must be rebuilt (the structs grew).
+ * 102 (round 5): no layout change; a bf16x3 weight image (iq_pack_weight_bf3) now has its k range padded to a multiple of 32 (only images of layers with cin % 32 == 16 differ, and no kernel consumed those before), dense
+ * layers take the image for any cin >= 32 and cout = 256 n or 256 n + 64, iq_knn uses a larger tmp when it is given one, PointNet
+ * takes clouds of up to IQ_MAX_POINTS points and PointConv of 64 and more. */
+#define IQ_ABI_VERSION 102
 int iq_version(void);
 const char* iq_last_error(void);
 

@@ -133,7 +133,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 101   # IQ_ABI_VERSION of include/iq.h these struct layouts were written for
+ABI_VERSION = 102   # IQ_ABI_VERSION of include/iq.h these struct layouts were written for
 
 
 def lib_path():
