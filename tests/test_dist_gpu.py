@@ -105,13 +105,33 @@ def test_bench_runs_its_collectives_on_rccl_with_a_forced_single_rank_group(tmp_
     assert len([ln for ln in r2.stdout.splitlines() if ln.startswith("{")]) == 1
 
 
-def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
+@pytest.fixture(scope="module")
+def bench_runs(tmp_path_factory):
+    """Four bench.py launches the tests below look at, started together as two chains (most of a launch is process start-up; at most
+    four GPU processes beside this one): [self-launched 2-rank weak run, 2-rank sweep mode] and [strong scaling on 1 rank, on 2]."""
+    bench = os.path.join(REPO, "bench.py")
+    root = tmp_path_factory.mktemp("bench_runs")
+    dirs = {k: root / k for k in ("self", "sweep", "strong1", "strong2")}
+    for v in dirs.values():
+        v.mkdir()
+    weak = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "1", "--perms", "100", "--strong-steps", "0", "--profile-steps", "1"]
+    sweep = ["--gpus", "2", "--scaling", "sweep", "--sweep-models", "pointnet,gcnn", "--sweep-datasets", "modelnet10", "--sweep-clouds", "1",
+             "--sweep-reduced", "1"]
+    strong = lambda n: ["--gpus", str(n), "--scaling", "strong", "--steps", "1", "--warmup", "0", "--repeats", "1"]
+    (r_self, r_sweep), (r_s1, r_s2) = _run_chains([
+        [([sys.executable, bench] + weak, dirs["self"], _env(IQ_REHEARSAL="1")),
+         ([sys.executable, bench] + sweep, dirs["sweep"], _env(IQ_REHEARSAL="1"))],
+        [([sys.executable, bench] + strong(1), dirs["strong1"], _env()),
+         (_torchrun(2, 29615) + [bench] + strong(2), dirs["strong2"], _env(IQ_REHEARSAL="1"))]])
+    return {"self": r_self, "sweep": r_sweep, 1: r_s1, 2: r_s2, "dirs": dirs}
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher(bench_runs, tmp_path):
     """Plain `python bench.py --gpus 2 --steps 2` - no torchrun: the script becomes the parent of two fresh ranks before it
     touches the GPU (interpret_quality_amd/launch.py), picks a free rendezvous port, and rank 0's ONE JSON line comes back
     through it (rehearsal: both ranks on cuda:0, gloo collectives)."""
     bench = os.path.join(REPO, "bench.py")
-    flags = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "1", "--perms", "100", "--strong-steps", "0", "--profile-steps", "1"]
-    r = _run([sys.executable, bench] + flags, tmp_path, _env(IQ_REHEARSAL="1"))
+    r = bench_runs["self"]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
@@ -126,13 +146,10 @@ def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
     assert r.returncode != 0 and "this node shows" in r.stderr
 
 
-def test_bench_sweep_mode_emits_a_configs4_line_on_two_self_launched_ranks(tmp_path):
+def test_bench_sweep_mode_emits_a_configs4_line_on_two_self_launched_ranks(bench_runs):
     """`python bench.py --gpus 2 --scaling sweep`: BASELINE configs[4] in the bench schema (two families x one dataset x one cloud
     at rehearsal sizes here), units pulled from the shared queue."""
-    bench = os.path.join(REPO, "bench.py")
-    flags = ["--gpus", "2", "--scaling", "sweep", "--sweep-models", "pointnet,gcnn", "--sweep-datasets", "modelnet10", "--sweep-clouds", "1",
-             "--sweep-reduced", "1"]
-    r = _run([sys.executable, bench] + flags, tmp_path, _env(IQ_REHEARSAL="1"))
+    r = bench_runs["sweep"]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
@@ -140,19 +157,14 @@ def test_bench_sweep_mode_emits_a_configs4_line_on_two_self_launched_ranks(tmp_p
     assert d["coalitions"] == sum(p["coalitions"] for p in d["phases"].values()) > 0
     assert set(d["phases"]) == {"0_fps", "A_shapley", "B_gen_pair", "C_interaction"}
     assert len(d["phases"]["A_shapley"]["per_rank"]) == 2 and "configs[4]" in d["config"]["workload"]
-    assert not (tmp_path / "checkpoints").exists()      # the sweep ran in a scratch directory
+    assert not (bench_runs["dirs"]["sweep"] / "checkpoints").exists()      # the sweep ran in a scratch directory
 
 
 @pytest.mark.parametrize("ranks", [1, 2])
-def test_bench_strong_scaling_mode_shards_one_cloud_over_the_ranks(tmp_path, ranks):
+def test_bench_strong_scaling_mode_shards_one_cloud_over_the_ranks(bench_runs, ranks):
     """`bench.py --scaling strong`: the rotation sweep (poses sharded) and one interaction setting (pairs sharded) of ONE cloud
-    through the drivers' own sharded code, 1 process and 2 ranks (rehearsal: both on cuda:0, gloo)."""
-    bench = os.path.join(REPO, "bench.py")
-    flags = ["--gpus", str(ranks), "--scaling", "strong", "--steps", "1", "--warmup", "0", "--repeats", "1"]
-    if ranks == 1:
-        r = _run([sys.executable, bench] + flags, tmp_path, _env())
-    else:
-        r = _run(_torchrun(2, 29615) + [bench] + flags, tmp_path, _env(IQ_REHEARSAL="1"))
+    through the drivers' own sharded code, 1 process and 2 ranks (rehearsal: both on cuda:0, gloo; under torchrun)."""
+    r = bench_runs[ranks]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
