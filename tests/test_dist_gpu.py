@@ -107,23 +107,27 @@ def test_bench_runs_its_collectives_on_rccl_with_a_forced_single_rank_group(tmp_
 
 @pytest.fixture(scope="module")
 def bench_runs(tmp_path_factory):
-    """Four bench.py launches the tests below look at, started together as two chains (most of a launch is process start-up; at most
-    four GPU processes beside this one): [self-launched 2-rank weak run, 2-rank sweep mode] and [strong scaling on 1 rank, on 2]."""
+    """Five bench.py launches the tests below look at, started together as two chains (most of a launch is process start-up; at most
+    four GPU processes beside this one): [self-launched 2-rank weak run, 2-rank sweep mode] and [strong scaling on 1 rank, on 2, the
+    driver's torchrun form at N = 2]."""
     bench = os.path.join(REPO, "bench.py")
     root = tmp_path_factory.mktemp("bench_runs")
-    dirs = {k: root / k for k in ("self", "sweep", "strong1", "strong2")}
+    dirs = {k: root / k for k in ("self", "sweep", "strong1", "strong2", "n2")}
     for v in dirs.values():
         v.mkdir()
     weak = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "1", "--perms", "100", "--strong-steps", "0", "--profile-steps", "1"]
     sweep = ["--gpus", "2", "--scaling", "sweep", "--sweep-models", "pointnet,gcnn", "--sweep-datasets", "modelnet10", "--sweep-clouds", "1",
              "--sweep-reduced", "1"]
     strong = lambda n: ["--gpus", str(n), "--scaling", "strong", "--steps", "1", "--warmup", "0", "--repeats", "1"]
-    (r_self, r_sweep), (r_s1, r_s2) = _run_chains([
+    # the driver's own launch form for N = 2 (torchrun, every default leg of the line on)
+    n2 = ["--gpus", "2", "--steps", "1", "--warmup", "1", "--repeats", "1", "--perms", "100", "--sustained-s", "0.3"]
+    (r_self, r_sweep), (r_s1, r_s2, r_n2) = _run_chains([
         [([sys.executable, bench] + weak, dirs["self"], _env(IQ_REHEARSAL="1")),
          ([sys.executable, bench] + sweep, dirs["sweep"], _env(IQ_REHEARSAL="1"))],
         [([sys.executable, bench] + strong(1), dirs["strong1"], _env()),
-         (_torchrun(2, 29615) + [bench] + strong(2), dirs["strong2"], _env(IQ_REHEARSAL="1"))]])
-    return {"self": r_self, "sweep": r_sweep, 1: r_s1, 2: r_s2, "dirs": dirs}
+         (_torchrun(2, 29615) + [bench] + strong(2), dirs["strong2"], _env(IQ_REHEARSAL="1")),
+         (_torchrun(2, 29591) + [bench] + n2, dirs["n2"], _env(IQ_BENCH_REHEARSAL="1"))]])
+    return {"self": r_self, "sweep": r_sweep, 1: r_s1, 2: r_s2, "n2": r_n2, "dirs": dirs}
 
 
 def test_bench_starts_its_own_ranks_without_a_launcher(bench_runs, tmp_path):
@@ -144,6 +148,20 @@ def test_bench_starts_its_own_ranks_without_a_launcher(bench_runs, tmp_path):
     # a node with fewer GPUs than ranks is refused up front (no rehearsal switch), before anything is started
     r = subprocess.run([sys.executable, bench, "--gpus", "64"], cwd=str(tmp_path), env=_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "this node shows" in r.stderr
+
+
+def test_bench_n2_rehearsal_prints_one_valid_json_line(bench_runs):
+    """bench.py's N > 1 path as the driver starts it (torchrun, --gpus 2): barrier + max over ranks + all-gather of the logits with 2
+    ranks on the one GPU (IQ_BENCH_REHEARSAL=1: gloo instead of RCCL; the number itself means nothing)."""
+    r = bench_runs["n2"]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["unit"] == "coalitions/s" and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    # the same line carries the path's own shard axes at this rank count (one cloud's pose sweep + interaction setting sharded)
+    st = d["strong_scaling"]
+    assert st["value"] > 0 and st["steps"] == 1 and "poses sharded" in st["config"]["workload"] and 0.0 <= st["gather"]["share_of_step"] < 1.0
 
 
 def test_bench_sweep_mode_emits_a_configs4_line_on_two_self_launched_ranks(bench_runs):

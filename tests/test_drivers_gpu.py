@@ -334,28 +334,6 @@ def test_two_rank_pipelines_write_the_same_artefacts_as_one_process(tmp_path, mo
     assert np.array_equal(one["inter"], two["inter"]) and one["inter"].shape[0] == 4
 
 
-def test_bench_n2_rehearsal_prints_one_valid_json_line(tmp_path):
-    """bench.py's N > 1 path (barrier + max over ranks + all-gather of the logits) with 2 ranks on the one GPU
-    (IQ_BENCH_REHEARSAL=1: gloo instead of RCCL; the number itself means nothing)."""
-    import json
-    import subprocess
-    import sys
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, IQ_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29591", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1",
-                        "--warmup", "1", "--repeats", "1", "--perms", "100", "--sustained-s", "0.3"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["unit"] == "coalitions/s" and d["value"] > 0 and d["scaling"] == "weak"
-    assert d["vs_baseline"] is None and {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
-    # the same line carries the path's own shard axes at this rank count (one cloud's pose sweep + interaction setting sharded)
-    st = d["strong_scaling"]
-    assert st["value"] > 0 and st["steps"] == 1 and "poses sharded" in st["config"]["workload"] and 0.0 <= st["gather"]["share_of_step"] < 1.0
-
-
 def test_checkpoint_file_in_the_references_layout_is_loaded(tmp_path, monkeypatch):
     """tools/final_util.py:236-262: a `.t7` saved from an nn.DataParallel model (keys prefixed with `module.`) at the
     reference's path is what the drivers load; --synthetic only stands in when the file is absent."""
